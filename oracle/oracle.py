@@ -1,0 +1,392 @@
+"""Python face of the CPU oracle.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may import this
+module.  It is the *checker* for the HIP product path (fbpic_amd/), never a fallback:
+nothing under fbpic_amd/ imports it.
+
+Particle and spectral kernels live in fbpic_oracle.c (restated from the reference's
+Numba CPU kernels, file:line cited there).  The two vendor-library operations of the
+reference CPU path are restated here with the libraries the reference itself falls back
+to: `np.fft` for the z-FFT (fbpic/fields/spectral_transform/fourier.py:98-168, forward
+unnormalised / backward 1/Nz) and `np.dot` for the Hankel GEMM
+(fbpic/fields/spectral_transform/hankel.py:206-212, 237-243).
+
+Parity PINNED: tests/test_oracle_golden.py checks every entry point against
+tests/golden/*.npz, produced by the real reference via oracle/capture_golden.py.
+"""
+import ctypes
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+c_d = ctypes.c_double
+c_i = ctypes.c_int
+c_l = ctypes.c_long
+c_p = ctypes.c_void_p
+
+
+def build():
+    """Compile libfbpic_oracle.so with gcc (idempotent)."""
+    so = os.path.join(_HERE, 'libfbpic_oracle.so')
+    src = os.path.join(_HERE, 'fbpic_oracle.c')
+    if (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(['make', '-C', _HERE, 'libfbpic_oracle.so'],
+                              stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(build())
+        _LIB.orc_max_threads.restype = c_i
+        from scipy.constants import c, epsilon_0, mu_0
+        _LIB.orc_set_constants(c_d(c), c_d(epsilon_0), c_d(mu_0))
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(c_p)
+
+
+def _f64(a):
+    assert a.dtype == np.float64 and a.flags.c_contiguous
+    return _p(a)
+
+
+def _c128(a):
+    assert a.dtype == np.complex128 and a.flags.c_contiguous
+    return _p(a)
+
+
+def max_threads():
+    return lib().orc_max_threads()
+
+
+def set_threads(n):
+    lib().orc_set_threads(c_i(n))
+
+
+# ----------------------------------------------------------------- particles
+def push_x(x, y, z, ux, uy, uz, inv_gamma, dt, px=1., py=1., pz=1.):
+    lib().orc_push_x(c_l(x.size), _f64(x), _f64(y), _f64(z), _f64(ux), _f64(uy), _f64(uz),
+                     _f64(inv_gamma), c_d(dt), c_d(px), c_d(py), c_d(pz))
+
+
+def push_p(ux, uy, uz, inv_gamma, Ex, Ey, Ez, Bx, By, Bz, q, m, dt):
+    lib().orc_push_p(c_l(ux.size), _f64(ux), _f64(uy), _f64(uz), _f64(inv_gamma),
+                     _f64(Ex), _f64(Ey), _f64(Ez), _f64(Bx), _f64(By), _f64(Bz),
+                     c_d(q), c_d(m), c_d(dt))
+
+
+def shift_periodic(z, zmin, zmax):
+    lib().orc_shift_periodic(c_l(z.size), _f64(z), c_d(zmin), c_d(zmax))
+
+
+def gather(shape, fused, x, y, z, rmax_gather, invdz, zmin, Nz, invdr, rmin, Nr, grids,
+           Ex, Ey, Ez, Bx, By, Bz):
+    """grids: list over modes of 6 complex (Nz,Nr) arrays Er,Et,Ez,Br,Bt,Bz."""
+    Nm = len(grids)
+    flat = [g for gm in grids for g in gm]
+    for g in flat:
+        assert g.shape == (Nz, Nr)
+    ptrs = (c_p * (6 * Nm))(*[_c128(g) for g in flat])
+    lib().orc_gather(c_i(1 if shape == 'linear' else 3), c_i(int(fused)), c_i(Nm),
+                     c_l(x.size), _f64(x), _f64(y), _f64(z), c_d(rmax_gather),
+                     c_d(invdz), c_d(zmin), c_i(Nz), c_d(invdr), c_d(rmin), c_i(Nr), ptrs,
+                     _f64(Ex), _f64(Ey), _f64(Ez), _f64(Bx), _f64(By), _f64(Bz))
+
+
+def cell_index(x, y, z, invdz, zmin, Nz, invdr, rmin, Nr):
+    out = np.empty(x.size, dtype=np.int32)
+    lib().orc_cell_index(c_l(x.size), _f64(x), _f64(y), _f64(z), c_d(invdz), c_d(zmin),
+                         c_i(Nz), c_d(invdr), c_d(rmin), c_i(Nr), _p(out))
+    return out
+
+
+def deposit_rho_global(shape, Nm, x, y, z, w, q, invdz, zmin, Nz, invdr, rmin, Nr,
+                       beta0, betah, nthreads=1, glob=None):
+    if glob is None:
+        glob = np.zeros((nthreads, Nm, Nz + 4, Nr + 4), dtype=np.complex128)
+    lib().orc_deposit_rho(c_i(1 if shape == 'linear' else 3), c_i(Nm), c_l(x.size),
+                          _f64(x), _f64(y), _f64(z), _f64(w), c_d(q),
+                          c_d(invdz), c_d(zmin), c_i(Nz), c_d(invdr), c_d(rmin), c_i(Nr),
+                          _c128(glob), c_i(nthreads), _f64(beta0), _f64(betah))
+    return glob
+
+
+def deposit_J_global(shape, Nm, x, y, z, w, q, ux, uy, uz, inv_gamma, invdz, zmin, Nz,
+                     invdr, rmin, Nr, beta0, betah, nthreads=1, globs=None):
+    if globs is None:
+        globs = [np.zeros((nthreads, Nm, Nz + 4, Nr + 4), dtype=np.complex128) for _ in range(3)]
+    lib().orc_deposit_J(c_i(1 if shape == 'linear' else 3), c_i(Nm), c_l(x.size),
+                        _f64(x), _f64(y), _f64(z), _f64(w), c_d(q),
+                        _f64(ux), _f64(uy), _f64(uz), _f64(inv_gamma),
+                        c_d(invdz), c_d(zmin), c_i(Nz), c_d(invdr), c_d(rmin), c_i(Nr),
+                        _c128(globs[0]), _c128(globs[1]), _c128(globs[2]), c_i(nthreads),
+                        _f64(beta0), _f64(betah))
+    return globs
+
+
+def sum_reduce(glob, m, reduced):
+    nthreads, Nm, Nz4, Nr4 = glob.shape
+    lib().orc_sum_reduce(_c128(glob), c_i(nthreads), c_i(Nm), c_i(Nz4 - 4), c_i(Nr4 - 4),
+                         c_i(m), _c128(reduced))
+
+
+def divide_by_volume(F, invvol):
+    Nz, Nr = F.shape
+    lib().orc_divide_by_volume(_c128(F), _f64(invvol), c_i(Nz), c_i(Nr))
+
+
+# ------------------------------------------------------------------ spectral
+def filter_(F, fz, fr):
+    Nz, Nr = F.shape
+    lib().orc_filter(_c128(F), _f64(fz), _f64(fr), c_i(Nz), c_i(Nr))
+
+
+def rt_to_pm(r, t, p, m):
+    lib().orc_rt_to_pm(_c128(r), _c128(t), _c128(p), _c128(m), c_l(r.size))
+
+
+def pm_to_rt(p, m, r, t):
+    lib().orc_pm_to_rt(_c128(p), _c128(m), _c128(r), _c128(t), c_l(r.size))
+
+
+def correct_currents_curlfree(rho_prev, rho_next, Jp, Jm, Jz, kz, kr, inv_k2, inv_dt):
+    Nz, Nr = Jp.shape
+    lib().orc_correct_currents_curlfree(_c128(rho_prev), _c128(rho_next), _c128(Jp), _c128(Jm),
+                                        _c128(Jz), _f64(kz), _f64(kr), _f64(inv_k2),
+                                        c_d(inv_dt), c_i(Nz), c_i(Nr))
+
+
+def push_eb_standard(Ep, Em, Ez, Bp, Bm, Bz, Jp, Jm, Jz, rho_prev, rho_next,
+                     rho_prev_coef, rho_next_coef, j_coef, C, S_w, kr, kz, dt, use_true_rho):
+    Nz, Nr = Ep.shape
+    lib().orc_push_eb_standard(_c128(Ep), _c128(Em), _c128(Ez), _c128(Bp), _c128(Bm), _c128(Bz),
+                               _c128(Jp), _c128(Jm), _c128(Jz), _c128(rho_prev), _c128(rho_next),
+                               _f64(rho_prev_coef), _f64(rho_next_coef), _f64(j_coef),
+                               _f64(C), _f64(S_w), _f64(kr), _f64(kz), c_d(dt),
+                               c_i(int(use_true_rho)), c_i(Nz), c_i(Nr))
+
+
+def fft_z(a):
+    """fourier.py:104-126: unnormalised forward DFT along axis 0."""
+    return np.fft.fft(a, axis=0)
+
+
+def ifft_z(a):
+    """fourier.py:128-168: backward DFT along axis 0 including the 1/Nz factor."""
+    return np.fft.ifft(a, axis=0)
+
+
+def dht(F, mat):
+    """hankel.py:182-243: complex (Nz,Nr) -> real (2Nz,Nr) [re rows, then im rows],
+    one real matrix product with the (Nr,Nr) matrix, back to complex."""
+    Nz = F.shape[0]
+    a = np.empty((2 * Nz, F.shape[1]))
+    a[:Nz] = F.real
+    a[Nz:] = F.imag
+    o = np.dot(a, mat)
+    return o[:Nz] + 1.j * o[Nz:]
+
+
+class Transformer:
+    """spectral_transform/spectral_transformer.py:89-223 for one azimuthal mode.
+    mats = dict(M0, invM0, Mp, invMp, Mm, invMm) from the host-side DHT setup."""
+
+    def __init__(self, mats):
+        self.m = mats
+
+    def interp2spect_scal(self, a):
+        return dht(fft_z(a), self.m['M0'])
+
+    def spect2interp_scal(self, a):
+        return ifft_z(dht(a, self.m['invM0']))
+
+    def interp2spect_vect(self, r, t):
+        br = fft_z(r)
+        bt = fft_z(t)
+        p = np.empty_like(br)
+        mm = np.empty_like(br)
+        rt_to_pm(np.ascontiguousarray(br), np.ascontiguousarray(bt), p, mm)
+        return dht(p, self.m['Mp']), dht(mm, self.m['Mm'])
+
+    def spect2interp_vect(self, p, mm):
+        bp = np.ascontiguousarray(dht(p, self.m['invMp']))
+        bm = np.ascontiguousarray(dht(mm, self.m['invMm']))
+        r = np.empty_like(bp)
+        t = np.empty_like(bp)
+        pm_to_rt(bp, bm, r, t)
+        return ifft_z(r), ifft_z(t)
+
+
+INTERP = ['Er', 'Et', 'Ez', 'Br', 'Bt', 'Bz', 'Jr', 'Jt', 'Jz', 'rho']
+SPECT = ['Ep', 'Em', 'Ez', 'Bp', 'Bm', 'Bz', 'Jp', 'Jm', 'Jz', 'rho_prev', 'rho_next']
+
+
+class OracleSim:
+    """Whole PIC cycle on the CPU, restating Simulation.step / .deposit /
+    .exchange_and_damp_EB (fbpic/main.py:346-769) for the single-domain, z-periodic,
+    standard-PSATD, curl-free configuration (C1/C2/C5).
+
+    tables: host-side setup arrays (the product's fbpic_amd host code builds them and
+    they are themselves pinned against tests/golden/grid_setup.npz):
+      per mode m: M0,invM0,Mp,invMp,Mm,invMm, kz(Nz,Nr), kr(Nz,Nr), inv_k2, filter_z,
+      filter_r, C, S_w, j_coef, rho_prev_coef, rho_next_coef, invvol, ruyten (Nr+1)
+    species: list of dicts with q, m, and the 8 particle arrays.
+    """
+
+    def __init__(self, Nz, Nr, Nm, zmin, zmax, rmax, dt, shape, tables, species,
+                 nthreads=1, filter_currents=True):
+        self.Nz, self.Nr, self.Nm = Nz, Nr, Nm
+        self.zmin, self.zmax, self.rmax = zmin, zmax, rmax
+        self.dz = (zmax - zmin) / Nz
+        self.dr = rmax / Nr
+        self.invdz = 1. / self.dz
+        self.invdr = 1. / self.dr
+        self.dt = dt
+        self.shape = shape
+        self.t = tables
+        self.nthreads = nthreads
+        self.filter_currents = filter_currents
+        self.trans = [Transformer(tables[m]) for m in range(Nm)]
+        z = lambda: np.zeros((Nz, Nr), dtype=np.complex128)  # noqa: E731
+        self.interp = [{k: z() for k in INTERP} for _ in range(Nm)]
+        self.spect = [{k: z() for k in SPECT} for _ in range(Nm)]
+        self.species = species
+        for s in species:
+            n = s['x'].size
+            for k in ('Ex', 'Ey', 'Ez', 'Bx', 'By', 'Bz'):
+                s.setdefault(k, np.zeros(n))
+        self.time = 0.
+        self.iteration = 0
+        self.glob = [np.zeros((nthreads, Nm, Nz + 4, Nr + 4), dtype=np.complex128)
+                     for _ in range(3)]
+
+    # -- transforms (fields/fields.py:313-429)
+    def interp2spect(self, ft):
+        for m in range(self.Nm):
+            it, sp, tr = self.interp[m], self.spect[m], self.trans[m]
+            if ft in ('E', 'B', 'J'):
+                sp[ft + 'z'][:] = tr.interp2spect_scal(it[ft + 'z'])
+                sp[ft + 'p'][:], sp[ft + 'm'][:] = tr.interp2spect_vect(it[ft + 'r'], it[ft + 't'])
+            else:
+                sp[ft][:] = tr.interp2spect_scal(it['rho'])
+
+    def spect2interp(self, ft):
+        for m in range(self.Nm):
+            it, sp, tr = self.interp[m], self.spect[m], self.trans[m]
+            if ft in ('E', 'B', 'J'):
+                it[ft + 'z'][:] = tr.spect2interp_scal(sp[ft + 'z'])
+                it[ft + 'r'][:], it[ft + 't'][:] = tr.spect2interp_vect(sp[ft + 'p'], sp[ft + 'm'])
+            else:
+                it['rho'][:] = tr.spect2interp_scal(sp[ft])
+
+    def partial_roundtrip(self, ft):
+        """spect2partial_interp followed by partial_interp2spect
+        (fields/fields.py:431-536; main.py:741-766): iFFT then FFT along z."""
+        for m in range(self.Nm):
+            sp = self.spect[m]
+            for k in (ft + 'z', ft + 'p', ft + 'm'):
+                sp[k][:] = fft_z(ifft_z(sp[k]))
+
+    # -- deposition (main.py:588-670)
+    def deposit(self, fieldtype):
+        t = self.t
+        Nm, Nz, Nr = self.Nm, self.Nz, self.Nr
+        ruy = 'ruyten_linear' if self.shape == 'linear' else 'ruyten_cubic'
+        b0 = t[0][ruy]
+        bh = t[1 if Nm > 1 else 0][ruy]
+        geom = (self.invdz, self.zmin, Nz, self.invdr, 0., Nr)
+        if fieldtype.startswith('rho'):
+            for m in range(Nm):
+                self.interp[m]['rho'][:] = 0.
+            self.glob[0][:] = 0.
+            for s in self.species:
+                if s['q'] == 0:
+                    continue
+                deposit_rho_global(self.shape, Nm, s['x'], s['y'], s['z'], s['w'], s['q'],
+                                   *geom, b0, bh, self.nthreads, self.glob[0])
+            for m in range(Nm):
+                sum_reduce(self.glob[0], m, self.interp[m]['rho'])
+                divide_by_volume(self.interp[m]['rho'], t[m]['invvol'])
+        else:
+            for g in self.glob:
+                g[:] = 0.
+            for m in range(Nm):
+                for k in ('Jr', 'Jt', 'Jz'):
+                    self.interp[m][k][:] = 0.
+            for s in self.species:
+                if s['q'] == 0:
+                    continue
+                deposit_J_global(self.shape, Nm, s['x'], s['y'], s['z'], s['w'], s['q'],
+                                 s['ux'], s['uy'], s['uz'], s['inv_gamma'], *geom, b0, bh,
+                                 self.nthreads, self.glob)
+            for m in range(Nm):
+                for i, k in enumerate(('Jr', 'Jt', 'Jz')):
+                    sum_reduce(self.glob[i], m, self.interp[m][k])
+                    divide_by_volume(self.interp[m][k], t[m]['invvol'])
+        self.interp2spect(fieldtype)
+        if self.filter_currents:
+            for m in range(Nm):
+                sp = self.spect[m]
+                keys = ('Jp', 'Jm', 'Jz') if fieldtype == 'J' else (fieldtype,)
+                for k in keys:
+                    filter_(sp[k], t[m]['filter_z'], t[m]['filter_r'])
+
+    def gather(self):
+        grids = [[self.interp[m][k] for k in INTERP[:6]] for m in range(self.Nm)]
+        for s in self.species:
+            if s['q'] == 0:
+                continue
+            gather(self.shape, self.Nm == 2, s['x'], s['y'], s['z'], self.rmax,
+                   self.invdz, self.zmin, self.Nz, self.invdr, 0., self.Nr, grids,
+                   s['Ex'], s['Ey'], s['Ez'], s['Bx'], s['By'], s['Bz'])
+
+    def step(self, N=1, correct_currents=True, use_true_rho=False):
+        dt = self.dt
+        self.interp2spect('E')
+        self.interp2spect('B')
+        for i_step in range(N):
+            # exchange_period == 1 for single-proc periodic (boundary_communicator.py:294)
+            for s in self.species:
+                shift_periodic(s['z'], self.zmin, self.zmax)
+            self.deposit('rho_prev')
+            if i_step == 0:
+                self.deposit('J')
+            self.gather()
+            for s in self.species:
+                if s['q'] != 0:
+                    push_p(s['ux'], s['uy'], s['uz'], s['inv_gamma'], s['Ex'], s['Ey'], s['Ez'],
+                           s['Bx'], s['By'], s['Bz'], s['q'], s['m'], dt)
+            for s in self.species:
+                push_x(s['x'], s['y'], s['z'], s['ux'], s['uy'], s['uz'], s['inv_gamma'], 0.5 * dt)
+            self.deposit('J')
+            for s in self.species:
+                push_x(s['x'], s['y'], s['z'], s['ux'], s['uy'], s['uz'], s['inv_gamma'], 0.5 * dt)
+            self.deposit('rho_next')
+            if correct_currents:
+                for m in range(self.Nm):
+                    sp, t = self.spect[m], self.t[m]
+                    correct_currents_curlfree(sp['rho_prev'], sp['rho_next'], sp['Jp'], sp['Jm'],
+                                              sp['Jz'], t['kz'], t['kr'], t['inv_k2'], 1. / dt)
+            for m in range(self.Nm):
+                sp, t = self.spect[m], self.t[m]
+                push_eb_standard(sp['Ep'], sp['Em'], sp['Ez'], sp['Bp'], sp['Bm'], sp['Bz'],
+                                 sp['Jp'], sp['Jm'], sp['Jz'], sp['rho_prev'], sp['rho_next'],
+                                 t['rho_prev_coef'], t['rho_next_coef'], t['j_coef'],
+                                 t['C'], t['S_w'], t['kr'], t['kz'], dt, use_true_rho)
+                sp['rho_prev'][:] = sp['rho_next']
+                sp['rho_next'][:] = 0.
+            self.partial_roundtrip('E')
+            self.partial_roundtrip('B')
+            self.spect2interp('E')
+            self.spect2interp('B')
+            self.time += dt
+            self.iteration += 1
+        self.spect2interp('J')
+        self.spect2interp('rho_prev')
