@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Benchmark of the FBPIC per-step PIC cycle on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload: uniform plasma, Nz x Nr = 1024 x 128, Nm = 2,
+32 particles per cell (p_nz, p_nr, p_nt = 2, 4, 4 -> 4 194 304 macroparticles per 1024
+cells in z), dz = dr = 0.2 um, dt = dz/c, z-periodic, linear shape, curl-free correction,
+filtered currents, thermal momenta N(0, 0.01^2).  A "step" is one full PIC cycle
+(Simulation.step: sort, deposit rho/J, transforms, gather, Vay push, PSATD solve).
+With N > 1 ranks the domain is decomposed in z (one rank per GPU, RCCL guard-cell
+exchange); every rank owns a 1024-cell slab (weak scaling: global Nz = 1024 * N).
+
+Prints ONE JSON line on rank 0.  `value` = macroparticle updates per second over all
+ranks with all data resident in HBM.  `roofline` is for the kernel with the largest
+share of device time, measured with HIP events on the launch stream in an instrumented
+pass after the timed region.  `cpu_baseline` times the CPU oracle (C/OpenMP restatement
+of the reference's Numba CPU path + NumPy FFT/dot, `kind: port`) on the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (datasheet)
+
+# algorithmic work per launch: name -> (bound, function(args) -> bytes|flops)
+WORK = {
+    'fb_push_x': ('hbm', lambda a: 80.0 * a[0]),
+    'fb_push_p': ('hbm', lambda a: 112.0 * a[0]),
+    'fb_gather': ('hbm', lambda a: 72.0 * a[2]),
+    'fb_deposit_rho': ('hbm', lambda a: 32.0 * a[2]),
+    'fb_deposit_J': ('hbm', lambda a: 64.0 * a[2]),
+    'fb_cell_index': ('hbm', lambda a: 32.0 * a[0]),
+    'fb_sort_by_cell': ('hbm', lambda a: 16.0 * a[0]),          # one read+write of (key, value)
+    'fb_permute': ('hbm', lambda a: (16.0 * a[2] + 4.0) * a[0]),
+    'fb_shift_periodic': ('hbm', lambda a: 8.0 * a[0]),
+    'fb_hankel': ('mfma', lambda a: 4.0 * a[7] * a[8] * a[8] * a[0]),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--Nz', type=int, default=1024)
+    ap.add_argument('--Nr', type=int, default=128)
+    ap.add_argument('--Nm', type=int, default=2)
+    ap.add_argument('--shape', default='linear')
+    ap.add_argument('--ppc', default='2,4,4')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-steps', type=int, default=3)
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import helpers
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node == --gpus'
+    from fbpic_amd import _capi
+    from fbpic_amd.main import GpuMemoryManager
+    ppc = tuple(int(v) for v in args.ppc.split(','))
+    n_order = -1 if world == 1 else 32
+    # weak scaling: every rank owns args.Nz cells; the Simulation is given the global box
+    sim = helpers.uniform_plasma_sim(args.Nz * world, args.Nr, args.Nm, ppc, args.shape, seed=0,
+                                     n_order=n_order)
+    n_local = sum(s.Ntot for s in sim.ptcl)
+    n_total = n_local
+    if world > 1:
+        tcount = torch.tensor([n_local], dtype=torch.int64, device='cuda')
+        dist.all_reduce(tcount)
+        n_total = int(tcount.item())
+    cpu_base = None
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        cpu_base = cpu_baseline(sim, args)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with GpuMemoryManager(sim):
+        sim.step(args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        sim.step(args.steps)
+        barrier()
+        dt_wall = time.perf_counter() - t0
+        kern = None
+        if not args.no_kernel_timing:
+            _capi.enable_timing()
+            sim.step(3)
+            kern = _capi.collect_timing()
+    if world > 1:
+        tt = torch.tensor([dt_wall], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt_wall = float(tt.item())
+    if rank != 0:
+        return
+    value = n_total * args.steps / dt_wall
+    out = {
+        'metric': 'particle-updates/sec', 'value': value, 'unit': 'particle-updates/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * dt_wall / args.steps, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'ns_per_particle_step': 1e9 * dt_wall / (args.steps * n_total) * world,
+        'config': {'workload': 'C2 uniform plasma %dx%d Nm=%d %d ppc %s shape, z-periodic, '
+                               'standard PSATD n_order=%d, curl-free correction, filtered'
+                               % (args.Nz * world, args.Nr, args.Nm, ppc[0] * ppc[1] * ppc[2],
+                                  args.shape, n_order),
+                   'particles': n_total, 'parallelism': 'z-slab x%d' % world},
+    }
+    if kern:
+        out['roofline'], out['kernels'] = roofline(kern)
+    if cpu_base:
+        out['cpu_baseline'] = cpu_base
+    print(json.dumps(out))
+
+
+def roofline(kern):
+    """Per entry point: launches, mean device ms, achieved GB/s or TFLOP/s; the roofline
+    object describes the entry point with the largest total device time."""
+    table = {}
+    for name, recs in kern.items():
+        ms = [r[0] for r in recs]
+        tot = sum(ms)
+        ent = {'launches': len(ms), 'mean_ms': tot / max(len(ms), 1), 'total_ms': tot}
+        if name in WORK:
+            bound, fn = WORK[name]
+            work = sum(fn(r[1]) for r in recs)
+            if bound == 'hbm':
+                ent.update(bound='hbm', achieved=work / (tot * 1e-3) / 1e9, unit='GB/s',
+                           peak=HBM_PEAK_GBS)
+            else:
+                ent.update(bound='mfma', achieved=work / (tot * 1e-3) / 1e12, unit='TFLOP/s',
+                           peak=FP64_MFMA_PEAK_TFLOPS)
+            ent['frac'] = ent['achieved'] / ent['peak']
+        table[name] = ent
+    cand = [n for n in table if 'frac' in table[n]]
+    dom = max(cand, key=lambda n: table[n]['total_ms'])
+    d = table[dom]
+    roof = {'kernel': dom, 'bound': d['bound'], 'achieved': d['achieved'], 'peak': d['peak'],
+            'unit': d['unit'], 'frac': d['frac'], 'traffic': None,
+            'mean_launch_ms': d['mean_ms']}
+    compact = {n: {k: (round(v, 5) if isinstance(v, float) else v) for k, v in e.items()
+                   if k in ('launches', 'mean_ms', 'achieved', 'unit', 'frac')}
+               for n, e in table.items()}
+    return roof, compact
+
+
+def cpu_baseline(sim, args):
+    """CPU oracle (port of the reference's Numba-threaded CPU path) on the same workload:
+    `cpu_steps` full PIC cycles at full size, all host cores."""
+    from oracle import oracle as orc
+    nthreads = orc.max_threads()
+    o = orc.from_sim(sim, nthreads=nthreads)
+    o.step(1)                       # warm-up (thread pools, FFT plans)
+    t0 = time.perf_counter()
+    o.step(args.cpu_steps)
+    dt = time.perf_counter() - t0
+    n = sum(s['x'].size for s in o.species)
+    return {'value': n * args.cpu_steps / dt, 'unit': 'particle-updates/s', 'cores': nthreads,
+            'kind': 'port',
+            'sample': '%d full PIC steps of the same %dx%d Nm=%d %d-particle workload '
+                      '(after 1 warm-up step), C/OpenMP oracle + NumPy FFT/dot'
+                      % (args.cpu_steps, sim.fld.Nz, sim.fld.Nr, sim.fld.Nm, n),
+            'seconds': dt}
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,286 @@
+// Grid kernels for gfx950 (interpolation grid + spectral grid), all HBM/cache-bound
+// element-wise passes over complex128 (Nz, Nr) views with an explicit row stride so the
+// same kernels run on the reference's contiguous arrays and on z-major field slabs.
+// One lane = one complex element (16-byte accesses, r contiguous -> coalesced).
+#include "fb_common.h"
+
+namespace fb {
+
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return {a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return {a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ cplx rmul(double s, cplx a) { return {s * a.re, s * a.im}; }
+__device__ __forceinline__ cplx imul(cplx a) { return {-a.im, a.re}; }   // i * a
+__device__ __forceinline__ cplx ld(const cplx *p) { double2 v = *(const double2 *)p; return {v.x, v.y}; }
+__device__ __forceinline__ void st(cplx *p, cplx v) { *(double2 *)p = make_double2(v.re, v.im); }
+
+#define FB_GRID_LOOP(idx, iz, ir)                                                     \
+    const long ncell_ = (long)Nz * Nr;                                                \
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < ncell_;        \
+         idx += (long)gridDim.x * blockDim.x)                                         \
+        for (int iz = (int)(idx / Nr), ir = (int)(idx - (long)iz * Nr), once_ = 1; once_; once_ = 0)
+
+// fields/cuda_methods.py:18-66
+__global__ __launch_bounds__(256) void k_erase(int nf, Ptrs48 P, long rs, int Nz, int Nr)
+{
+    FB_GRID_LOOP(idx, iz, ir) {
+        for (int f = 0; f < nf; f++) st((cplx *)P.p[f] + (long)iz * rs + ir, {0., 0.});
+    }
+}
+
+// fields/cuda_methods.py:68-118 ; CPU: F *= invvol[newaxis, :]
+__global__ __launch_bounds__(256) void k_divide(int nf, Ptrs48 P, long rs,
+                                                const double *__restrict__ invvol, int Nz, int Nr)
+{
+    FB_GRID_LOOP(idx, iz, ir) {
+        const double v = invvol[ir];
+        for (int f = 0; f < nf; f++) {
+            cplx *p = (cplx *)P.p[f] + (long)iz * rs + ir;
+            cplx a = ld(p);
+            st(p, {a.re * v, a.im * v});
+        }
+    }
+}
+
+// fields/numba_methods.py:14-60 : field = fz[iz]*fr[ir]*field
+__global__ __launch_bounds__(256) void k_filter(int nf, Ptrs48 P, long rs,
+        const double *__restrict__ fz, const double *__restrict__ fr, int Nz, int Nr)
+{
+    FB_GRID_LOOP(idx, iz, ir) {
+        const double f_ = fz[iz] * fr[ir];
+        for (int f = 0; f < nf; f++) {
+            cplx *p = (cplx *)P.p[f] + (long)iz * rs + ir;
+            cplx a = ld(p);
+            st(p, {f_ * a.re, f_ * a.im});
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scale(int nf, Ptrs48 P, long rs, double s, int Nz, int Nr)
+{
+    FB_GRID_LOOP(idx, iz, ir) {
+        for (int f = 0; f < nf; f++) {
+            cplx *p = (cplx *)P.p[f] + (long)iz * rs + ir;
+            cplx a = ld(p);
+            st(p, {a.re * s, a.im * s});
+        }
+    }
+}
+
+// fields/spectral_transform/numba_methods.py:60-103 (in-place safe: reads before writes)
+__global__ __launch_bounds__(256) void k_rt_to_pm(int np, CPtrs48 R, CPtrs48 T, Ptrs48 Pp, Ptrs48 Pm,
+                                                  long rs, int Nz, int Nr)
+{
+    FB_GRID_LOOP(idx, iz, ir) {
+        const long o = (long)iz * rs + ir;
+        for (int f = 0; f < np; f++) {
+            cplx vr = ld((const cplx *)R.p[f] + o), vt = ld((const cplx *)T.p[f] + o);
+            st((cplx *)Pp.p[f] + o, {0.5 * (vr.re + vt.im), 0.5 * (vr.im - vt.re)});
+            st((cplx *)Pm.p[f] + o, {0.5 * (vr.re - vt.im), 0.5 * (vr.im + vt.re)});
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_pm_to_rt(int np, CPtrs48 Pp, CPtrs48 Pm, Ptrs48 R, Ptrs48 T,
+                                                  long rs, int Nz, int Nr)
+{
+    FB_GRID_LOOP(idx, iz, ir) {
+        const long o = (long)iz * rs + ir;
+        for (int f = 0; f < np; f++) {
+            cplx vp = ld((const cplx *)Pp.p[f] + o), vm = ld((const cplx *)Pm.p[f] + o);
+            st((cplx *)R.p[f] + o, {vp.re + vm.re, vp.im + vm.im});
+            const double dre = vp.re - vm.re, dim = vp.im - vm.im;
+            st((cplx *)T.p[f] + o, {-dim, dre});
+        }
+    }
+}
+
+// fields/numba_methods.py:63-85
+__global__ __launch_bounds__(256) void k_correct_currents(const cplx *__restrict__ rho_prev,
+        const cplx *__restrict__ rho_next, cplx *__restrict__ Jp, cplx *__restrict__ Jm,
+        cplx *__restrict__ Jz, long rs, const double *__restrict__ kz,
+        const double *__restrict__ kr, const double *__restrict__ inv_k2, double inv_dt,
+        int Nz, int Nr)
+{
+    FB_GRID_LOOP(idx, iz, ir) {
+        const long o = (long)iz * rs + ir;
+        const double kzz = kz[idx], krr = kr[idx];
+        cplx jp = ld(Jp + o), jm = ld(Jm + o), jz = ld(Jz + o);
+        cplx t1 = rmul(inv_dt, csub(ld(rho_next + o), ld(rho_prev + o)));
+        cplx t2 = rmul(kzz, imul(jz));
+        cplx t3 = rmul(krr, csub(jp, jm));
+        cplx F = rmul(-inv_k2[idx], cadd(cadd(t1, t2), t3));
+        st(Jp + o, cadd(jp, rmul(0.5 * krr, F)));
+        st(Jm + o, cadd(jm, rmul(-0.5 * krr, F)));
+        st(Jz + o, cadd(jz, rmul(kzz, imul(rmul(-1., F)))));
+    }
+}
+
+// fields/numba_methods.py:118-185
+__global__ __launch_bounds__(256) void k_push_eb(cplx *__restrict__ Ep, cplx *__restrict__ Em,
+        cplx *__restrict__ Ez, cplx *__restrict__ Bp, cplx *__restrict__ Bm, cplx *__restrict__ Bz,
+        const cplx *__restrict__ Jp, const cplx *__restrict__ Jm, const cplx *__restrict__ Jz,
+        const cplx *__restrict__ rho_prev, const cplx *__restrict__ rho_next, long rs,
+        const double *__restrict__ rho_prev_coef, const double *__restrict__ rho_next_coef,
+        const double *__restrict__ j_coef, const double *__restrict__ C,
+        const double *__restrict__ S_w, const double *__restrict__ kr,
+        const double *__restrict__ kz, double dt, int use_true_rho,
+        double c2, double eps0, double mu0, int Nz, int Nr)
+{
+    FB_GRID_LOOP(idx, iz, ir) {
+        const long o = (long)iz * rs + ir;
+        const double krr = kr[idx], kzz = kz[idx], Cc = C[idx], Sw = S_w[idx], jc = j_coef[idx];
+        const double rnc = rho_next_coef[idx], rpc = rho_prev_coef[idx];
+        const cplx ep = ld(Ep + o), em = ld(Em + o), ez = ld(Ez + o);
+        const cplx bp = ld(Bp + o), bm = ld(Bm + o), bz = ld(Bz + o);
+        const cplx jp = ld(Jp + o), jm = ld(Jm + o), jz = ld(Jz + o);
+        cplx rho_diff;
+        if (use_true_rho) {
+            rho_diff = csub(rmul(rnc, ld(rho_next + o)), rmul(rpc, ld(rho_prev + o)));
+        } else {
+            cplx divE = cadd(rmul(krr, csub(ep, em)), rmul(kzz, imul(ez)));
+            cplx divJ = cadd(rmul(krr, csub(jp, jm)), rmul(kzz, imul(jz)));
+            rho_diff = csub(rmul((rnc - rpc) * eps0, divE), rmul(rnc * dt, divJ));
+        }
+        const cplx mihkBz = rmul(0.5 * krr, imul(rmul(-1., bz)));
+        st(Ep + o, cadd(cadd(rmul(Cc, ep), rmul(0.5 * krr, rho_diff)),
+                        rmul(c2 * Sw, csub(cadd(mihkBz, rmul(kzz, bp)), rmul(mu0, jp)))));
+        st(Em + o, cadd(csub(rmul(Cc, em), rmul(0.5 * krr, rho_diff)),
+                        rmul(c2 * Sw, csub(csub(mihkBz, rmul(kzz, bm)), rmul(mu0, jm)))));
+        st(Ez + o, cadd(csub(rmul(Cc, ez), rmul(kzz, imul(rho_diff))),
+                        rmul(c2 * Sw, csub(cadd(rmul(krr, imul(bp)), rmul(krr, imul(bm))),
+                                           rmul(mu0, jz)))));
+        const cplx mihkEz = rmul(0.5 * krr, imul(rmul(-1., ez)));
+        const cplx mihkJz = rmul(0.5 * krr, imul(rmul(-1., jz)));
+        st(Bp + o, cadd(csub(rmul(Cc, bp), rmul(Sw, cadd(mihkEz, rmul(kzz, ep)))),
+                        rmul(jc, cadd(mihkJz, rmul(kzz, jp)))));
+        st(Bm + o, cadd(csub(rmul(Cc, bm), rmul(Sw, csub(mihkEz, rmul(kzz, em)))),
+                        rmul(jc, csub(mihkJz, rmul(kzz, jm)))));
+        st(Bz + o, cadd(csub(rmul(Cc, bz), rmul(Sw, cadd(rmul(krr, imul(ep)), rmul(krr, imul(em))))),
+                        rmul(jc, cadd(rmul(krr, imul(jp)), rmul(krr, imul(jm))))));
+    }
+}
+
+// fields/spectral_grid.py:407-421
+__global__ __launch_bounds__(256) void k_push_rho(cplx *__restrict__ rho_prev,
+                                                  cplx *__restrict__ rho_next, long rs, int Nz, int Nr)
+{
+    FB_GRID_LOOP(idx, iz, ir) {
+        const long o = (long)iz * rs + ir;
+        st(rho_prev + o, ld(rho_next + o));
+        st(rho_next + o, {0., 0.});
+    }
+}
+
+static inline int grid_for(int Nz, int Nr) { return stream_grid((long)Nz * Nr, 256, 256 * 8); }
+
+template <class T, class U>
+static bool fill48(T &dst, U *const *src, int n, const char *where)
+{
+    if (n < 0 || n > 48) { set_error(where, "more than 48 fields"); return false; }
+    for (int i = 0; i < 48; i++) dst.p[i] = i < n ? src[i] : nullptr;
+    return true;
+}
+
+}  // namespace fb
+
+using namespace fb;
+
+extern "C" int fb_erase(int nf, void *const *ptrs, long rs, int Nz, int Nr, void *stream)
+{
+    Ptrs48 P;
+    if (!fill48(P, ptrs, nf, "fb_erase")) return -1;
+    if (nf == 0) return 0;
+    hipLaunchKernelGGL(k_erase, dim3(grid_for(Nz, Nr)), dim3(256), 0, (hipStream_t)stream, nf, P, rs, Nz, Nr);
+    FB_CHECK_LAUNCH("fb_erase");
+}
+
+extern "C" int fb_divide_by_volume(int nf, void *const *ptrs, long rs, const double *invvol,
+                                   int Nz, int Nr, void *stream)
+{
+    Ptrs48 P;
+    if (!fill48(P, ptrs, nf, "fb_divide_by_volume")) return -1;
+    if (nf == 0) return 0;
+    hipLaunchKernelGGL(k_divide, dim3(grid_for(Nz, Nr)), dim3(256), 0, (hipStream_t)stream, nf, P, rs,
+                       invvol, Nz, Nr);
+    FB_CHECK_LAUNCH("fb_divide_by_volume");
+}
+
+extern "C" int fb_filter(int nf, void *const *ptrs, long rs, const double *fz, const double *fr,
+                         int Nz, int Nr, void *stream)
+{
+    Ptrs48 P;
+    if (!fill48(P, ptrs, nf, "fb_filter")) return -1;
+    if (nf == 0) return 0;
+    hipLaunchKernelGGL(k_filter, dim3(grid_for(Nz, Nr)), dim3(256), 0, (hipStream_t)stream, nf, P, rs,
+                       fz, fr, Nz, Nr);
+    FB_CHECK_LAUNCH("fb_filter");
+}
+
+extern "C" int fb_scale(int nf, void *const *ptrs, long rs, double factor, int Nz, int Nr,
+                        void *stream)
+{
+    Ptrs48 P;
+    if (!fill48(P, ptrs, nf, "fb_scale")) return -1;
+    if (nf == 0) return 0;
+    hipLaunchKernelGGL(k_scale, dim3(grid_for(Nz, Nr)), dim3(256), 0, (hipStream_t)stream, nf, P, rs,
+                       factor, Nz, Nr);
+    FB_CHECK_LAUNCH("fb_scale");
+}
+
+extern "C" int fb_rt_to_pm(int np, const void *const *r, const void *const *t, void *const *p,
+                           void *const *m, long rs, int Nz, int Nr, void *stream)
+{
+    CPtrs48 R, T;
+    Ptrs48 P, M;
+    if (!fill48(R, r, np, "fb_rt_to_pm") || !fill48(T, t, np, "fb_rt_to_pm") ||
+        !fill48(P, p, np, "fb_rt_to_pm") || !fill48(M, m, np, "fb_rt_to_pm")) return -1;
+    if (np == 0) return 0;
+    hipLaunchKernelGGL(k_rt_to_pm, dim3(grid_for(Nz, Nr)), dim3(256), 0, (hipStream_t)stream, np, R, T,
+                       P, M, rs, Nz, Nr);
+    FB_CHECK_LAUNCH("fb_rt_to_pm");
+}
+
+extern "C" int fb_pm_to_rt(int np, const void *const *p, const void *const *m, void *const *r,
+                           void *const *t, long rs, int Nz, int Nr, void *stream)
+{
+    CPtrs48 P, M;
+    Ptrs48 R, T;
+    if (!fill48(P, p, np, "fb_pm_to_rt") || !fill48(M, m, np, "fb_pm_to_rt") ||
+        !fill48(R, r, np, "fb_pm_to_rt") || !fill48(T, t, np, "fb_pm_to_rt")) return -1;
+    if (np == 0) return 0;
+    hipLaunchKernelGGL(k_pm_to_rt, dim3(grid_for(Nz, Nr)), dim3(256), 0, (hipStream_t)stream, np, P, M,
+                       R, T, rs, Nz, Nr);
+    FB_CHECK_LAUNCH("fb_pm_to_rt");
+}
+
+extern "C" int fb_correct_currents_curlfree_standard(const void *rho_prev, const void *rho_next,
+        void *Jp, void *Jm, void *Jz, long rs, const double *kz, const double *kr,
+        const double *inv_k2, double inv_dt, int Nz, int Nr, void *stream)
+{
+    hipLaunchKernelGGL(k_correct_currents, dim3(grid_for(Nz, Nr)), dim3(256), 0, (hipStream_t)stream,
+                       (const cplx *)rho_prev, (const cplx *)rho_next, (cplx *)Jp, (cplx *)Jm,
+                       (cplx *)Jz, rs, kz, kr, inv_k2, inv_dt, Nz, Nr);
+    FB_CHECK_LAUNCH("fb_correct_currents_curlfree_standard");
+}
+
+extern "C" int fb_push_eb_standard(void *Ep, void *Em, void *Ez, void *Bp, void *Bm, void *Bz,
+        const void *Jp, const void *Jm, const void *Jz, const void *rho_prev,
+        const void *rho_next, long rs, const double *rho_prev_coef, const double *rho_next_coef,
+        const double *j_coef, const double *C, const double *S_w, const double *kr,
+        const double *kz, double dt, int use_true_rho, double c, double epsilon_0, double mu_0,
+        int Nz, int Nr, void *stream)
+{
+    hipLaunchKernelGGL(k_push_eb, dim3(grid_for(Nz, Nr)), dim3(256), 0, (hipStream_t)stream,
+                       (cplx *)Ep, (cplx *)Em, (cplx *)Ez, (cplx *)Bp, (cplx *)Bm, (cplx *)Bz,
+                       (const cplx *)Jp, (const cplx *)Jm, (const cplx *)Jz,
+                       (const cplx *)rho_prev, (const cplx *)rho_next, rs, rho_prev_coef,
+                       rho_next_coef, j_coef, C, S_w, kr, kz, dt, use_true_rho, c * c,
+                       epsilon_0, mu_0, Nz, Nr);
+    FB_CHECK_LAUNCH("fb_push_eb_standard");
+}
+
+extern "C" int fb_push_rho(void *rho_prev, void *rho_next, long rs, int Nz, int Nr, void *stream)
+{
+    hipLaunchKernelGGL(k_push_rho, dim3(grid_for(Nz, Nr)), dim3(256), 0, (hipStream_t)stream,
+                       (cplx *)rho_prev, (cplx *)rho_next, rs, Nz, Nr);
+    FB_CHECK_LAUNCH("fb_push_rho");
+}

@@ -1,0 +1,30 @@
+// Runtime glue of libfbpic_amd.so: error reporting, device binding, stream sync.
+#include "fb_common.h"
+#include <stdio.h>
+#include <string.h>
+
+namespace fb {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *where, const char *what)
+{
+    snprintf(g_err, sizeof(g_err), "%s: %s", where, what);
+}
+
+int check(hipError_t e, const char *where)
+{
+    if (e == hipSuccess) return 0;
+    set_error(where, hipGetErrorString(e));
+    return (int)e;
+}
+
+}  // namespace fb
+
+extern "C" int fb_abi_version(void) { return 1; }
+extern "C" const char *fb_last_error(void) { return fb::g_err; }
+extern "C" int fb_set_device(int device) { return fb::check(hipSetDevice(device), "fb_set_device"); }
+extern "C" int fb_sync(void *stream)
+{
+    return fb::check(hipStreamSynchronize((hipStream_t)stream), "fb_sync");
+}

@@ -1,0 +1,276 @@
+"""`Fields`: all grid data of the simulation and the interpolation <-> spectral transforms.
+
+Same public surface as the reference's `Fields` (fbpic/fields/fields.py:20-625):
+`interp[m]`, `spect[m]`, `trans[m]`, `psatd[m]`, `push`, `correct_currents`,
+`interp2spect`, `spect2interp`, `spect2partial_interp`, `partial_interp2spect`, `erase`,
+`divide_by_volume`, `filter_spect`, `sum_reduce_deposition_array`, `exchanged_source`.
+
+MI355X data layout.  While on the GPU, all interpolation-grid fields of all modes live in
+ONE z-major slab `complex128[Nz, 10*Nm, Nr]` and all spectral fields in a second slab
+`complex128[Nz, 11*Nm, Nr]`; `interp[m].Ez` etc. are (Nz, Nr) views with row stride
+`NF*Nr`.  Consequences:
+  * one rocFFT call transforms a whole group (e.g. Er,Et,Ez of every mode = 3*Nm*Nr
+    columns, stride NF*Nr, distance 1) -- no per-field launches, no transposes;
+  * one MFMA launch applies the 3*Nm different Hankel matrices of that group;
+  * a z-range of guard cells of every field is one contiguous block (multi-GPU exchange).
+Field order inside a slab: E | B | J | rho(_prev | _next), each vector group ordered
+[mode0: (r|p, t|m, z), mode1: ...].
+"""
+import numpy as np
+from .. import _capi
+from .interpolation_grid import InterpolationGrid, INTERP_FIELDS
+from .spectral_grid import SpectralGrid, SPECT_FIELDS
+from .psatd_coefs import PsatdCoeffs
+from .smoothing import BinomialSmoother
+from .utility_methods import get_modified_k
+from .spectral_transform.spectral_transformer import SpectralTransformer
+from .spectral_transform.fourier import fft_exec
+
+_VEC = {'E': 0, 'B': 1, 'J': 2}
+_I_COMP = ('r', 't', 'z')
+_S_COMP = ('p', 'm', 'z')
+
+
+class Fields(object):
+    def __init__(self, Nz, zmax, Nr, rmax, Nm, dt, zmin=0., n_order=-1, v_comoving=None,
+                 use_pml=False, use_galilean=True, current_correction='curl-free',
+                 use_cuda=True, smoother=None, create_threading_buffers=False,
+                 use_ruyten_shapes=True, use_modified_volume=True):
+        if v_comoving is not None:
+            raise NotImplementedError('Galilean / comoving schemes are outside the fbpic_amd scope')
+        if current_correction not in ('curl-free', 'cross-deposition'):
+            raise ValueError('Unkown current correction:%s' % current_correction)
+        self.Nz, self.Nr, self.rmax, self.Nm, self.dt = Nz, Nr, rmax, Nm, dt
+        self.n_order = n_order
+        self.v_comoving = None
+        self.use_galilean = False
+        self.smoother = smoother if smoother is not None else \
+            BinomialSmoother(n_passes=1, compensator=False)
+        self.use_cuda = use_cuda
+        self.data_is_on_gpu = False
+        self.current_correction = current_correction
+        self.trans = [SpectralTransformer(Nz, Nr, m, rmax, use_cuda=use_cuda) for m in range(Nm)]
+        self.interp = [InterpolationGrid(Nz, Nr, m, zmin, zmax, rmax, use_pml=use_pml,
+                                         use_cuda=use_cuda, use_ruyten_shapes=use_ruyten_shapes,
+                                         use_modified_volume=use_modified_volume)
+                       for m in range(Nm)]
+        dz = (zmax - zmin) / Nz
+        kz_true = 2 * np.pi * np.fft.fftfreq(Nz, dz)
+        kz_modified = get_modified_k(kz_true, n_order, dz)
+        self.spect = []
+        self.psatd = []
+        for m in range(Nm):
+            kr = 2 * np.pi * self.trans[m].dht0.get_nu()
+            self.spect.append(SpectralGrid(kz_modified, kr, m, kz_true, self.interp[m].dz,
+                                           self.interp[m].dr, current_correction, self.smoother,
+                                           use_pml=use_pml, use_cuda=use_cuda))
+            self.psatd.append(PsatdCoeffs(self.spect[m].kz, self.spect[m].kr, m, dt, Nz, Nr,
+                                          V=None, use_cuda=use_cuda))
+        self.exchanged_source = {'J': False, 'rho_prev': False, 'rho_new': False,
+                                 'rho_next_xy': False, 'rho_next_z': False}
+        # device state (allocated at the first send_fields_to_gpu)
+        self.NFi = 10 * Nm
+        self.NFs = 11 * Nm
+        self.NFx = 6 * Nm
+        self.d_interp = None
+        self.d_spect = None
+        self.d_scratch = None
+
+    # ---------------------------------------------------------------- slab indexing
+    def interp_index(self, name, m):
+        if name == 'rho':
+            return 9 * self.Nm + m
+        return 3 * self.Nm * _VEC[name[0]] + 3 * m + _I_COMP.index(name[1])
+
+    def spect_index(self, name, m):
+        if name == 'rho_prev':
+            return 9 * self.Nm + m
+        if name == 'rho_next':
+            return 10 * self.Nm + m
+        return 3 * self.Nm * _VEC[name[0]] + 3 * m + _S_COMP.index(name[1])
+
+    # ---------------------------------------------------------------- host <-> device
+    def send_fields_to_gpu(self):
+        """Move all grid data to the MI355X; attributes become views of the device slabs."""
+        if self.data_is_on_gpu:
+            return
+        t = _capi.torch()
+        dev = _capi.require_device()
+        Nz, Nr, Nm = self.Nz, self.Nr, self.Nm
+        hi = np.empty((Nz, self.NFi, Nr), dtype=np.complex128)
+        hs = np.empty((Nz, self.NFs, Nr), dtype=np.complex128)
+        for m in range(Nm):
+            for name in INTERP_FIELDS:
+                hi[:, self.interp_index(name, m), :] = getattr(self.interp[m], name)
+            for name in SPECT_FIELDS:
+                hs[:, self.spect_index(name, m), :] = getattr(self.spect[m], name)
+        if self.d_interp is None:
+            self.d_interp = t.empty((Nz, self.NFi, Nr), dtype=t.complex128, device=dev)
+            self.d_spect = t.empty((Nz, self.NFs, Nr), dtype=t.complex128, device=dev)
+            self.d_scratch = t.zeros((Nz, self.NFx, Nr), dtype=t.complex128, device=dev)
+            self._build_job_tables()
+        self.d_interp.copy_(t.from_numpy(hi))
+        self.d_spect.copy_(t.from_numpy(hs))
+        for m in range(Nm):
+            for name in INTERP_FIELDS:
+                setattr(self.interp[m], name, self.d_interp[:, self.interp_index(name, m), :])
+            for name in SPECT_FIELDS:
+                setattr(self.spect[m], name, self.d_spect[:, self.spect_index(name, m), :])
+            self.interp[m].upload_tables()
+            self.spect[m].upload_tables()
+            self.psatd[m].device_tables()
+        self.data_is_on_gpu = True
+
+    def receive_fields_from_gpu(self):
+        """Copy all grid data back to host NumPy arrays (C-contiguous, like `.get()`)."""
+        if not self.data_is_on_gpu:
+            return
+        hi = self.d_interp.cpu().numpy()
+        hs = self.d_spect.cpu().numpy()
+        for m in range(self.Nm):
+            for name in INTERP_FIELDS:
+                setattr(self.interp[m], name,
+                        np.ascontiguousarray(hi[:, self.interp_index(name, m), :]))
+            for name in SPECT_FIELDS:
+                setattr(self.spect[m], name,
+                        np.ascontiguousarray(hs[:, self.spect_index(name, m), :]))
+        self.data_is_on_gpu = False
+
+    def _need_gpu(self):
+        if not self.data_is_on_gpu:
+            raise _capi.BackendError(
+                'Field data is on the host: fbpic_amd only computes on the GPU. Call '
+                'send_fields_to_gpu() (or use GpuMemoryManager / Simulation.step) first.')
+
+    # ---------------------------------------------------------------- batched transforms
+    def _build_job_tables(self):
+        """Per vector group (3*Nm fields, slab order) and per scalar group (Nm fields):
+        host arrays of device pointers to the Hankel matrices."""
+        fwd, inv = [], []
+        fwd_s, inv_s = [], []
+        for m in range(self.Nm):
+            tr = self.trans[m]
+            for d in (tr.dhtp, tr.dhtm, tr.dht0):      # slab order: (r|p, t|m, z)
+                M, iM = d.device_matrices()
+                fwd.append(M)
+                inv.append(iM)
+            M, iM = tr.dht0.device_matrices()
+            fwd_s.append(M)
+            inv_s.append(iM)
+        self._mats = {'vec_fwd': fwd, 'vec_inv': inv, 'scal_fwd': fwd_s, 'scal_inv': inv_s}
+
+    def _field_views(self, slab, f0, nf):
+        return [slab[:, f0 + j, :] for j in range(nf)]
+
+    def _group(self, fieldtype):
+        """(interp first field, spect first field, n fields, is_vector)."""
+        Nm = self.Nm
+        if fieldtype in _VEC:
+            f0 = 3 * Nm * _VEC[fieldtype]
+            return f0, f0, 3 * Nm, True
+        if fieldtype in ('rho_prev', 'rho_next'):
+            return 9 * Nm, (9 if fieldtype == 'rho_prev' else 10) * Nm, Nm, False
+        if fieldtype in ('E_pml', 'B_pml', 'rho_next_z', 'rho_next_xy'):
+            raise NotImplementedError('%s is outside the fbpic_amd scope' % fieldtype)
+        raise ValueError('Invalid string for fieldtype: %s' % fieldtype)
+
+    def interp2spect(self, fieldtype):
+        """FFT(z) then DHT(r) of one field group, all modes at once
+        (reference: fields.py:313-368 + spectral_transformer.py:157-223)."""
+        self._need_gpu()
+        fi, fs, nf, vec = self._group(fieldtype)
+        Nz, Nr = self.Nz, self.Nr
+        lib, pa, st = _capi.lib(), _capi.ptr_array, _capi.stream()
+        src = self.d_interp[:, fi, :]
+        scr = self.d_scratch[:, 0, :]
+        fft_exec(src, scr, -1, ncols=nf * Nr)
+        scr_f = self._field_views(self.d_scratch, 0, nf)
+        if vec:
+            r = pa(scr_f[0::3])
+            t = pa(scr_f[1::3])
+            _capi.check(lib.fb_rt_to_pm(self.Nm, r, t, r, t, self.NFx * Nr, Nz, Nr, st),
+                        'fb_rt_to_pm')
+        out = self._field_views(self.d_spect, fs, nf)
+        mats = self._mats['vec_fwd' if vec else 'scal_fwd']
+        _capi.check(lib.fb_hankel(nf, pa(scr_f), self.NFx * Nr, pa(out), self.NFs * Nr,
+                                  pa(mats), 1.0, Nz, Nr, st), 'fb_hankel')
+
+    def spect2interp(self, fieldtype):
+        """inverse DHT(r) then inverse FFT(z) (reference: fields.py:370-429)."""
+        self._need_gpu()
+        fi, fs, nf, vec = self._group(fieldtype)
+        Nz, Nr = self.Nz, self.Nr
+        lib, pa, st = _capi.lib(), _capi.ptr_array, _capi.stream()
+        inp = self._field_views(self.d_spect, fs, nf)
+        scr_f = self._field_views(self.d_scratch, 0, nf)
+        mats = self._mats['vec_inv' if vec else 'scal_inv']
+        _capi.check(lib.fb_hankel(nf, pa(inp), self.NFs * Nr, pa(scr_f), self.NFx * Nr,
+                                  pa(mats), 1.0, Nz, Nr, st), 'fb_hankel')
+        if vec:
+            p = pa(scr_f[0::3])
+            mm = pa(scr_f[1::3])
+            _capi.check(lib.fb_pm_to_rt(self.Nm, p, mm, p, mm, self.NFx * Nr, Nz, Nr, st),
+                        'fb_pm_to_rt')
+        fft_exec(self.d_scratch[:, 0, :], self.d_interp[:, fi, :], +1, ncols=nf * Nr)
+
+    def spect2partial_interp(self, fieldtype):
+        """inverse FFT only: spectral (p,m,z) -> interpolation-grid storage (r,t,z slots),
+        reference fields.py:431-483."""
+        self._need_gpu()
+        fi, fs, nf, _ = self._group(fieldtype)
+        fft_exec(self.d_spect[:, fs, :], self.d_interp[:, fi, :], +1, ncols=nf * self.Nr)
+
+    def partial_interp2spect(self, fieldtype):
+        """forward FFT only, reference fields.py:485-536."""
+        self._need_gpu()
+        fi, fs, nf, _ = self._group(fieldtype)
+        fft_exec(self.d_interp[:, fi, :], self.d_spect[:, fs, :], -1, ncols=nf * self.Nr)
+
+    # ---------------------------------------------------------------- solver steps
+    def push(self, use_true_rho=False, check_exchanges=False):
+        self._need_gpu()
+        if check_exchanges:
+            assert self.exchanged_source['J'] is True
+            if use_true_rho:
+                assert self.exchanged_source['rho_prev'] is True
+                assert self.exchanged_source['rho_next'] is True
+        for m in range(self.Nm):
+            self.spect[m].push_eb_with(self.psatd[m], use_true_rho)
+            self.spect[m].push_rho()
+
+    def correct_currents(self, check_exchanges=False):
+        self._need_gpu()
+        if check_exchanges:
+            assert self.exchanged_source['rho_prev'] is False
+            assert self.exchanged_source['rho_next'] is False
+            assert self.exchanged_source['J'] is False
+        for m in range(self.Nm):
+            self.spect[m].correct_currents(self.dt, self.psatd[m], self.current_correction)
+
+    def correct_divE(self):
+        raise NotImplementedError('correct_divE is outside the fbpic_amd hot path')
+
+    def erase(self, fieldtype):
+        """Zero a field group on the interpolation grid, all modes in one launch."""
+        self._need_gpu()
+        if fieldtype not in ('E', 'B', 'J', 'rho'):
+            raise ValueError('Invalid string for fieldtype: %s' % fieldtype)
+        fi, _, nf, _ = self._group('rho_prev' if fieldtype == 'rho' else fieldtype)
+        views = self._field_views(self.d_interp, fi, nf)
+        _capi.check(_capi.lib().fb_erase(nf, _capi.ptr_array(views), self.NFi * self.Nr,
+                                         self.Nz, self.Nr, _capi.stream()), 'fb_erase')
+
+    def sum_reduce_deposition_array(self, fieldtype):
+        """No-op: the HIP deposition accumulates directly into the grid (LDS-privatised
+        tiles), there are no per-thread copies to reduce (reference fields.py:566-593)."""
+        return
+
+    def filter_spect(self, fieldtype):
+        self._need_gpu()
+        for m in range(self.Nm):
+            self.spect[m].filter(fieldtype)
+
+    def divide_by_volume(self, fieldtype):
+        self._need_gpu()
+        for m in range(self.Nm):
+            self.interp[m].divide_by_volume(fieldtype)

@@ -1,0 +1,283 @@
+"""`Simulation`: the PIC-cycle driver, same interface as the reference
+(fbpic/main.py:51-1111) for the hot path: constructor arguments, `step`, `deposit`,
+`exchange_and_damp_EB`, `add_new_species`, attributes `fld`, `ptcl`, `comm`, `time`,
+`iteration`, `diags`.  The order of operations in `step` follows main.py:346-586
+exactly; every operation is a HIP kernel launch (fbpic_amd has no CPU path)."""
+import numpy as np
+from scipy.constants import m_e, m_p, e, c
+from . import _capi
+from .particles.particles import Particles
+from .fields import Fields
+from .boundaries.boundary_communicator import BoundaryCommunicator
+
+
+def send_data_to_gpu(simulation):
+    """fbpic/utils/cuda.py:101-118"""
+    for species in simulation.ptcl:
+        species.send_particles_to_gpu()
+    simulation.fld.send_fields_to_gpu()
+
+
+def receive_data_from_gpu(simulation):
+    """fbpic/utils/cuda.py:120-137"""
+    for species in simulation.ptcl:
+        species.receive_particles_from_gpu()
+    simulation.fld.receive_fields_from_gpu()
+
+
+class GpuMemoryManager(object):
+    """Context manager that keeps the simulation data on the GPU for its duration
+    (fbpic/utils/cuda.py:139-182); inside it `Simulation.step` does not copy anything."""
+
+    def __init__(self, simulation):
+        self.sim = simulation
+        self.fields_were_on_gpu = simulation.fld.data_is_on_gpu
+        self.species_were_on_gpu = [s.data_is_on_gpu for s in simulation.ptcl]
+
+    def __enter__(self):
+        if not self.fields_were_on_gpu:
+            self.sim.fld.send_fields_to_gpu()
+        for i, s in enumerate(self.sim.ptcl):
+            if not self.species_were_on_gpu[i]:
+                s.send_particles_to_gpu()
+        return self.sim
+
+    def __exit__(self, type, value, traceback):
+        if not self.fields_were_on_gpu:
+            self.sim.fld.receive_fields_from_gpu()
+        for i, s in enumerate(self.sim.ptcl):
+            if i >= len(self.species_were_on_gpu) or not self.species_were_on_gpu[i]:
+                s.receive_particles_from_gpu()
+
+
+class Simulation(object):
+    def __init__(self, Nz, zmax, Nr, rmax, Nm, dt,
+                 p_zmin=-np.inf, p_zmax=np.inf, p_rmin=0, p_rmax=np.inf,
+                 p_nz=None, p_nr=None, p_nt=None, n_e=None, zmin=0.,
+                 n_order=-1, dens_func=None, filter_currents=True,
+                 v_comoving=None, use_galilean=True,
+                 initialize_ions=False, use_cuda=True, n_guard=None,
+                 n_damp={'z': 64, 'r': 32}, exchange_period=None,
+                 current_correction='curl-free',
+                 boundaries={'z': 'periodic', 'r': 'reflective'},
+                 gamma_boost=None, use_all_mpi_ranks=True,
+                 particle_shape='linear', verbose_level=1,
+                 smoother=None, use_ruyten_shapes=True, use_modified_volume=True):
+        if not use_cuda:
+            raise ValueError('fbpic_amd executes only on the GPU (use_cuda=True); the CPU '
+                             'path of the reference is not part of this backend.')
+        if v_comoving is not None or gamma_boost is not None:
+            raise NotImplementedError('Galilean/comoving and boosted-frame runs are outside '
+                                      'the scope of the fbpic_amd hot path')
+        self.use_cuda = True
+        self.use_threading = False
+        self.cpu_threads = 1
+        self.v_comoving = None
+        self.use_galilean = False
+        self.boost = None
+        self.dt = dt
+        cdt_over_dr = c * dt / (rmax / Nr)
+        self.comm = BoundaryCommunicator(Nz, zmin, zmax, Nr, rmax, Nm, dt, None, False,
+                                         boundaries, n_order, n_guard, n_damp, cdt_over_dr,
+                                         None, exchange_period, use_all_mpi_ranks)
+        self.use_pml = self.comm.use_pml
+        zmin, zmax, Nz = self.comm.divide_into_domain()
+        Nr = self.comm.get_Nr(with_damp=True)
+        rmax = self.comm.get_rmax(with_damp=True)
+        self.fld = Fields(Nz, zmax, Nr, rmax, Nm, dt, n_order=n_order, zmin=zmin,
+                          current_correction=current_correction, use_cuda=True,
+                          smoother=smoother, use_ruyten_shapes=use_ruyten_shapes,
+                          use_modified_volume=use_modified_volume)
+        self.grid_shape = self.fld.interp[0].Ez.shape
+        self.particle_shape = particle_shape
+        self.ptcl = []
+        if n_e is not None:
+            self.add_new_species(q=-e, m=m_e, n=n_e, dens_func=dens_func,
+                                 p_nz=p_nz, p_nr=p_nr, p_nt=p_nt, p_zmin=p_zmin, p_zmax=p_zmax,
+                                 p_rmin=p_rmin, p_rmax=p_rmax)
+            if initialize_ions:
+                self.add_new_species(q=e, m=m_p, n=n_e, dens_func=dens_func,
+                                     p_nz=p_nz, p_nr=p_nr, p_nt=p_nt, p_zmin=p_zmin,
+                                     p_zmax=p_zmax, p_rmin=p_rmin, p_rmax=p_rmax)
+        self.time = 0.
+        self.iteration = 0
+        self.filter_currents = filter_currents
+        self.external_fields = []
+        self.diags = []
+        self.checkpoints = []
+        self.laser_antennas = []
+        self.mirrors = []
+
+    # -------------------------------------------------------------------- PIC cycle
+    def step(self, N=1, correct_currents=True, correct_divE=False, use_true_rho=False,
+             move_positions=True, move_momenta=True, show_progress=False):
+        """Perform N PIC cycles (main.py:346-586)."""
+        ptcl, fld, dt = self.ptcl, self.fld, self.dt
+        if correct_divE:
+            raise NotImplementedError('correct_divE is outside the fbpic_amd hot path')
+        if self.comm.size > 1 and use_true_rho and correct_currents:
+            raise ValueError('`use_true_rho` cannot be used together with '
+                             '`correct_currents` in multi-proc mode.')
+        was_on_gpu = fld.data_is_on_gpu and all(s.data_is_on_gpu for s in ptcl)
+        send_data_to_gpu(self)
+        # E and B go to spectral space once; afterwards only spectral -> interp
+        self.comm.exchange_fields(fld.interp, 'E', 'replace')
+        self.comm.exchange_fields(fld.interp, 'B', 'replace')
+        self.comm.damp_EB_open_boundary(fld.interp)
+        fld.interp2spect('E')
+        fld.interp2spect('B')
+        for i_step in range(N):
+            if self.iteration % self.comm.exchange_period == 0 or i_step == 0:
+                for species in ptcl:
+                    self.comm.exchange_particles(species, fld, self.time)
+                self.deposit('rho_prev', exchange=(use_true_rho is True))
+            if i_step == 0:
+                self.deposit('J', exchange=True)
+            for species in ptcl:
+                species.keep_fields_sorted = True
+            for species in ptcl:
+                species.gather(fld.interp, self.comm)
+            for ext_field in self.external_fields:
+                ext_field.apply_expression(ptcl, self.time)
+            for diag in self.diags:
+                diag.write(self.iteration)
+            if move_momenta:
+                for species in ptcl:
+                    species.push_p(self.time + 0.5 * dt)
+            if move_positions:
+                for species in ptcl:
+                    species.push_x(0.5 * dt)
+            for species in ptcl:
+                species.handle_elementary_processes(self.time + 0.5 * dt)
+            for species in ptcl:
+                species.keep_fields_sorted = False
+            self.deposit('J', exchange=(correct_currents is False))
+            if move_positions:
+                for species in ptcl:
+                    species.push_x(0.5 * dt)
+            self.deposit('rho_next', exchange=(use_true_rho is True))
+            if correct_currents:
+                fld.correct_currents(check_exchanges=(self.comm.size > 1))
+                if self.comm.size > 1:
+                    fld.spect2partial_interp('J')
+                    self.comm.exchange_fields(fld.interp, 'J', 'add')
+                    fld.partial_interp2spect('J')
+                fld.exchanged_source['J'] = True
+            fld.push(use_true_rho, check_exchanges=(self.comm.size > 1))
+            if self.comm.moving_win is not None:
+                self.comm.move_grids(fld, ptcl, dt, self.time)
+            self.exchange_and_damp_EB()
+            self.time += dt
+            self.iteration += 1
+            for checkpoint in self.checkpoints:
+                checkpoint.write(self.iteration)
+        fld.spect2interp('J')
+        if (not fld.exchanged_source['J']) and (self.comm.size > 1):
+            self.comm.exchange_fields(fld.interp, 'J', 'add')
+        fld.spect2interp('rho_prev')
+        if (not fld.exchanged_source['rho_prev']) and (self.comm.size > 1):
+            self.comm.exchange_fields(fld.interp, 'rho', 'add')
+        if not was_on_gpu:
+            receive_data_from_gpu(self)
+
+    def deposit(self, fieldtype, exchange=False, update_spectral=True, species_list=None):
+        """Deposit rho or J on the interpolation grid, then transform and filter
+        (main.py:588-670)."""
+        fld = self.fld
+        if species_list is None:
+            species_list = [s for s in self.ptcl if not s.is_tracer]
+        if fieldtype.startswith('rho'):
+            kind = 'rho'
+        elif fieldtype == 'J':
+            kind = 'J'
+        else:
+            raise ValueError('Unknown fieldtype: %s' % fieldtype)
+        fld.erase(kind)
+        for species in species_list:
+            species.deposit(fld, kind)
+        fld.sum_reduce_deposition_array(kind)
+        fld.divide_by_volume(kind)
+        if exchange and self.comm.size > 1:
+            self.comm.exchange_fields(fld.interp, kind, 'add')
+        if update_spectral:
+            fld.interp2spect(fieldtype)
+            if self.filter_currents:
+                fld.filter_spect(fieldtype)
+            fld.exchanged_source[fieldtype] = exchange
+
+    def exchange_and_damp_EB(self):
+        """E/B guard exchange + open-boundary damping in (z-real, r-spectral) space, then
+        back to the interpolation grid (main.py:719-769).  On a single periodic rank the
+        iFFT/FFT round trip of main.py:741-766 is the identity (nothing touches the
+        partial-interp fields) and is skipped (difference ~1e-16 relative)."""
+        fld = self.fld
+        needs_partial = (self.comm.size > 1) or (self.comm.nz_damp != 0) or len(self.mirrors) > 0
+        if needs_partial:
+            fld.spect2partial_interp('E')
+            fld.spect2partial_interp('B')
+            self.comm.exchange_fields(fld.interp, 'E', 'replace')
+            self.comm.exchange_fields(fld.interp, 'B', 'replace')
+            self.comm.damp_EB_open_boundary(fld.interp)
+            for mirror in self.mirrors:
+                mirror.set_fields_to_zero(fld.interp, self.comm, self.time)
+            fld.partial_interp2spect('E')
+            fld.partial_interp2spect('B')
+        fld.spect2interp('E')
+        fld.spect2interp('B')
+
+    # -------------------------------------------------------------------- species
+    def add_new_species(self, q, m, n=None, dens_func=None, p_nz=None, p_nr=None, p_nt=None,
+                        p_zmin=-np.inf, p_zmax=np.inf, p_rmin=0, p_rmax=np.inf,
+                        uz_m=0., ux_m=0., uy_m=0., uz_th=0., ux_th=0., uy_th=0.,
+                        continuous_injection=True, boost_positions_in_dens_func=False,
+                        is_tracer=False):
+        """Create a species and (if n is given) its evenly-spaced macroparticles
+        (main.py:792-1001)."""
+        if n is not None:
+            for var in [p_nz, p_nr, p_nt]:
+                if var is None:
+                    raise ValueError('If the density `n` is passed to `add_new_species`,\n'
+                                     'then the arguments `p_nz`, `p_nr` and `p_nt` need '
+                                     'to be passed too.')
+            zmin_l, zmax_l = self.comm.get_zmin_zmax(local=True, rank=self.comm.rank,
+                                                     with_damp=False, with_guard=False)
+            p_zmin = max(zmin_l, p_zmin)
+            p_zmax = min(zmax_l, p_zmax)
+            p_rmax = min(self.comm.get_rmax(with_damp=False), p_rmax)
+            p_zmin, p_zmax, Npz = adapt_to_grid(self.fld.interp[0].z, p_zmin, p_zmax, p_nz)
+            p_rmin, p_rmax, Npr = adapt_to_grid(self.fld.interp[0].r, p_rmin, p_rmax, p_nr)
+            dz_particles = self.comm.dz / p_nz
+        else:
+            n = 0
+            p_zmin = p_zmax = p_rmin = p_rmax = 0
+            Npz = Npr = p_nt = 0
+            continuous_injection = False
+            dz_particles = 0.
+        new_species = Particles(q=q, m=m, n=n, dens_func=dens_func, Npz=Npz, zmin=p_zmin,
+                                zmax=p_zmax, Npr=Npr, rmin=p_rmin, rmax=p_rmax, Nptheta=p_nt,
+                                dt=self.dt, particle_shape=self.particle_shape, use_cuda=True,
+                                grid_shape=self.grid_shape, ux_m=ux_m, uy_m=uy_m, uz_m=uz_m,
+                                ux_th=ux_th, uy_th=uy_th, uz_th=uz_th,
+                                continuous_injection=continuous_injection,
+                                dz_particles=dz_particles, is_tracer=is_tracer)
+        if self.fld.data_is_on_gpu:
+            new_species.send_particles_to_gpu()
+        self.ptcl.append(new_species)
+        return new_species
+
+
+def adapt_to_grid(x, p_xmin, p_xmax, p_nx, ncells_empty=0):
+    """Snap [p_xmin, p_xmax] to cell edges of the grid x and count p_nx particles per
+    enclosed cell (main.py:1056-1111)."""
+    xmin, xmax = x.min(), x.max()
+    dx = x[1] - x[0]
+    if p_xmin < xmin - 0.5 * dx:
+        p_xmin = xmin - 0.5 * dx
+    if p_xmax > xmax + (0.5 - ncells_empty) * dx:
+        p_xmax = xmax + (0.5 - ncells_empty) * dx
+    x_load = x[(x > p_xmin) & (x < p_xmax)]
+    Npx = len(x_load) * p_nx
+    if Npx > 0:
+        p_xmin = x_load.min() - 0.5 * dx
+        p_xmax = x_load.max() + 0.5 * dx
+    return p_xmin, p_xmax, Npx

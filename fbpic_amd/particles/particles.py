@@ -1,0 +1,220 @@
+"""`Particles`: one macroparticle species (structure of arrays) and its kernels.
+
+Same surface as the reference class (fbpic/particles/particles.py:52-1094): attributes
+x, y, z, ux, uy, uz, inv_gamma, w, Ex..Bz, q, m, Ntot, cell_idx, sorted_idx, prefix_sum,
+sorted, keep_fields_sorted; methods push_p, push_x, gather, deposit, sort_particles,
+rearrange_particle_arrays, send_particles_to_gpu, receive_particles_from_gpu.
+Every compute method launches a HIP kernel of libfbpic_amd.so; nothing runs on the host.
+"""
+import numpy as np
+from scipy.constants import c
+from .. import _capi
+from .injection import generate_evenly_spaced
+
+_SHAPE = {'linear': 1, 'cubic': 3}
+_STATE = ('x', 'y', 'z', 'ux', 'uy', 'uz', 'w', 'inv_gamma')
+_FIELDS = ('Ex', 'Ey', 'Ez', 'Bx', 'By', 'Bz')
+
+
+class Particles(object):
+    def __init__(self, q, m, n, Npz, zmin, zmax, Npr, rmin, rmax, Nptheta, dt,
+                 ux_m=0., uy_m=0., uz_m=0., ux_th=0., uy_th=0., uz_th=0.,
+                 dens_func=None, continuous_injection=True, grid_shape=None,
+                 particle_shape='linear', use_cuda=True, dz_particles=None, is_tracer=False):
+        if particle_shape not in _SHAPE:
+            raise ValueError("`particle_shape` should be either 'linear' or 'cubic' "
+                             "but is `%s`" % particle_shape)
+        self.use_cuda = use_cuda
+        self.data_is_on_gpu = False
+        Ntot, x, y, z, ux, uy, uz, inv_gamma, w = generate_evenly_spaced(
+            Npz, zmin, zmax, Npr, rmin, rmax, Nptheta, n, dens_func,
+            ux_m, uy_m, uz_m, ux_th, uy_th, uz_th)
+        self.Ntot = Ntot
+        self.q, self.m, self.dt = q, m, dt
+        self.is_tracer = is_tracer
+        self.x, self.y, self.z = x, y, z
+        self.ux, self.uy, self.uz = ux, uy, uz
+        self.inv_gamma, self.w = inv_gamma, w
+        for k in _FIELDS:
+            setattr(self, k, np.zeros(Ntot))
+        # continuous injection (moving window) is a "next" row: keep the flag only
+        self.continuous_injection = continuous_injection
+        self.injector = None
+        self.tracker = None
+        self.ionizer = None
+        self.compton_scatterer = None
+        self.n_integer_quantities = 0
+        self.n_float_quantities = 8
+        self.particle_shape = particle_shape
+        self.keep_fields_sorted = False
+        if grid_shape is None:
+            raise ValueError("A `grid_shape` is needed (the HIP backend sorts particles per cell).")
+        self.grid_shape = grid_shape
+        self.prefix_sum_shift = 0
+        self.sorted = False
+        # device-only helpers (allocated in send_particles_to_gpu)
+        self.cell_idx = None
+        self.sorted_idx = None
+        self.prefix_sum = None
+        self.sorting_buffer = None
+        self._alt = None
+        self._sort_ws = None
+
+    # ---------------------------------------------------------------- host <-> device
+    def _alloc_device_helpers(self):
+        t = _capi.torch()
+        dev = _capi.require_device()
+        Nz, Nr = self.grid_shape
+        n = self.Ntot
+        ncell = Nz * (Nr + 1)
+        self.cell_idx = t.empty(n, dtype=t.int32, device=dev)
+        self.sorted_idx = t.empty(n, dtype=t.int32, device=dev)
+        self.prefix_sum = t.zeros(ncell, dtype=t.int32, device=dev)
+        self._alt = [t.empty(n, dtype=t.float64, device=dev) for _ in range(14)]
+        self.sorting_buffer = self._alt[0]
+        nbytes = int(_capi.lib().fb_sort_workspace_bytes(n, ncell))
+        self._sort_ws = t.empty(nbytes, dtype=t.uint8, device=dev)
+
+    def send_particles_to_gpu(self):
+        if self.data_is_on_gpu:
+            return
+        for k in _STATE + _FIELDS:
+            setattr(self, k, _capi.to_device(getattr(self, k), dtype=np.float64))
+        if self.cell_idx is None or self.cell_idx.shape[0] != self.Ntot:
+            self._alloc_device_helpers()
+        self.sorted = False
+        self.data_is_on_gpu = True
+
+    def receive_particles_from_gpu(self):
+        if not self.data_is_on_gpu:
+            return
+        for k in _STATE + _FIELDS:
+            setattr(self, k, _capi.to_host(getattr(self, k)))
+        self.data_is_on_gpu = False
+
+    def _need_gpu(self):
+        if not self.data_is_on_gpu:
+            raise _capi.BackendError(
+                'Particle data is on the host: fbpic_amd only computes on the GPU. Call '
+                'send_particles_to_gpu() (or use GpuMemoryManager / Simulation.step) first.')
+
+    def handle_elementary_processes(self, t):
+        """Ionization / Compton scattering are outside the hot path: nothing to do."""
+        return
+
+    # ---------------------------------------------------------------- pushers
+    def push_p(self, t):
+        """Vay push of (ux, uy, uz, inv_gamma) by one step (reference :557-636)."""
+        if self.q == 0:
+            return
+        self._need_gpu()
+        p = _capi.ptr
+        rc = _capi.lib().fb_push_p(self.Ntot, p(self.ux), p(self.uy), p(self.uz), p(self.inv_gamma),
+                                   p(self.Ex), p(self.Ey), p(self.Ez), p(self.Bx), p(self.By),
+                                   p(self.Bz), self.q, self.m, c, self.dt, _capi.stream())
+        _capi.check(rc, 'fb_push_p')
+
+    def push_x(self, dt, x_push=1., y_push=1., z_push=1.):
+        """x += c dt inv_gamma push u (reference :639-671); invalidates the cell sort."""
+        self._need_gpu()
+        p = _capi.ptr
+        rc = _capi.lib().fb_push_x(self.Ntot, p(self.x), p(self.y), p(self.z), p(self.ux),
+                                   p(self.uy), p(self.uz), p(self.inv_gamma), c, dt,
+                                   x_push, y_push, z_push, _capi.stream())
+        _capi.check(rc, 'fb_push_x')
+        self.sorted = False
+
+    # ---------------------------------------------------------------- gather
+    def gather(self, grid, comm):
+        """Interpolate E, B of all modes onto the particles (reference :673-837)."""
+        if self.q == 0:
+            return
+        self._need_gpu()
+        Nm = len(grid)
+        rmax_gather = comm.get_rmax(with_damp=False)
+        g0 = grid[0]
+        views = []
+        for m in range(Nm):
+            views += [grid[m].Er, grid[m].Et, grid[m].Ez, grid[m].Br, grid[m].Bt, grid[m].Bz]
+        p = _capi.ptr
+        rc = _capi.lib().fb_gather(_SHAPE[self.particle_shape], Nm, self.Ntot,
+                                   p(self.x), p(self.y), p(self.z), rmax_gather,
+                                   g0.invdz, g0.zmin, g0.Nz, g0.invdr, g0.rmin, g0.Nr,
+                                   _capi.ptr_array(views), _capi.row_stride(views[0]),
+                                   p(self.Ex), p(self.Ey), p(self.Ez), p(self.Bx), p(self.By),
+                                   p(self.Bz), _capi.stream())
+        _capi.check(rc, 'fb_gather')
+
+    # ---------------------------------------------------------------- sort
+    def sort_particles(self, fld):
+        """Cell index -> stable radix sort -> per-cell prefix sum -> permutation
+        (reference :1049-1094)."""
+        self._need_gpu()
+        g0 = fld.interp[0]
+        lib = _capi.lib()
+        p = _capi.ptr
+        st = _capi.stream()
+        rc = lib.fb_cell_index(self.Ntot, p(self.x), p(self.y), p(self.z), g0.invdz, g0.zmin,
+                               g0.Nz, g0.invdr, g0.rmin, g0.Nr, p(self.cell_idx),
+                               p(self.sorted_idx), st)
+        _capi.check(rc, 'fb_cell_index')
+        rc = lib.fb_sort_by_cell(self.Ntot, self.prefix_sum.shape[0], p(self.cell_idx),
+                                 p(self.sorted_idx), p(self.prefix_sum), p(self._sort_ws),
+                                 self._sort_ws.shape[0], st)
+        _capi.check(rc, 'fb_sort_by_cell')
+        self.prefix_sum_shift = 0
+        self.rearrange_particle_arrays()
+
+    def rearrange_particle_arrays(self):
+        """Apply sorted_idx to every particle attribute in one launch (ping-pong buffers)."""
+        names = list(_STATE)
+        if self.keep_fields_sorted:
+            names += list(_FIELDS)
+        src = [getattr(self, k) for k in names]
+        dst = self._alt[:len(names)]
+        rc = _capi.lib().fb_permute(self.Ntot, _capi.ptr(self.sorted_idx), len(names),
+                                    _capi.ptr_array(src), _capi.ptr_array(dst), _capi.stream())
+        _capi.check(rc, 'fb_permute')
+        for i, k in enumerate(names):
+            setattr(self, k, dst[i])
+            self._alt[i] = src[i]
+        self.sorting_buffer = self._alt[0]
+
+    # ---------------------------------------------------------------- deposit
+    def deposit(self, fld, fieldtype):
+        """Deposit rho or J of this species on the interpolation grid (reference :839-1046)."""
+        if self.q == 0:
+            return
+        assert fieldtype in ['rho', 'J']
+        self._need_gpu()
+        if not self.sorted:
+            self.sort_particles(fld=fld)
+            self.sorted = True
+        grid = fld.interp
+        Nm = len(grid)
+        g0 = grid[0]
+        weight = self.w
+        suffix = 'linear' if self.particle_shape == 'linear' else 'cubic'
+        ruy0 = getattr(grid[0], 'd_ruyten_%s_coef' % suffix)
+        ruyh = getattr(grid[1 if Nm > 1 else 0], 'd_ruyten_%s_coef' % suffix)
+        lib = _capi.lib()
+        p = _capi.ptr
+        if fieldtype == 'rho':
+            views = [grid[m].rho for m in range(Nm)]
+            rc = lib.fb_deposit_rho(_SHAPE[self.particle_shape], Nm, self.Ntot, p(self.x),
+                                    p(self.y), p(self.z), p(weight), self.q, g0.invdz, g0.zmin,
+                                    g0.Nz, g0.invdr, g0.rmin, g0.Nr, _capi.ptr_array(views),
+                                    _capi.row_stride(views[0]), p(self.prefix_sum), p(ruy0),
+                                    p(ruyh), _capi.stream())
+            _capi.check(rc, 'fb_deposit_rho')
+        else:
+            views = []
+            for m in range(Nm):
+                views += [grid[m].Jr, grid[m].Jt, grid[m].Jz]
+            rc = lib.fb_deposit_J(_SHAPE[self.particle_shape], Nm, self.Ntot, p(self.x), p(self.y),
+                                  p(self.z), p(weight), self.q, p(self.ux), p(self.uy), p(self.uz),
+                                  p(self.inv_gamma), c, g0.invdz, g0.zmin, g0.Nz, g0.invdr,
+                                  g0.rmin, g0.Nr, _capi.ptr_array(views),
+                                  _capi.row_stride(views[0]), p(self.prefix_sum), p(ruy0), p(ruyh),
+                                  _capi.stream())
+            _capi.check(rc, 'fb_deposit_J')

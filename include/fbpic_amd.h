@@ -1,0 +1,183 @@
+/*
+ * fbpic_amd.h -- C ABI of libfbpic_amd.so: the MI355X (gfx950) backend for FBPIC's
+ * per-step PIC cycle.
+ *
+ * The reference (pure Python) has no FFI on this path; its backend boundary is the
+ * `use_cuda` branch of every Particles / Fields / SpectralGrid / DHT / FFT method,
+ * where a Numba-CUDA kernel is launched as `kernel[grid, block](*device_arrays, *scalars)`
+ * (SURVEY.md 8b).  Each entry point below replaces exactly one of those launch sites
+ * (cited per function, paths relative to fbpic/), keeps the reference's argument order
+ * and meaning, and adds only what a C ABI needs: explicit sizes, an explicit row stride
+ * for (Nz, Nr) grids, the physical constants the reference reads from scipy.constants,
+ * and a trailing hipStream_t.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter is documented "host";
+ *   - grids are complex128, r contiguous, `row_stride` = complex elements between
+ *     consecutive z rows (== Nr for the reference's C-contiguous (Nz, Nr) arrays);
+ *   - particle arrays are float64[n] (structure of arrays);
+ *   - all functions are asynchronous on `stream`, return 0 on success and a non-zero
+ *     hipError_t / rocfft_status otherwise (fb_last_error() gives the text); none throws.
+ *   - ownership: the caller owns every buffer; the library owns only FFT plans.
+ */
+#ifndef FBPIC_AMD_H
+#define FBPIC_AMD_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FB_SHAPE_LINEAR 1
+#define FB_SHAPE_CUBIC 3
+#define FB_MAX_MODES 8
+
+/* ---- runtime ---------------------------------------------------------------- */
+int fb_abi_version(void);
+const char *fb_last_error(void);
+/* utils/cuda.py:261-299 (GPU selection) -> explicit device binding per process */
+int fb_set_device(int device);
+int fb_sync(void *stream);
+
+/* ---- particle push ---------------------------------------------------------- */
+/* particles/particles.py:660-663 -> push_x_gpu (push/cuda_methods.py:16-52);
+ * arithmetic order of the CPU twin push_x_numba (push/numba_methods.py:16-32). */
+int fb_push_x(long n, double *x, double *y, double *z,
+              const double *ux, const double *uy, const double *uz,
+              const double *inv_gamma, double c, double dt,
+              double x_push, double y_push, double z_push, void *stream);
+
+/* particles/particles.py:609-613 -> push_p_gpu (push/cuda_methods.py:54-99),
+ * Vay pusher push/inline_functions.py:11-48. */
+int fb_push_p(long n, double *ux, double *uy, double *uz, double *inv_gamma,
+              const double *Ex, const double *Ey, const double *Ez,
+              const double *Bx, const double *By, const double *Bz,
+              double q, double m, double c, double dt, void *stream);
+
+/* boundaries/particle_buffer_handling.py:528-531 -> shift_particles_periodic_cuda */
+int fb_shift_periodic(long n, double *z, double zmin, double zmax, void *stream);
+
+/* ---- gather ------------------------------------------------------------------ */
+/* particles/particles.py:703-800 -> gather_field_gpu_{linear,cubic}[_one_mode]
+ * (gathering/cuda_methods.py:26,209; cuda_methods_one_mode.py:22,46,216).
+ * One launch for any Nm.  grids (HOST array of 6*Nm device pointers): for mode m,
+ * grids[6m..6m+5] = Er, Et, Ez, Br, Bt, Bz. */
+int fb_gather(int shape, int Nm, long n,
+              const double *x, const double *y, const double *z, double rmax_gather,
+              double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
+              const void *const *grids, long row_stride,
+              double *Ex, double *Ey, double *Ez, double *Bx, double *By, double *Bz,
+              void *stream);
+
+/* ---- cell sort ---------------------------------------------------------------- */
+/* particles/particles.py:1075-1081 -> get_cell_idx_per_particle
+ * (utilities/cuda_sorting.py:21-88): cell_idx = ir_upper + iz_upper*(Nr+1);
+ * sorted_idx[i] = i. */
+int fb_cell_index(long n, const double *x, const double *y, const double *z,
+                  double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
+                  int *cell_idx, int *sorted_idx, void *stream);
+
+/* particles/particles.py:1083-1092 -> sort_particles_per_cell (Thrust argsort,
+ * cuda_sorting.py:90-122) + prefill_prefix_sum + incl_prefix_sum (:124-190).
+ * Stable radix sort (rocPRIM) of (cell_idx, sorted_idx) in place, then the inclusive
+ * per-cell particle count prefix_sum[ncell].  workspace: fb_sort_workspace_bytes(). */
+size_t fb_sort_workspace_bytes(long n, int ncell);
+int fb_sort_by_cell(long n, int ncell, int *cell_idx, int *sorted_idx, int *prefix_sum,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* particles/particles.py:519-538 -> write_sorting_buffer (cuda_sorting.py:192-213),
+ * all attributes in one launch: dst[k][i] = src[k][sorted_idx[i]].
+ * src, dst: HOST arrays of nattr device pointers (nattr <= 16). */
+int fb_permute(long n, const int *sorted_idx, int nattr,
+               const double *const *src, double *const *dst, void *stream);
+
+/* ---- deposition ---------------------------------------------------------------- */
+/* particles/particles.py:893-936 -> deposit_rho_gpu_{linear,cubic}[_one_mode]
+ * (deposition/cuda_methods.py:27,465; cuda_methods_one_mode.py).  Particles must be
+ * cell-sorted (prefix_sum from fb_sort_by_cell).  rho: HOST array of Nm device pointers.
+ * ruyten_m0 / ruyten_mh: Ruyten coefficients (Nr+1) for mode 0 / modes >= 1. */
+int fb_deposit_rho(int shape, int Nm, long n,
+                   const double *x, const double *y, const double *z, const double *w, double q,
+                   double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
+                   void *const *rho, long row_stride,
+                   const int *prefix_sum, const double *ruyten_m0, const double *ruyten_mh,
+                   void *stream);
+
+/* particles/particles.py:937-985 -> deposit_J_gpu_{linear,cubic}[_one_mode]
+ * (deposition/cuda_methods.py:201,750).  J: HOST array of 3*Nm device pointers,
+ * J[3m..3m+2] = Jr, Jt, Jz of mode m. */
+int fb_deposit_J(int shape, int Nm, long n,
+                 const double *x, const double *y, const double *z, const double *w, double q,
+                 const double *ux, const double *uy, const double *uz, const double *inv_gamma,
+                 double c,
+                 double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
+                 void *const *J, long row_stride,
+                 const int *prefix_sum, const double *ruyten_m0, const double *ruyten_mh,
+                 void *stream);
+
+/* ---- interpolation-grid kernels ------------------------------------------------ */
+/* fields/interpolation_grid.py:236-250 -> cuda_erase_scalar/vector (fields/cuda_methods.py:18,40).
+ * ptrs: HOST array of nfields device pointers (nfields <= 48). */
+int fb_erase(int nfields, void *const *ptrs, long row_stride, int Nz, int Nr, void *stream);
+/* fields/interpolation_grid.py:286-296 -> cuda_divide_{scalar,vector}_by_volume (:68,92) */
+int fb_divide_by_volume(int nfields, void *const *ptrs, long row_stride,
+                        const double *invvol, int Nz, int Nr, void *stream);
+
+/* ---- spectral-grid kernels ------------------------------------------------------ */
+/* fields/spectral_grid.py:437-454 -> cuda_filter_{scalar,vector} (fields/cuda_methods.py:467,492) */
+int fb_filter(int nfields, void *const *ptrs, long row_stride,
+              const double *filter_z, const double *filter_r, int Nz, int Nr, void *stream);
+/* fields/spectral_grid.py:225-230 -> cuda_correct_currents_curlfree_standard (:121).
+ * kz, kr, inv_k2: real (Nz, Nr) contiguous, as the reference's d_kz/d_kr/d_inv_k2. */
+int fb_correct_currents_curlfree_standard(const void *rho_prev, const void *rho_next,
+        void *Jp, void *Jm, void *Jz, long row_stride,
+        const double *kz, const double *kr, const double *inv_k2, double inv_dt,
+        int Nz, int Nr, void *stream);
+/* fields/spectral_grid.py:350-355 -> cuda_push_eb_standard (:235); same argument order
+ * as numba_push_eb_standard (fields/numba_methods.py:118-185) + c, epsilon_0, mu_0. */
+int fb_push_eb_standard(void *Ep, void *Em, void *Ez, void *Bp, void *Bm, void *Bz,
+        const void *Jp, const void *Jm, const void *Jz,
+        const void *rho_prev, const void *rho_next, long row_stride,
+        const double *rho_prev_coef, const double *rho_next_coef, const double *j_coef,
+        const double *C, const double *S_w, const double *kr, const double *kz,
+        double dt, int use_true_rho, double c, double epsilon_0, double mu_0,
+        int Nz, int Nr, void *stream);
+/* fields/spectral_grid.py:416-417 -> cuda_push_rho (:443) */
+int fb_push_rho(void *rho_prev, void *rho_next, long row_stride, int Nz, int Nr, void *stream);
+/* fields/spectral_transform/spectral_transformer.py:140-142, 208-210 ->
+ * cuda_pm_to_rt / cuda_rt_to_pm (spectral_transform/cuda_methods.py:119,140).
+ * In-place allowed (p aliases r, m aliases t), as in the reference's shared buffers. */
+int fb_rt_to_pm(int npairs, const void *const *r, const void *const *t,
+                void *const *p, void *const *m, long row_stride, int Nz, int Nr, void *stream);
+int fb_pm_to_rt(int npairs, const void *const *p, const void *const *m,
+                void *const *r, void *const *t, long row_stride, int Nz, int Nr, void *stream);
+/* cupy.multiply(..., 1/Nz) of fourier.py:157 for the FFT-only (partial) transforms */
+int fb_scale(int nfields, void *const *ptrs, long row_stride, double factor,
+             int Nz, int Nr, void *stream);
+
+/* ---- FFT along z (rocFFT) --------------------------------------------------------- */
+/* fields/spectral_transform/fourier.py:78 (cufft Plan1d) and :116-160.
+ * One plan transforms `ncols` columns at once: element (iz, col) lives at
+ * base + iz*stride + col (stride in complex elements), i.e. a (Nz, ncols) strided view
+ * covering one or several side-by-side (Nz, Nr) grids.  No transpose copies.
+ * direction: -1 forward (unnormalised), +1 backward (unnormalised: the 1/Nz of
+ * fourier.py:157 is folded into the consumer, see fb_hankel / fb_scale). */
+int fb_fft_plan_create(int Nz, long ncols, long in_stride, long out_stride, int inplace,
+                       void **plan_fwd_bwd);
+int fb_fft_exec(void *plan, int direction, const void *in, void *out, void *stream);
+int fb_fft_plan_destroy(void *plan);
+
+/* ---- Hankel transform along r (fp64 MFMA GEMM) ------------------------------------ */
+/* fields/spectral_transform/hankel.py:196-205, 227-236 (copy_2dC_to_2dR + cublas dgemm
+ * + copy_2dR_to_2dC).  For each job j < njobs:
+ *     out_j[iz, :] = alpha * ( in_j[iz, :] . mat_j )        (complex row times real matrix)
+ * in/out/mat: HOST arrays of njobs device pointers; mat_j is (Nr, Nr) float64 row-major
+ * (the reference's M / invM).  The complex<->real split of the reference is fused into
+ * the operand loads/stores. */
+int fb_hankel(int njobs, const void *const *in, long in_row_stride,
+              void *const *out, long out_row_stride, const double *const *mat,
+              double alpha, int Nz, int Nr, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

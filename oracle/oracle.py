@@ -390,3 +390,46 @@ class OracleSim:
             self.iteration += 1
         self.spect2interp('J')
         self.spect2interp('rho_prev')
+
+
+PTCL = ['x', 'y', 'z', 'ux', 'uy', 'uz', 'inv_gamma', 'w', 'Ex', 'Ey', 'Ez', 'Bx', 'By', 'Bz']
+
+
+def tables_from_sim(sim):
+    """Host setup tables (NumPy) of an fbpic_amd `Simulation` in the form OracleSim
+    expects.  Only host-side setup data is read (matrices, coefficient tables, volumes);
+    those tables are pinned against the reference in tests/test_host_setup.py."""
+    fld = sim.fld
+    tabs = []
+    for m in range(fld.Nm):
+        tr, sp, ps, it = fld.trans[m], fld.spect[m], fld.psatd[m], fld.interp[m]
+        tabs.append(dict(
+            M0=tr.dht0.M, invM0=tr.dht0.invM, Mp=tr.dhtp.M, invMp=tr.dhtp.invM,
+            Mm=tr.dhtm.M, invMm=tr.dhtm.invM,
+            kz=np.ascontiguousarray(sp.kz), kr=np.ascontiguousarray(sp.kr),
+            inv_k2=np.ascontiguousarray(sp.inv_k2),
+            filter_z=sp.filter_array_z, filter_r=sp.filter_array_r,
+            C=ps.C, S_w=ps.S_w, j_coef=ps.j_coef, rho_prev_coef=ps.rho_prev_coef,
+            rho_next_coef=ps.rho_next_coef, invvol=it.invvol,
+            ruyten_linear=it.ruyten_linear_coef, ruyten_cubic=it.ruyten_cubic_coef))
+    return tabs
+
+
+def from_sim(sim, nthreads=1):
+    """OracleSim holding a private host copy of the state of `sim` (which must be on the
+    host): same inputs, independent compute path."""
+    fld = sim.fld
+    g0 = fld.interp[0]
+    species = []
+    for s in sim.ptcl:
+        d = dict(q=s.q, m=s.m)
+        for k in PTCL:
+            d[k] = np.array(getattr(s, k), dtype=np.float64, copy=True)
+        species.append(d)
+    o = OracleSim(fld.Nz, fld.Nr, fld.Nm, g0.zmin, g0.zmax, fld.rmax, sim.dt,
+                  sim.particle_shape, tables_from_sim(sim), species, nthreads=nthreads,
+                  filter_currents=sim.filter_currents)
+    for m in range(fld.Nm):
+        for k in INTERP:
+            o.interp[m][k][:] = getattr(fld.interp[m], k)
+    return o

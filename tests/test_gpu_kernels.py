@@ -1,0 +1,355 @@
+"""Kernel-level parity: every C-ABI entry point of libfbpic_amd.so on the MI355X against
+the CPU oracle (oracle/, itself pinned to the reference) and the golden vectors.
+
+Tolerances: cell indices bit-exact; push bit-exact against the oracle (same
+operation order, no FMA contraction, IEEE sqrt/div); gather / field kernels 1e-13 of
+max|array|; deposition / transforms 1e-13 * max|F| (the reference's own CPU<->GPU bound,
+tests/test_cpu_gpu_deposition.py:96).
+"""
+import ctypes
+import numpy as np
+import pytest
+from scipy.constants import c, e, m_e, epsilon_0, mu_0
+from conftest import golden, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-13
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from fbpic_amd import _capi
+    _capi.require_device()
+    return _capi
+
+
+def dev(hip, a, dtype=None):
+    return hip.to_device(np.ascontiguousarray(a, dtype=dtype))
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------ push
+@pytest.mark.parametrize('n', [4096, 4095, 1])
+def test_push_bit_exact(hip, oracle, n):
+    g = golden('push')
+    dt = float(g['dt'])
+    names = ('ux', 'uy', 'uz', 'inv_gamma', 'Ex', 'Ey', 'Ez', 'Bx', 'By', 'Bz', 'x', 'y', 'z')
+    h = {k: g['in_' + k][:n].copy() for k in names}
+    d = {k: dev(hip, h[k]) for k in names}
+    p = hip.ptr
+    rc = hip.lib().fb_push_p(n, p(d['ux']), p(d['uy']), p(d['uz']), p(d['inv_gamma']),
+                             p(d['Ex']), p(d['Ey']), p(d['Ez']), p(d['Bx']), p(d['By']), p(d['Bz']),
+                             -e, m_e, c, dt, hip.stream())
+    hip.check(rc, 'fb_push_p')
+    oracle.push_p(h['ux'], h['uy'], h['uz'], h['inv_gamma'], h['Ex'], h['Ey'], h['Ez'],
+                  h['Bx'], h['By'], h['Bz'], -e, m_e, dt)
+    for k in ('ux', 'uy', 'uz', 'inv_gamma'):
+        assert np.array_equal(host(d[k]), h[k]), k
+        ref = g['pp_e_' + k][:n]
+        assert np.all(np.abs(h[k] - ref) <= 4e-15 * np.abs(ref) + 1e-300)
+    rc = hip.lib().fb_push_x(n, p(d['x']), p(d['y']), p(d['z']), p(d['ux']), p(d['uy']), p(d['uz']),
+                             p(d['inv_gamma']), c, 0.5 * dt, 1., 1., 1., hip.stream())
+    hip.check(rc, 'fb_push_x')
+    for k, gk in (('x', 'px_x'), ('y', 'px_y'), ('z', 'px_z')):
+        assert np.array_equal(host(d[k]), g[gk][:n]), k   # bit-exact vs the reference itself
+
+
+def test_shift_periodic(hip, oracle):
+    rng = np.random.default_rng(5)
+    z = rng.uniform(-3., 4., 10001)
+    dz = dev(hip, z)
+    hip.check(hip.lib().fb_shift_periodic(z.size, hip.ptr(dz), 0.25, 1.5, hip.stream()), 'shift')
+    oracle.shift_periodic(z, 0.25, 1.5)
+    assert np.array_equal(host(dz), z)
+    assert z.min() >= 0.25 and z.max() < 1.5
+
+
+# ------------------------------------------------------------------ gather
+def _gather_gpu(hip, g, shape, nm, slab):
+    Nz, Nr = int(g['Nz']), int(g['Nr'])
+    n = g['x'].size
+    t = hip.torch()
+    if slab:   # z-major slab views (row stride 6*nm*Nr), as used by Fields
+        s = t.empty((Nz, 6 * nm, Nr), dtype=t.complex128, device='cuda')
+        for m in range(nm):
+            for k in range(6):
+                s[:, 6 * m + k, :] = dev(hip, g['grids'][m, k])
+        views = [s[:, j, :] for j in range(6 * nm)]
+    else:
+        views = [dev(hip, g['grids'][m, k]) for m in range(nm) for k in range(6)]
+    x, y, z = dev(hip, g['x']), dev(hip, g['y']), dev(hip, g['z'])
+    F = [t.full((n,), 7., dtype=t.float64, device='cuda') for _ in range(6)]
+    p = hip.ptr
+    rc = hip.lib().fb_gather(1 if shape == 'linear' else 3, nm, n, p(x), p(y), p(z),
+                             float(g['rmax_gather']), 1. / float(g['dz']), float(g['zmin']), Nz,
+                             1. / float(g['dr']), 0., Nr, hip.ptr_array(views),
+                             hip.row_stride(views[0]), *[p(f) for f in F], hip.stream())
+    hip.check(rc, 'fb_gather')
+    return np.array([host(f) for f in F])
+
+
+@pytest.mark.parametrize('shape', ['linear', 'cubic'])
+@pytest.mark.parametrize('slab', [False, True])
+def test_gather(hip, oracle, shape, slab):
+    g = golden('gather')
+    got = _gather_gpu(hip, g, shape, 2, slab)
+    assert rel_err(got, g['%s_nm2' % shape]) < TOL
+    for nm in (1, 3, 4):
+        got = _gather_gpu(hip, g, shape, nm, slab)
+        assert rel_err(got, g['%s_nm%d_onemode' % (shape, nm)]) < TOL
+    out = np.hypot(g['x'], g['y']) >= float(g['rmax_gather'])
+    assert np.all(got[:, out] == 0.)
+
+
+# ------------------------------------------------------------------ cell index / sort
+def _sort(hip, x, y, z, geom, Nz, Nr):
+    t = hip.torch()
+    n = x.size
+    ncell = Nz * (Nr + 1)
+    dx, dy, dz_ = dev(hip, x), dev(hip, y), dev(hip, z)
+    ci = t.empty(n, dtype=t.int32, device='cuda')
+    si = t.empty(n, dtype=t.int32, device='cuda')
+    pre = t.full((ncell,), -1, dtype=t.int32, device='cuda')
+    p = hip.ptr
+    hip.check(hip.lib().fb_cell_index(n, p(dx), p(dy), p(dz_), *geom, p(ci), p(si), hip.stream()), 'ci')
+    ci0 = host(ci).copy()
+    nb = int(hip.lib().fb_sort_workspace_bytes(n, ncell))
+    ws = t.empty(nb, dtype=t.uint8, device='cuda')
+    hip.check(hip.lib().fb_sort_by_cell(n, ncell, p(ci), p(si), p(pre), p(ws), nb, hip.stream()), 'sort')
+    return ci0, host(ci), host(si), host(pre), (dx, dy, dz_, si)
+
+
+def test_cell_index_and_sort(hip, oracle):
+    g = golden('deposit')
+    Nz, Nr = int(g['Nz']), int(g['Nr'])
+    geom = (1. / float(g['dz']), float(g['zmin']), Nz, 1. / float(g['dr']), 0., Nr)
+    ci0, cis, si, pre, (dx, dy, dz_, dsi) = _sort(hip, g['x'], g['y'], g['z'], geom, Nz, Nr)
+    ref = oracle.cell_index(g['x'], g['y'], g['z'], *geom)
+    assert np.array_equal(ci0, ref)                      # bit-exact particle -> cell index
+    order = np.argsort(ref, kind='stable')               # Thrust argsort is stable too
+    assert np.array_equal(si, order.astype(np.int32))
+    assert np.array_equal(cis, ref[order])
+    counts = np.bincount(ref, minlength=Nz * (Nr + 1))
+    assert np.array_equal(pre, np.cumsum(counts).astype(np.int32))
+    # permutation of several attributes in one launch
+    t = hip.torch()
+    src = [dx, dy, dz_]
+    dst = [t.empty_like(dx) for _ in range(3)]
+    hip.check(hip.lib().fb_permute(dx.shape[0], hip.ptr(dsi), 3, hip.ptr_array(src),
+                                   hip.ptr_array(dst), hip.stream()), 'permute')
+    for a, b in zip((g['x'], g['y'], g['z']), dst):
+        assert np.array_equal(host(b), a[order])
+
+
+def test_cell_index_large_random(hip, oracle):
+    rng = np.random.default_rng(11)
+    n, Nz, Nr = 1 << 20, 256, 64
+    dzc = 0.2e-6
+    r = rng.uniform(0, 1.05 * Nr * dzc, n)
+    th = rng.uniform(0, 2 * np.pi, n)
+    x, y = r * np.cos(th), r * np.sin(th)
+    z = rng.uniform(0, Nz * dzc, n)
+    geom = (1. / dzc, 0., Nz, 1. / dzc, 0., Nr)
+    ci0, cis, si, pre, _ = _sort(hip, x, y, z, geom, Nz, Nr)
+    ref = oracle.cell_index(x, y, z, *geom)
+    assert np.array_equal(ci0, ref)
+    assert np.all(np.diff(cis) >= 0) and pre[-1] == n
+    assert np.array_equal(np.sort(si), np.arange(n, dtype=np.int32))
+
+
+# ------------------------------------------------------------------ deposition
+def _deposit_gpu(hip, g, shape, Nm, what, b0, bh, slab=False):
+    Nz, Nr = int(g['Nz']), int(g['Nr'])
+    geom = (1. / float(g['dz']), float(g['zmin']), Nz, 1. / float(g['dr']), 0., Nr)
+    t = hip.torch()
+    _, _, si, pre, _ = _sort(hip, g['x'], g['y'], g['z'], geom, Nz, Nr)
+    names = ('x', 'y', 'z', 'w', 'ux', 'uy', 'uz', 'inv_gamma')
+    d = {k: dev(hip, g[k][si]) for k in names}            # sorted particle arrays
+    dpre = dev(hip, pre)
+    ncomp = 1 if what == 'rho' else 3
+    if slab:
+        s = t.zeros((Nz, ncomp * Nm + 1, Nr), dtype=t.complex128, device='cuda')
+        views = [s[:, j, :] for j in range(ncomp * Nm)]
+    else:
+        views = [t.zeros((Nz, Nr), dtype=t.complex128, device='cuda') for _ in range(ncomp * Nm)]
+    p = hip.ptr
+    sh = 1 if shape == 'linear' else 3
+    db0, dbh = dev(hip, b0), dev(hip, bh)
+    if what == 'rho':
+        rc = hip.lib().fb_deposit_rho(sh, Nm, g['x'].size, p(d['x']), p(d['y']), p(d['z']), p(d['w']),
+                                      float(g['q']), *geom, hip.ptr_array(views),
+                                      hip.row_stride(views[0]), p(dpre), p(db0), p(dbh), hip.stream())
+    else:
+        rc = hip.lib().fb_deposit_J(sh, Nm, g['x'].size, p(d['x']), p(d['y']), p(d['z']), p(d['w']),
+                                    float(g['q']), p(d['ux']), p(d['uy']), p(d['uz']),
+                                    p(d['inv_gamma']), c, *geom, hip.ptr_array(views),
+                                    hip.row_stride(views[0]), p(dpre), p(db0), p(dbh), hip.stream())
+    hip.check(rc, 'fb_deposit')
+    return np.array([host(v) for v in views])
+
+
+@pytest.mark.parametrize('shape', ['linear', 'cubic'])
+@pytest.mark.parametrize('Nm', [1, 2, 3, 4, 5])
+def test_deposit_vs_oracle_and_golden(hip, oracle, shape, Nm):
+    g = golden('deposit')
+    Nz, Nr = int(g['Nz']), int(g['Nr'])
+    geom = (1. / float(g['dz']), float(g['zmin']), Nz, 1. / float(g['dr']), 0., Nr)
+    sh = 'lin' if shape == 'linear' else 'cub'
+    for ruy in (1, 0):
+        b0 = g['ruy_%s_m0' % sh] if ruy else np.zeros(Nr + 1)
+        bh = (g['ruy_%s_m1' % sh] if Nm > 1 else b0) if ruy else np.zeros(Nr + 1)
+        # oracle
+        glob = oracle.deposit_rho_global(shape, Nm, g['x'], g['y'], g['z'], g['w'], float(g['q']),
+                                         *geom, b0, bh, 1)
+        red = np.zeros((Nm, Nz, Nr), complex)
+        for m in range(Nm):
+            oracle.sum_reduce(glob, m, red[m])
+        got = _deposit_gpu(hip, g, shape, Nm, 'rho', b0, bh, slab=bool(ruy))
+        assert rel_err(got, red) < TOL
+        gl = oracle.deposit_J_global(shape, Nm, g['x'], g['y'], g['z'], g['w'], float(g['q']),
+                                     g['ux'], g['uy'], g['uz'], g['inv_gamma'], *geom, b0, bh, 1)
+        gotJ = _deposit_gpu(hip, g, shape, Nm, 'J', b0, bh, slab=bool(ruy)).reshape(Nm, 3, Nz, Nr)
+        for k in range(3):
+            redk = np.zeros((Nm, Nz, Nr), complex)
+            for m in range(Nm):
+                oracle.sum_reduce(gl[k], m, redk[m])
+            assert rel_err(gotJ[:, k], redk) < TOL, (k, ruy)
+        if Nm in (1, 2, 4):   # and directly against the reference's output
+            tag = '%s_r%d_nm%d' % (shape, ruy, Nm)
+            assert rel_err(got, g['rho_' + tag]) < TOL
+            for k in range(3):
+                assert rel_err(gotJ[:, k], g['J_' + tag][k]) < TOL
+
+
+# ------------------------------------------------------------------ grid kernels
+def test_spectral_kernels(hip, oracle):
+    g = golden('spectral')
+    gs = golden('grid_setup')
+    Nm, Nz, Nr = int(g['Nm']), int(g['Nz']), int(g['Nr'])
+    dt = float(g['dt'])
+    names = ['Ep', 'Em', 'Ez', 'Bp', 'Bm', 'Bz', 'Jp', 'Jm', 'Jz', 'rho_prev', 'rho_next']
+    t = hip.torch()
+    p = hip.ptr
+    for m in range(Nm):
+        tg = 'o-1_m%d' % m
+        kz = np.repeat(gs['kz_' + tg][:, None], Nr, 1).copy()
+        kr = np.repeat(gs['kr_' + tg][None, :], Nz, 0).copy()
+        dkz, dkr, dik2 = dev(hip, kz), dev(hip, kr), dev(hip, gs['inv_k2_' + tg])
+        # slab storage with a non-trivial row stride
+        slab = t.zeros((Nz, 11, Nr), dtype=t.complex128, device='cuda')
+        a = {k: slab[:, i, :] for i, k in enumerate(names)}
+
+        def load():
+            for k in names:
+                a[k].copy_(dev(hip, g['sp_in_%s_m%d' % (k, m)]))
+        load()
+        rs = hip.row_stride(a['Jp'])
+        hip.check(hip.lib().fb_correct_currents_curlfree_standard(
+            p(a['rho_prev']), p(a['rho_next']), p(a['Jp']), p(a['Jm']), p(a['Jz']), rs,
+            p(dkz), p(dkr), p(dik2), 1. / dt, Nz, Nr, hip.stream()), 'cc')
+        for k in ('Jp', 'Jm', 'Jz'):
+            assert rel_err(host(a[k]), g['cc_%s_m%d' % (k, m)]) < TOL
+        tabs = [dev(hip, gs[k + '_' + tg]) for k in ('rho_prev_coef', 'rho_next_coef', 'j_coef', 'C', 'S_w')]
+        for utr in (0, 1):
+            load()
+            hip.check(hip.lib().fb_push_eb_standard(
+                *[p(a[k]) for k in names], rs, *[p(x) for x in tabs], p(dkr), p(dkz), dt, utr,
+                c, epsilon_0, mu_0, Nz, Nr, hip.stream()), 'push_eb')
+            for k in names[:6]:
+                assert rel_err(host(a[k]), g['pe%d_%s_m%d' % (utr, k, m)]) < TOL, (utr, k)
+        load()
+        fz, fr = dev(hip, gs['filter_z_' + tg]), dev(hip, gs['filter_r_' + tg])
+        fl = [a['Jp'], a['Jm'], a['Jz'], a['rho_next']]
+        hip.check(hip.lib().fb_filter(4, hip.ptr_array(fl), rs, p(fz), p(fr), Nz, Nr, hip.stream()), 'filter')
+        for k in ('Jp', 'Jm', 'Jz', 'rho_next'):
+            assert rel_err(host(a[k]), g['fl_%s_m%d' % (k, m)]) < TOL
+        # push_rho, erase, divide_by_volume, scale, rt<->pm
+        load()
+        hip.check(hip.lib().fb_push_rho(p(a['rho_prev']), p(a['rho_next']), rs, Nz, Nr, hip.stream()), 'pr')
+        assert np.array_equal(host(a['rho_prev']), g['sp_in_rho_next_m%d' % m])
+        assert np.all(host(a['rho_next']) == 0)
+        load()
+        inv = np.linspace(1., 2., Nr)
+        hip.check(hip.lib().fb_divide_by_volume(2, hip.ptr_array([a['Jp'], a['Jm']]), rs,
+                                                p(dev(hip, inv)), Nz, Nr, hip.stream()), 'div')
+        assert np.array_equal(host(a['Jp']), g['sp_in_Jp_m%d' % m] * inv[None, :])
+        r0, t0 = g['sp_in_Ep_m%d' % m], g['sp_in_Em_m%d' % m]
+        pp, mm = np.empty_like(r0), np.empty_like(r0)
+        oracle.rt_to_pm(r0.copy(), t0.copy(), pp, mm)
+        hip.check(hip.lib().fb_rt_to_pm(1, hip.ptr_array([a['Ep']]), hip.ptr_array([a['Em']]),
+                                        hip.ptr_array([a['Ep']]), hip.ptr_array([a['Em']]), rs,
+                                        Nz, Nr, hip.stream()), 'rt2pm')
+        assert np.array_equal(host(a['Ep']), pp) and np.array_equal(host(a['Em']), mm)
+        hip.check(hip.lib().fb_pm_to_rt(1, hip.ptr_array([a['Ep']]), hip.ptr_array([a['Em']]),
+                                        hip.ptr_array([a['Ep']]), hip.ptr_array([a['Em']]), rs,
+                                        Nz, Nr, hip.stream()), 'pm2rt')
+        rr, tt = np.empty_like(r0), np.empty_like(r0)
+        oracle.pm_to_rt(pp, mm, rr, tt)
+        assert np.array_equal(host(a['Ep']), rr) and np.array_equal(host(a['Em']), tt)
+        hip.check(hip.lib().fb_erase(3, hip.ptr_array([a['Ep'], a['Em'], a['Ez']]), rs, Nz, Nr,
+                                     hip.stream()), 'erase')
+        assert np.all(host(slab[:, :3, :]) == 0) and np.any(host(slab[:, 3, :]) != 0)
+
+
+# ------------------------------------------------------------------ FFT / Hankel
+@pytest.mark.parametrize('Nz,Nr,nf', [(32, 16, 1), (200, 64, 3), (254, 50, 2), (1024, 128, 6)])
+def test_fft_matches_numpy(hip, Nz, Nr, nf):
+    from fbpic_amd.fields.spectral_transform.fourier import fft_exec
+    rng = np.random.default_rng(3)
+    t = hip.torch()
+    a = rng.normal(size=(Nz, nf + 1, Nr)) + 1j * rng.normal(size=(Nz, nf + 1, Nr))
+    src = dev(hip, a)
+    dst = t.zeros((Nz, nf + 2, Nr), dtype=t.complex128, device='cuda')
+    fft_exec(src[:, 1, :], dst[:, 2, :], -1, ncols=nf * Nr)
+    ref = np.fft.fft(a[:, 1:, :], axis=0)
+    assert rel_err(host(dst[:, 2:, :]), ref) < TOL
+    assert np.all(host(dst[:, :2, :]) == 0)           # neighbours untouched
+    fft_exec(src[:, 1, :], dst[:, 2, :], +1, ncols=nf * Nr)
+    assert rel_err(host(dst[:, 2:, :]), np.fft.ifft(a[:, 1:, :], axis=0)) < TOL
+
+
+@pytest.mark.parametrize('Nz,Nr', [(32, 16), (100, 50), (200, 64), (1024, 128), (70, 130)])
+def test_hankel_gemm(hip, Nz, Nr):
+    """fp64 MFMA GEMM with an ASYMMETRIC matrix (catches row/column fragment swaps)."""
+    rng = np.random.default_rng(4)
+    t = hip.torch()
+    njobs = 3
+    a = rng.normal(size=(Nz, njobs, Nr)) + 1j * rng.normal(size=(Nz, njobs, Nr))
+    mats = [rng.normal(size=(Nr, Nr)) * np.exp(rng.uniform(-5, 5, size=(Nr, 1))) for _ in range(njobs)]
+    src = dev(hip, a)
+    dst = t.zeros((Nz, njobs + 1, Nr), dtype=t.complex128, device='cuda')
+    dm = [dev(hip, m) for m in mats]
+    ins = [src[:, j, :] for j in range(njobs)]
+    outs = [dst[:, j, :] for j in range(njobs)]
+    hip.check(hip.lib().fb_hankel(njobs, hip.ptr_array(ins), njobs * Nr, hip.ptr_array(outs),
+                                  (njobs + 1) * Nr, hip.ptr_array(dm), 0.5, Nz, Nr, hip.stream()), 'hk')
+    for j in range(njobs):
+        ref = 0.5 * (a[:, j, :] @ mats[j])
+        # error bound relative to sum |a||m| (ill-scaled rows): compare to the fp64 product
+        scale = (np.abs(a[:, j, :]) @ np.abs(mats[j])).max()
+        assert np.abs(host(dst[:, j, :]) - ref).max() < 1e-14 * scale
+    assert np.all(host(dst[:, njobs, :]) == 0)
+
+
+def test_transformer_vs_golden(hip):
+    from fbpic_amd.fields.spectral_transform.spectral_transformer import SpectralTransformer
+    g = golden('spectral')
+    Nz, Nr, Nm = int(g['Nz']), int(g['Nr']), int(g['Nm'])
+    t = hip.torch()
+    for m in range(Nm):
+        tr = SpectralTransformer(Nz, Nr, m, Nr * float(g['dr']))
+        a, r, tt = (dev(hip, g[k + '_m%d' % m]) for k in ('in_scal', 'in_r', 'in_t'))
+        o1 = t.empty_like(a); o2 = t.empty_like(a)
+        tr.interp2spect_scal(a, o1)
+        assert rel_err(host(o1), g['i2s_scal_m%d' % m]) < 1e-12
+        tr.spect2interp_scal(a, o1)
+        assert rel_err(host(o1), g['s2i_scal_m%d' % m]) < 1e-12
+        tr.interp2spect_vect(r, tt, o1, o2)
+        assert rel_err(host(o1), g['i2s_p_m%d' % m]) < 1e-12
+        assert rel_err(host(o2), g['i2s_m_m%d' % m]) < 1e-12
+        tr.spect2interp_vect(r, tt, o1, o2)
+        assert rel_err(host(o1), g['s2i_r_m%d' % m]) < 1e-12
+        assert rel_err(host(o2), g['s2i_t_m%d' % m]) < 1e-12
