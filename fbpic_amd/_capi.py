@@ -62,6 +62,10 @@ def lib():
                 'libfbpic_amd.so not found at %s: build it with '
                 '`make -C fbpic_amd/csrc` (or __graft_entry__.build()). '
                 'fbpic_amd has no CPU fallback.' % LIB_PATH)
+        # PyTorch-ROCm bundles its own libamdhip64 / librocfft / libhiprtc (same SONAMEs as
+        # /opt/rocm).  Import torch FIRST so that the process holds exactly one HIP runtime:
+        # the DT_NEEDED entries of libfbpic_amd.so then resolve to the copies torch loaded.
+        torch()
         _l = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             f = getattr(_l, name)
