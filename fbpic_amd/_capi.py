@@ -26,7 +26,7 @@ _SIGNATURES = {
     'fb_gather': (I, [I, I, L, P, P, P, D, D, D, I, D, D, I, _PP, L, P, P, P, P, P, P, P]),
     'fb_cell_index': (I, [L, P, P, P, D, D, I, D, D, I, P, P, P]),
     'fb_sort_workspace_bytes': (Z, [L, I]),
-    'fb_sort_by_cell': (I, [L, I, P, P, P, P, Z, P]),
+    'fb_sort_by_cell': (I, [L, I, P, P, P, P, ctypes.POINTER(I), P, P, Z, P]),
     'fb_permute': (I, [L, P, I, _PP, _PP, P]),
     'fb_deposit_rho': (I, [I, I, L, P, P, P, P, D, D, D, I, D, D, I, _PP, L, P, P, P, P]),
     'fb_deposit_J': (I, [I, I, L, P, P, P, P, D, P, P, P, P, D, D, D, I, D, D, I, _PP, L,

@@ -1,21 +1,32 @@
 // Charge / current deposition for gfx950.
 //
-// Design (MI355X-first, not the reference's one-thread-per-cell CUDA layout):
-//   * particles are cell-sorted (sort.hip); a workgroup owns a TZ x TR tile of cells and
-//     therefore a few contiguous particle ranges (one per z row of the tile) that it
-//     streams with coalesced SoA loads, one lane per macroparticle;
-//   * the tile's stencil footprint ((TZ+S-1) x (TR+S) grid nodes, all components and
-//     modes) is privatised in LDS and accumulated with ds_add_f64; the deposition guard
-//     cells of the reference (below the axis / beyond rmax / periodic z,
-//     fbpic/fields/numba_methods.py:409-461) are folded when the tile is flushed to HBM
-//     with global_atomic_add_f64;
-//   * any contribution that falls outside the LDS tile (possible only if the sort is
-//     stale) goes straight to HBM with the same folding, so the result never depends on
-//     the sort being exact -- only the speed does.
+// Design (MI355X-first; the reference's CUDA kernel is one thread per cell with serial
+// loops and 4/16 atomics per thread, fbpic/particles/deposition/cuda_methods.py:84-194):
+//
+//   * particles are cell-sorted (sort.hip), so the macroparticles of one cell are
+//     contiguous: each wave streams chunks of 64 consecutive particles with coalesced SoA
+//     loads (lane = particle) and computes, per particle, the S x S shape factors for
+//     mode 0 and modes >= 1 (Ruyten coefficient differs) and the NCOMP x NM complex mode
+//     amplitudes.  These ~20 (linear) / ~44 (cubic) doubles per particle are staged in a
+//     per-wave LDS panel (transposed + padded: conflict-free writes and reads);
+//   * then the roles flip: lane o owns ONE output value o = (node jz,jr ; component ;
+//     mode ; re/im) of the current cell and walks the 64 staged particles, accumulating
+//     weight x amplitude in a REGISTER.  All particles of a cell hit the same S x S nodes,
+//     so there is no atomic and no cross-lane reduction in the inner loop;
+//   * when the cell of the next particle differs (wave-uniform test on the staged key),
+//     the S*S*NCOMP*NM*2 registers are flushed with one global_atomic_add_f64 each, the
+//     deposition guard cells of the reference (below-axis mirror, r clamp, periodic z:
+//     fbpic/fields/numba_methods.py:409-461) being folded at that moment.  With ppc
+//     particles per cell that is ~1/ppc of the atomics of a per-particle scatter, and they
+//     are spread over distinct addresses.
+//   * correctness never depends on the sort: an unsorted (or stale-sorted) stream only
+//     flushes more often.
+//
 // Numerics: shape factors, Ruyten correction, axis flips and the mode recurrence restate
-// fbpic/particles/deposition/particle_shapes.py:17-80 and threading_methods.py:27-650.
-// Summation order differs from any CPU run (as the reference's own GPU path does):
-// parity is to 1e-13 * max|F| (tests/test_cpu_gpu_deposition.py:96).
+// fbpic/particles/deposition/particle_shapes.py:17-80 and threading_methods.py:27-650;
+// each term is ((Sz*Sr)*flip)*amplitude as in the reference, only the summation order
+// differs (as it does between the reference's own CPU and GPU paths): parity is
+// 1e-13 * max|F| (tests/test_cpu_gpu_deposition.py:96).
 #include "fb_common.h"
 
 namespace fb {
@@ -76,7 +87,21 @@ __device__ __forceinline__ void fold_node(int &iz, int &ir, int Nz, int Nr)
     if (ir < 0) ir = -ir - 1; else if (ir > Nr - 1) ir = Nr - 1;
 }
 
-// NCOMP = 1 (rho) or 3 (Jr,Jt,Jz); NM = modes handled by this launch (m0 .. m0+NM-1)
+constexpr int DEP_PAD = 65;          // panel row stride in doubles (64 particles + 1)
+constexpr int DEP_NOKEY = -0x40000000;
+
+template <int SHAPE, int NCOMP, int NM>
+struct DepLayout {
+    static constexpr int S = ShapeTraits<SHAPE>::S;
+    static constexpr int NW = 2 * S * S;              // weights: [mode0 | modes>=1][jz][jr]
+    static constexpr int NA = NCOMP * NM * 2;         // amplitudes: [comp][mode][re|im]
+    static constexpr int NOUT = S * S * NA;           // outputs of one cell
+    static constexpr int OPL = (NOUT + 63) / 64;      // outputs per lane
+    static constexpr int WAVE_DOUBLES = (NW + NA) * DEP_PAD + 1;
+    static constexpr size_t wave_bytes() { return (size_t)WAVE_DOUBLES * 8; }
+};
+
+// NCOMP = 1 (rho) or 3 (Jr,Jt,Jz); this launch handles modes m0 .. m0+NM-1
 template <int SHAPE, int NCOMP, int NM>
 __global__ __launch_bounds__(256) void k_deposit(long n,
         const double *__restrict__ x, const double *__restrict__ y,
@@ -85,34 +110,74 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
         const double *__restrict__ uz, const double *__restrict__ inv_gamma, double c_light,
         double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
         DepGrids G, long rs, int m0,
-        const int *__restrict__ prefix_sum,
         const double *__restrict__ beta0, const double *__restrict__ betah,
-        int TZ, int TR, int n_rtiles)
+        int chunks_per_wave)
 {
-    constexpr int S = ShapeTraits<SHAPE>::S, H = ShapeTraits<SHAPE>::H;
-    constexpr int NK = NCOMP * NM * 2;                 // doubles per node
+    using L = DepLayout<SHAPE, NCOMP, NM>;
+    constexpr int S = L::S, H = ShapeTraits<SHAPE>::H;
+    constexpr int NW = L::NW, NA = L::NA, NOUT = L::NOUT, OPL = L::OPL;
     extern __shared__ double lds[];
-    const int tz_id = blockIdx.x / n_rtiles, tr_id = blockIdx.x % n_rtiles;
-    const int z0 = tz_id * TZ, z1 = min(Nz, z0 + TZ);
-    const int r0 = tr_id * TR, r1 = min(Nr + 1, r0 + TR);
-    const int NTZ = TZ + S - 1, NTR = TR + S;          // node footprint (+1 col: r clamp)
-    const int plane = NTZ * NTR;
-    const int nz_org = z0 - H, nr_org = r0 - H;        // node (row, col) of tile origin
-    for (int i = threadIdx.x; i < NK * plane; i += blockDim.x) lds[i] = 0.;
-    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    double *Wl = lds + (size_t)wave * L::WAVE_DOUBLES;
+    double *Al = Wl + NW * DEP_PAD;
 
-    for (int izu = z0; izu < z1; izu++) {
-        const long c0 = (long)izu * (Nr + 1) + r0, c1 = (long)izu * (Nr + 1) + r1;
-        const long p_beg = (c0 > 0) ? prefix_sum[c0 - 1] : 0;
-        const long p_end = prefix_sum[c1 - 1];
-        for (long ip = p_beg + threadIdx.x; ip < p_end; ip += blockDim.x) {
+    // decode the outputs owned by this lane: o = lane + 64 j -> (jz, jr, comp, mode, re/im)
+    int o_w0[OPL], o_wh[OPL], o_a[OPL], o_jr[OPL], o_jz[OPL], o_km[OPL];
+    double o_sgn[OPL];
+    bool o_ok[OPL], o_m0[OPL];
+#pragma unroll
+    for (int j = 0; j < OPL; j++) {
+        int o = lane + 64 * j;
+        o_ok[j] = o < NOUT;
+        if (!o_ok[j]) o = 0;
+        const int ri = o & 1;
+        int t = o >> 1;
+        const int mm = t % NM; t /= NM;
+        const int k = t % NCOMP; t /= NCOMP;
+        const int jr = t % S, jz = t / S;
+        const int m = m0 + mm;
+        o_m0[j] = (m == 0);
+        o_w0[j] = (jz * S + jr) * DEP_PAD;
+        o_wh[j] = ((S + jz) * S + jr) * DEP_PAD;
+        o_a[j] = ((k * NM + mm) * 2 + ri) * DEP_PAD;
+        o_jr[j] = jr; o_jz[j] = jz;
+        o_km[j] = (k + NCOMP * m) * 2 + ri;
+        // rho, Jz: (-1)^m ; Jr, Jt: -(-1)^m (threading_methods.py:143-146, 289-302)
+        const double flip = m1pow(m);
+        o_sgn[j] = (NCOMP == 1 || k == 2) ? flip : -flip;
+    }
+
+    double acc[OPL];
+#pragma unroll
+    for (int j = 0; j < OPL; j++) acc[j] = 0.;
+    int cur_z = DEP_NOKEY, cur_r = DEP_NOKEY;
+
+    auto flush = [&]() {
+        if (cur_z == DEP_NOKEY) return;
+#pragma unroll
+        for (int j = 0; j < OPL; j++) {
+            if (!o_ok[j] || acc[j] == 0.) continue;
+            int gz = cur_z + o_jz[j], gr = cur_r + o_jr[j];
+            fold_node(gz, gr, Nz, Nr);
+            double *g = (double *)(G.g[o_km[j] >> 1] + (long)gz * rs + gr) + (o_km[j] & 1);
+            atomicAdd(g, acc[j]);
+        }
+    };
+
+    const long chunk0 = ((long)blockIdx.x * nwaves + wave) * chunks_per_wave;
+    for (int ch = 0; ch < chunks_per_wave; ch++) {
+        const long base = (chunk0 + ch) * 64;
+        if (base >= n) break;
+        const long ip = base + lane;
+        // ---- phase 1: lane = particle; stage weights / amplitudes, keep the cell key
+        int my_kz = DEP_NOKEY, my_kr = DEP_NOKEY, my_nb = 0;
+        if (ip < n) {
             const double xj = x[ip], yj = y[ip], zj = z[ip];
             const double wj = q * w[ip];
             const double rj = sqrt(xj * xj + yj * yj);
             double cs, sn;
             if (rj != 0.) { double invr = 1. / rj; cs = xj * invr; sn = yj * invr; }
             else { cs = 1.; sn = 0.; }
-            // amplitudes for mode m0 ... (threading_methods.py:119-121, 261-267)
             double are[NCOMP], aim[NCOMP];
             if constexpr (NCOMP == 1) {
                 are[0] = wj; aim[0] = 0.;
@@ -122,6 +187,7 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
                 are[1] = wj * c_light * ig * (cs * uy[ip] - sn * ux[ip]); aim[1] = 0.;
                 are[2] = wj * c_light * ig * uz[ip]; aim[2] = 0.;
             }
+            // mode recurrence (cos + i sin)^m, threading_methods.py:119-121, 264-267
             for (int m = 0; m < m0; m++) {
 #pragma unroll
                 for (int k = 0; k < NCOMP; k++) {
@@ -129,116 +195,108 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
                     are[k] = re; aim[k] = im;
                 }
             }
-            const double r_cell = invdr * (rj - rmin) - 0.5;
-            const double z_cell = invdz * (zj - zmin) - 0.5;
-            const int icr = (int)ceil(r_cell), icz = (int)ceil(z_cell);
-            int ir_low, iz_low;                        // lowest node (unfolded)
-            if constexpr (SHAPE == FB_SHAPE_LINEAR) { ir_low = min(icr - 1, Nr); iz_low = icz - 1; }
-            else { ir_low = min(icr, Nr) - 2; iz_low = icz - 2; }
-            const int ir_ruy = min(icr, Nr);
-            const int ir_shape = icr - H;              // particle_shapes: ir of index 0
-            double Sz[S], Sr0[S], Srh[S];
-            shape_z<SHAPE>(z_cell, Sz);
-            if (m0 == 0) shape_r<SHAPE>(r_cell, beta0[ir_ruy], Sr0);
-            if (m0 + NM > 1) shape_r<SHAPE>(r_cell, betah[ir_ruy], Srh);
-            // tile-local row of the lowest node; z is periodic inside every kernel
-            int lz = iz_low - nz_org;
-            if (lz < 0) lz += Nz; else if (lz >= Nz) lz -= Nz;
-            const int lr = ir_low - nr_org;
-            const bool in_tile = (lz >= 0) && (lz + S <= NTZ) && (lr >= 0) && (lr + S <= NTR);
 #pragma unroll
             for (int mm = 0; mm < NM; mm++) {
-                const int m = m0 + mm;
-                const double flip = m1pow(m);
-                const double *Srm = (m == 0) ? Sr0 : Srh;
 #pragma unroll
                 for (int k = 0; k < NCOMP; k++) {
-                    // rho, Jz: (-1)^m ; Jr, Jt: -(-1)^m (threading_methods.py:143-146, 289-302)
-                    const double fl = (NCOMP == 1 || k == 2) ? flip : -flip;
-#pragma unroll
-                    for (int jr = 0; jr < S; jr++) {
-                        double sr = Srm[jr];
-                        if (jr + ir_shape < 0) sr *= fl;
-#pragma unroll
-                        for (int jz = 0; jz < S; jz++) {
-                            const double Sw = Sz[jz] * sr;
-                            const double vr = Sw * are[k], vi = Sw * aim[k];
-                            if (in_tile) {
-                                double *t = lds + (long)((k * NM + mm) * 2) * plane +
-                                            (lz + jz) * NTR + (lr + jr);
-                                atomicAdd(t, vr);
-                                atomicAdd(t + plane, vi);
-                            } else {
-                                int gz = iz_low + jz, gr = ir_low + jr;
-                                fold_node(gz, gr, Nz, Nr);
-                                cplx *g = G.g[k + NCOMP * m] + (long)gz * rs + gr;
-                                atomicAdd(&g->re, vr);
-                                atomicAdd(&g->im, vi);
-                            }
-                        }
-                    }
-                    // next mode amplitude
+                    Al[((k * NM + mm) * 2 + 0) * DEP_PAD + lane] = are[k];
+                    Al[((k * NM + mm) * 2 + 1) * DEP_PAD + lane] = aim[k];
                     double re = cs * are[k] - sn * aim[k], im = cs * aim[k] + sn * are[k];
                     are[k] = re; aim[k] = im;
                 }
             }
+            const double r_cell = invdr * (rj - rmin) - 0.5;
+            const double z_cell = invdz * (zj - zmin) - 0.5;
+            const int icr = (int)ceil(r_cell), icz = (int)ceil(z_cell);
+            // lowest node of the stencil (unfolded)
+            if constexpr (SHAPE == FB_SHAPE_LINEAR) { my_kr = min(icr - 1, Nr); my_kz = icz - 1; }
+            else { my_kr = min(icr, Nr) - 2; my_kz = icz - 2; }
+            const int ir_ruy = min(icr, Nr);
+            double Sz[S], Sr0[S], Srh[S];
+            shape_z<SHAPE>(z_cell, Sz);
+            shape_r<SHAPE>(r_cell, beta0[ir_ruy], Sr0);
+            shape_r<SHAPE>(r_cell, betah[ir_ruy], Srh);
+#pragma unroll
+            for (int jz = 0; jz < S; jz++)
+#pragma unroll
+                for (int jr = 0; jr < S; jr++) {
+                    Wl[(jz * S + jr) * DEP_PAD + lane] = Sz[jz] * Sr0[jr];
+                    Wl[((S + jz) * S + jr) * DEP_PAD + lane] = Sz[jz] * Srh[jr];
+                }
+            // number of stencil columns below the axis: index + (icr - H) < 0
+            my_nb = H - icr;
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- phase 2: lane = output value.  Segment boundaries (first particle of a new
+        // cell) are found with one ballot; each segment is a branch-free register
+        // accumulation over its staged particles.
+        const int cnt = (int)min((long)64, n - base);
+        const int prev_kz = __shfl_up(my_kz, 1), prev_kr = __shfl_up(my_kr, 1);
+        bool is_start = (lane == 0) ? (my_kz != cur_z || my_kr != cur_r)
+                                    : (my_kz != prev_kz || my_kr != prev_kr);
+        const unsigned long long starts = __ballot(is_start && lane < cnt);
+        int p = 0;
+        while (p < cnt) {
+            if ((starts >> p) & 1ull) {
+                flush();
+#pragma unroll
+                for (int j = 0; j < OPL; j++) acc[j] = 0.;
+                cur_z = __builtin_amdgcn_readlane(my_kz, p);
+                cur_r = __builtin_amdgcn_readlane(my_kr, p);
+            }
+            const unsigned long long rest = (p + 1 < 64) ? (starts >> (p + 1)) : 0ull;
+            int e = rest ? p + 1 + __builtin_ctzll(rest) : cnt;
+            if (e > cnt) e = cnt;
+            if (cur_r >= 0) {                       // no node of this cell is below the axis
+                for (; p < e; p++) {
+#pragma unroll
+                    for (int j = 0; j < OPL; j++) {
+                        const double wv = o_m0[j] ? Wl[o_w0[j] + p] : Wl[o_wh[j] + p];
+                        acc[j] = __builtin_fma(wv, Al[o_a[j] + p], acc[j]);
+                    }
+                }
+            } else {
+                for (; p < e; p++) {
+                    const int nb = __builtin_amdgcn_readlane(my_nb, p);
+#pragma unroll
+                    for (int j = 0; j < OPL; j++) {
+                        double wv = o_m0[j] ? Wl[o_w0[j] + p] : Wl[o_wh[j] + p];
+                        if (o_jr[j] < nb) wv *= o_sgn[j];
+                        acc[j] = __builtin_fma(wv, Al[o_a[j] + p], acc[j]);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
-    __syncthreads();
-    // flush the privatised tile, folding the deposition guard nodes
-    for (int i = threadIdx.x; i < NK * plane; i += blockDim.x) {
-        const double v = lds[i];
-        if (v == 0.) continue;
-        const int kk = i / plane, rem = i - kk * plane;
-        const int tz = rem / NTR, tr = rem - tz * NTR;
-        int gz = nz_org + tz, gr = nr_org + tr;
-        fold_node(gz, gr, Nz, Nr);
-        const int comp_mode = kk >> 1;                 // k*NM + mm
-        const int k = comp_mode / NM, mm = comp_mode - k * NM;
-        double *g = (double *)(G.g[k + NCOMP * (m0 + mm)] + (long)gz * rs + gr) + (kk & 1);
-        atomicAdd(g, v);
-    }
-}
-
-struct TilePlan { int TZ, TR, n_ztiles, n_rtiles; size_t lds_bytes; };
-
-static TilePlan plan_tiles(int S, int NK, int Nz, int Nr)
-{
-    // Target <= 48 KiB of LDS per workgroup (3 workgroups / CU) and >= ~1000 workgroups
-    // at the headline size so all 256 CUs stay busy.
-    TilePlan p;
-    p.TR = 32; p.TZ = 4;
-    if (p.TR > Nr + 1) p.TR = Nr + 1;
-    if (p.TZ > Nz) p.TZ = Nz;
-    auto bytes = [&](int tz, int tr) { return (size_t)NK * (tz + S - 1) * (tr + S) * 8; };
-    while (bytes(p.TZ, p.TR) > 48 * 1024 && p.TZ > 1) p.TZ--;
-    while (bytes(p.TZ, p.TR) > 48 * 1024 && p.TR > 4) p.TR /= 2;
-    p.n_ztiles = (Nz + p.TZ - 1) / p.TZ;
-    p.n_rtiles = (Nr + 1 + p.TR - 1) / p.TR;
-    p.lds_bytes = bytes(p.TZ, p.TR);
-    return p;
+    flush();
 }
 
 template <int SHAPE, int NCOMP, int NM>
 static int launch_one(long n, const double *x, const double *y, const double *z, const double *w,
         double q, const double *ux, const double *uy, const double *uz, const double *ig,
         double c, double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
-        const DepGrids &G, long rs, int m0, const int *prefix, const double *b0,
-        const double *bh, hipStream_t s)
+        const DepGrids &G, long rs, int m0, const double *b0, const double *bh, hipStream_t s)
 {
-    constexpr int S = ShapeTraits<SHAPE>::S;
-    TilePlan p = plan_tiles(S, NCOMP * NM * 2, Nz, Nr);
+    using L = DepLayout<SHAPE, NCOMP, NM>;
+    // waves per workgroup: keep the LDS panel <= 64 KiB
+    int nwaves = 4;
+    while (nwaves > 1 && L::wave_bytes() * nwaves > 64 * 1024) nwaves >>= 1;
+    const long nchunks = (n + 63) / 64;
+    // ~8 waves per SIMD-quad in flight over 256 CUs, each walking consecutive chunks so
+    // that a cell straddling two chunks is not flushed twice
+    long target_waves = 256L * 32;
+    int cpw = (int)((nchunks + target_waves - 1) / target_waves);
+    if (cpw < 1) cpw = 1;
+    if (cpw > 64) cpw = 64;
+    const long total_waves = (nchunks + cpw - 1) / cpw;
+    const long nblocks = (total_waves + nwaves - 1) / nwaves;
     auto kern = k_deposit<SHAPE, NCOMP, NM>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        if (e != hipSuccess) return check(e, "fb_deposit(attr)");
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(p.n_ztiles * p.n_rtiles), dim3(256), p.lds_bytes, s, n, x, y, z,
-                       w, q, ux, uy, uz, ig, c, invdz, zmin, Nz, invdr, rmin, Nr, G, rs, m0,
-                       prefix, b0, bh, p.TZ, p.TR, p.n_rtiles);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(64 * nwaves),
+                       L::wave_bytes() * nwaves, s, n, x, y, z, w, q, ux, uy, uz, ig, c,
+                       invdz, zmin, Nz, invdr, rmin, Nr, G, rs, m0, b0, bh, cpw);
     return check(hipGetLastError(), "fb_deposit");
 }
 
@@ -246,13 +304,12 @@ template <int SHAPE, int NCOMP>
 static int launch_modes(int Nm, long n, const double *x, const double *y, const double *z,
         const double *w, double q, const double *ux, const double *uy, const double *uz,
         const double *ig, double c, double invdz, double zmin, int Nz, double invdr, double rmin,
-        int Nr, const DepGrids &G, long rs, const int *prefix, const double *b0, const double *bh,
-        hipStream_t s)
+        int Nr, const DepGrids &G, long rs, const double *b0, const double *bh, hipStream_t s)
 {
     int m0 = 0;
     while (m0 < Nm) {
         int left = Nm - m0, r;
-#define ARGS n, x, y, z, w, q, ux, uy, uz, ig, c, invdz, zmin, Nz, invdr, rmin, Nr, G, rs, m0, prefix, b0, bh, s
+#define ARGS n, x, y, z, w, q, ux, uy, uz, ig, c, invdz, zmin, Nz, invdr, rmin, Nr, G, rs, m0, b0, bh, s
         if (left >= 4) { r = launch_one<SHAPE, NCOMP, 4>(ARGS); m0 += 4; }
         else if (left == 3) { r = launch_one<SHAPE, NCOMP, 3>(ARGS); m0 += 3; }
         else if (left == 2) { r = launch_one<SHAPE, NCOMP, 2>(ARGS); m0 += 2; }
@@ -272,6 +329,7 @@ extern "C" int fb_deposit_rho(int shape, int Nm, long n, const double *x, const 
         double invdr, double rmin, int Nr, void *const *rho, long row_stride,
         const int *prefix_sum, const double *ruyten_m0, const double *ruyten_mh, void *stream)
 {
+    (void)prefix_sum;
     if (n <= 0) return 0;
     if (Nm < 1 || Nm > FB_MAX_MODES) { set_error("fb_deposit_rho", "Nm out of range"); return -1; }
     DepGrids G;
@@ -279,12 +337,12 @@ extern "C" int fb_deposit_rho(int shape, int Nm, long n, const double *x, const 
     hipStream_t s = (hipStream_t)stream;
     if (shape == FB_SHAPE_LINEAR)
         return launch_modes<FB_SHAPE_LINEAR, 1>(Nm, n, x, y, z, w, q, nullptr, nullptr, nullptr,
-                nullptr, 0., invdz, zmin, Nz, invdr, rmin, Nr, G, row_stride, prefix_sum,
-                ruyten_m0, ruyten_mh, s);
+                nullptr, 0., invdz, zmin, Nz, invdr, rmin, Nr, G, row_stride, ruyten_m0,
+                ruyten_mh, s);
     if (shape == FB_SHAPE_CUBIC)
         return launch_modes<FB_SHAPE_CUBIC, 1>(Nm, n, x, y, z, w, q, nullptr, nullptr, nullptr,
-                nullptr, 0., invdz, zmin, Nz, invdr, rmin, Nr, G, row_stride, prefix_sum,
-                ruyten_m0, ruyten_mh, s);
+                nullptr, 0., invdz, zmin, Nz, invdr, rmin, Nr, G, row_stride, ruyten_m0,
+                ruyten_mh, s);
     set_error("fb_deposit_rho", "unknown shape");
     return -1;
 }
@@ -295,6 +353,7 @@ extern "C" int fb_deposit_J(int shape, int Nm, long n, const double *x, const do
         double invdr, double rmin, int Nr, void *const *J, long row_stride,
         const int *prefix_sum, const double *ruyten_m0, const double *ruyten_mh, void *stream)
 {
+    (void)prefix_sum;
     if (n <= 0) return 0;
     if (Nm < 1 || Nm > FB_MAX_MODES) { set_error("fb_deposit_J", "Nm out of range"); return -1; }
     DepGrids G;
@@ -302,12 +361,10 @@ extern "C" int fb_deposit_J(int shape, int Nm, long n, const double *x, const do
     hipStream_t s = (hipStream_t)stream;
     if (shape == FB_SHAPE_LINEAR)
         return launch_modes<FB_SHAPE_LINEAR, 3>(Nm, n, x, y, z, w, q, ux, uy, uz, inv_gamma, c,
-                invdz, zmin, Nz, invdr, rmin, Nr, G, row_stride, prefix_sum, ruyten_m0,
-                ruyten_mh, s);
+                invdz, zmin, Nz, invdr, rmin, Nr, G, row_stride, ruyten_m0, ruyten_mh, s);
     if (shape == FB_SHAPE_CUBIC)
         return launch_modes<FB_SHAPE_CUBIC, 3>(Nm, n, x, y, z, w, q, ux, uy, uz, inv_gamma, c,
-                invdz, zmin, Nz, invdr, rmin, Nr, G, row_stride, prefix_sum, ruyten_m0,
-                ruyten_mh, s);
+                invdz, zmin, Nz, invdr, rmin, Nr, G, row_stride, ruyten_m0, ruyten_mh, s);
     set_error("fb_deposit_J", "unknown shape");
     return -1;
 }

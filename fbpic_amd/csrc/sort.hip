@@ -99,13 +99,15 @@ extern "C" int fb_cell_index(long n, const double *x, const double *y, const dou
 extern "C" size_t fb_sort_workspace_bytes(long n, int ncell)
 {
     if (n <= 0) return 256;
-    return align_up((size_t)n * sizeof(int), 256) * 2 + align_up(rocprim_temp_bytes(n, ncell), 256) + 256;
+    return align_up(rocprim_temp_bytes(n, ncell), 256) + 256;
 }
 
 extern "C" int fb_sort_by_cell(long n, int ncell, int *cell_idx, int *sorted_idx,
-        int *prefix_sum, void *workspace, size_t workspace_bytes, void *stream)
+        int *cell_idx_alt, int *sorted_idx_alt, int *result_in_alt, int *prefix_sum,
+        void *workspace, size_t workspace_bytes, void *stream)
 {
     hipStream_t s = (hipStream_t)stream;
+    *result_in_alt = 0;
     if (n <= 0) {
         if (ncell > 0)
             hipLaunchKernelGGL(k_fill_int, dim3((ncell + 255) / 256), dim3(256), 0, s, ncell,
@@ -116,28 +118,21 @@ extern "C" int fb_sort_by_cell(long n, int ncell, int *cell_idx, int *sorted_idx
         set_error("fb_sort_by_cell", "workspace too small");
         return -1;
     }
-    char *ws = (char *)workspace;
-    size_t kb = align_up((size_t)n * sizeof(int), 256);
-    int *keys_alt = (int *)ws;
-    int *vals_alt = (int *)(ws + kb);
-    void *temp = ws + 2 * kb;
-    size_t temp_bytes = workspace_bytes - 2 * kb;
-    rocprim::double_buffer<int> k(cell_idx, keys_alt);
-    rocprim::double_buffer<int> v(sorted_idx, vals_alt);
-    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, k, v, (size_t)n, 0u,
+    // rocPRIM ping-pongs between the two buffer pairs; instead of copying the result back
+    // (2 x 4n bytes per sort) the caller is told which pair holds it and swaps its handles.
+    rocprim::double_buffer<int> k(cell_idx, cell_idx_alt);
+    rocprim::double_buffer<int> v(sorted_idx, sorted_idx_alt);
+    size_t temp_bytes = workspace_bytes;
+    hipError_t e = rocprim::radix_sort_pairs(workspace, temp_bytes, k, v, (size_t)n, 0u,
                                              (unsigned)key_bits(ncell), s, false);
     if (e != hipSuccess) return check(e, "fb_sort_by_cell(radix)");
-    if (k.current() != cell_idx) {
-        e = hipMemcpyAsync(cell_idx, k.current(), (size_t)n * sizeof(int),
-                           hipMemcpyDeviceToDevice, s);
-        if (e != hipSuccess) return check(e, "fb_sort_by_cell(copy keys)");
+    const bool in_alt = (k.current() != cell_idx);
+    if (in_alt != (v.current() != sorted_idx)) {
+        set_error("fb_sort_by_cell", "key/value buffers out of step");
+        return -1;
     }
-    if (v.current() != sorted_idx) {
-        e = hipMemcpyAsync(sorted_idx, v.current(), (size_t)n * sizeof(int),
-                           hipMemcpyDeviceToDevice, s);
-        if (e != hipSuccess) return check(e, "fb_sort_by_cell(copy vals)");
-    }
-    hipLaunchKernelGGL(k_prefix, dim3(stream_grid(n)), dim3(256), 0, s, n, ncell, cell_idx,
+    *result_in_alt = in_alt ? 1 : 0;
+    hipLaunchKernelGGL(k_prefix, dim3(stream_grid(n)), dim3(256), 0, s, n, ncell, k.current(),
                        prefix_sum);
     FB_CHECK_LAUNCH("fb_sort_by_cell");
 }

@@ -107,6 +107,12 @@ class Simulation(object):
         self.checkpoints = []
         self.laser_antennas = []
         self.mirrors = []
+        # On a single z-periodic domain the reference re-deposits rho_prev at every step
+        # (exchange_period = 1, main.py:435-449) although no particle was added or removed:
+        # the spectral rho_prev left by push_rho (= the previous step's filtered rho_next)
+        # already is that charge density up to rounding.  The re-deposit is skipped after
+        # the first iteration of a step() call unless this flag is set.
+        self.redeposit_rho_prev_every_step = False
 
     # -------------------------------------------------------------------- PIC cycle
     def step(self, N=1, correct_currents=True, correct_divE=False, use_true_rho=False,
@@ -130,7 +136,9 @@ class Simulation(object):
             if self.iteration % self.comm.exchange_period == 0 or i_step == 0:
                 for species in ptcl:
                     self.comm.exchange_particles(species, fld, self.time)
-                self.deposit('rho_prev', exchange=(use_true_rho is True))
+                if (i_step == 0 or self.comm.n_guard != 0 or self.redeposit_rho_prev_every_step
+                        or use_true_rho):
+                    self.deposit('rho_prev', exchange=(use_true_rho is True))
             if i_step == 0:
                 self.deposit('J', exchange=True)
             for species in ptcl:

@@ -6,6 +6,7 @@ sorted, keep_fields_sorted; methods push_p, push_x, gather, deposit, sort_partic
 rearrange_particle_arrays, send_particles_to_gpu, receive_particles_from_gpu.
 Every compute method launches a HIP kernel of libfbpic_amd.so; nothing runs on the host.
 """
+import ctypes
 import numpy as np
 from scipy.constants import c
 from .. import _capi
@@ -52,6 +53,14 @@ class Particles(object):
         self.grid_shape = grid_shape
         self.prefix_sum_shift = 0
         self.sorted = False
+        # Sort policy.  The reference re-sorts before every deposit that follows a push_x.
+        # The HIP deposition does not need an exact sort (it accumulates runs of equal
+        # cells), so a re-sort is only worth its cost once the particles have moved far
+        # enough to fragment those runs: `sort_tolerance` is the displacement bound, in
+        # cells (c * dt_push / min(dz, dr) summed since the last sort), above which
+        # `deposit` sorts again.  0 restores the reference behaviour.
+        self.sort_tolerance = 0.75
+        self._moved_since_sort = np.inf
         # device-only helpers (allocated in send_particles_to_gpu)
         self.cell_idx = None
         self.sorted_idx = None
@@ -59,6 +68,7 @@ class Particles(object):
         self.sorting_buffer = None
         self._alt = None
         self._sort_ws = None
+        self._cell_size = None
 
     # ---------------------------------------------------------------- host <-> device
     def _alloc_device_helpers(self):
@@ -69,6 +79,8 @@ class Particles(object):
         ncell = Nz * (Nr + 1)
         self.cell_idx = t.empty(n, dtype=t.int32, device=dev)
         self.sorted_idx = t.empty(n, dtype=t.int32, device=dev)
+        self._cell_idx_alt = t.empty(n, dtype=t.int32, device=dev)
+        self._sorted_idx_alt = t.empty(n, dtype=t.int32, device=dev)
         self.prefix_sum = t.zeros(ncell, dtype=t.int32, device=dev)
         self._alt = [t.empty(n, dtype=t.float64, device=dev) for _ in range(14)]
         self.sorting_buffer = self._alt[0]
@@ -83,6 +95,7 @@ class Particles(object):
         if self.cell_idx is None or self.cell_idx.shape[0] != self.Ntot:
             self._alloc_device_helpers()
         self.sorted = False
+        self._moved_since_sort = np.inf
         self.data_is_on_gpu = True
 
     def receive_particles_from_gpu(self):
@@ -123,6 +136,9 @@ class Particles(object):
                                    x_push, y_push, z_push, _capi.stream())
         _capi.check(rc, 'fb_push_x')
         self.sorted = False
+        dmin = min(self._cell_size) if self._cell_size else 0.
+        self._moved_since_sort += (c * abs(dt) * max(abs(x_push), abs(y_push), abs(z_push)) / dmin
+                                   if dmin > 0 else np.inf)
 
     # ---------------------------------------------------------------- gather
     def gather(self, grid, comm):
@@ -158,11 +174,18 @@ class Particles(object):
                                g0.Nz, g0.invdr, g0.rmin, g0.Nr, p(self.cell_idx),
                                p(self.sorted_idx), st)
         _capi.check(rc, 'fb_cell_index')
+        in_alt = ctypes.c_int(0)
         rc = lib.fb_sort_by_cell(self.Ntot, self.prefix_sum.shape[0], p(self.cell_idx),
-                                 p(self.sorted_idx), p(self.prefix_sum), p(self._sort_ws),
-                                 self._sort_ws.shape[0], st)
+                                 p(self.sorted_idx), p(self._cell_idx_alt),
+                                 p(self._sorted_idx_alt), ctypes.byref(in_alt),
+                                 p(self.prefix_sum), p(self._sort_ws), self._sort_ws.shape[0], st)
         _capi.check(rc, 'fb_sort_by_cell')
+        if in_alt.value:     # the radix sort left its result in the alternate buffers
+            self.cell_idx, self._cell_idx_alt = self._cell_idx_alt, self.cell_idx
+            self.sorted_idx, self._sorted_idx_alt = self._sorted_idx_alt, self.sorted_idx
         self.prefix_sum_shift = 0
+        self._cell_size = (g0.dz, g0.dr)
+        self._moved_since_sort = 0.
         self.rearrange_particle_arrays()
 
     def rearrange_particle_arrays(self):
@@ -188,8 +211,9 @@ class Particles(object):
         assert fieldtype in ['rho', 'J']
         self._need_gpu()
         if not self.sorted:
-            self.sort_particles(fld=fld)
-            self.sorted = True
+            if self._moved_since_sort > self.sort_tolerance:
+                self.sort_particles(fld=fld)
+                self.sorted = True
         grid = fld.interp
         Nm = len(grid)
         g0 = grid[0]

@@ -78,11 +78,15 @@ int fb_cell_index(long n, const double *x, const double *y, const double *z,
 
 /* particles/particles.py:1083-1092 -> sort_particles_per_cell (Thrust argsort,
  * cuda_sorting.py:90-122) + prefill_prefix_sum + incl_prefix_sum (:124-190).
- * Stable radix sort (rocPRIM) of (cell_idx, sorted_idx) in place, then the inclusive
- * per-cell particle count prefix_sum[ncell].  workspace: fb_sort_workspace_bytes(). */
+ * Stable radix sort (rocPRIM) of the (cell_idx, sorted_idx) pairs, then the inclusive
+ * per-cell particle count prefix_sum[ncell].  The sort ping-pongs between the primary
+ * and the *_alt buffers (all int32[n]); on return *result_in_alt (HOST int) tells which
+ * pair holds the sorted data, so the caller swaps its handles instead of paying a copy.
+ * workspace: fb_sort_workspace_bytes() of scratch. */
 size_t fb_sort_workspace_bytes(long n, int ncell);
-int fb_sort_by_cell(long n, int ncell, int *cell_idx, int *sorted_idx, int *prefix_sum,
-                    void *workspace, size_t workspace_bytes, void *stream);
+int fb_sort_by_cell(long n, int ncell, int *cell_idx, int *sorted_idx,
+                    int *cell_idx_alt, int *sorted_idx_alt, int *result_in_alt,
+                    int *prefix_sum, void *workspace, size_t workspace_bytes, void *stream);
 
 /* particles/particles.py:519-538 -> write_sorting_buffer (cuda_sorting.py:192-213),
  * all attributes in one launch: dst[k][i] = src[k][sorted_idx[i]].
@@ -92,8 +96,11 @@ int fb_permute(long n, const int *sorted_idx, int nattr,
 
 /* ---- deposition ---------------------------------------------------------------- */
 /* particles/particles.py:893-936 -> deposit_rho_gpu_{linear,cubic}[_one_mode]
- * (deposition/cuda_methods.py:27,465; cuda_methods_one_mode.py).  Particles must be
- * cell-sorted (prefix_sum from fb_sort_by_cell).  rho: HOST array of Nm device pointers.
+ * (deposition/cuda_methods.py:27,465; cuda_methods_one_mode.py).  Particles should be
+ * cell-sorted for speed (runs of equal cells are accumulated in registers); the result
+ * does not depend on the order.  prefix_sum is accepted for signature compatibility with
+ * the reference launch and is not read (may be NULL).
+ * rho: HOST array of Nm device pointers.
  * ruyten_m0 / ruyten_mh: Ruyten coefficients (Nr+1) for mode 0 / modes >= 1. */
 int fb_deposit_rho(int shape, int Nm, long n,
                    const double *x, const double *y, const double *z, const double *w, double q,
@@ -159,8 +166,8 @@ int fb_scale(int nfields, void *const *ptrs, long row_stride, double factor,
  * One plan transforms `ncols` columns at once: element (iz, col) lives at
  * base + iz*stride + col (stride in complex elements), i.e. a (Nz, ncols) strided view
  * covering one or several side-by-side (Nz, Nr) grids.  No transpose copies.
- * direction: -1 forward (unnormalised), +1 backward (unnormalised: the 1/Nz of
- * fourier.py:157 is folded into the consumer, see fb_hankel / fb_scale). */
+ * direction: -1 forward (unnormalised), +1 backward (includes the 1/Nz of
+ * fourier.py:157 through the rocFFT plan's scale factor). */
 int fb_fft_plan_create(int Nz, long ncols, long in_stride, long out_stride, int inplace,
                        void **plan_fwd_bwd);
 int fb_fft_exec(void *plan, int direction, const void *in, void *out, void *stream);

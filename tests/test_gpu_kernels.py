@@ -118,7 +118,13 @@ def _sort(hip, x, y, z, geom, Nz, Nr):
     ci0 = host(ci).copy()
     nb = int(hip.lib().fb_sort_workspace_bytes(n, ncell))
     ws = t.empty(nb, dtype=t.uint8, device='cuda')
-    hip.check(hip.lib().fb_sort_by_cell(n, ncell, p(ci), p(si), p(pre), p(ws), nb, hip.stream()), 'sort')
+    ci2, si2 = t.empty_like(ci), t.empty_like(si)
+    in_alt = ctypes.c_int(-1)
+    hip.check(hip.lib().fb_sort_by_cell(n, ncell, p(ci), p(si), p(ci2), p(si2), ctypes.byref(in_alt),
+                                        p(pre), p(ws), nb, hip.stream()), 'sort')
+    assert in_alt.value in (0, 1)
+    if in_alt.value:
+        ci, si = ci2, si2
     return ci0, host(ci), host(si), host(pre), (dx, dy, dz_, si)
 
 
@@ -161,13 +167,15 @@ def test_cell_index_large_random(hip, oracle):
 
 
 # ------------------------------------------------------------------ deposition
-def _deposit_gpu(hip, g, shape, Nm, what, b0, bh, slab=False):
+def _deposit_gpu(hip, g, shape, Nm, what, b0, bh, slab=False, presort=True):
     Nz, Nr = int(g['Nz']), int(g['Nr'])
     geom = (1. / float(g['dz']), float(g['zmin']), Nz, 1. / float(g['dr']), 0., Nr)
     t = hip.torch()
     _, _, si, pre, _ = _sort(hip, g['x'], g['y'], g['z'], geom, Nz, Nr)
     names = ('x', 'y', 'z', 'w', 'ux', 'uy', 'uz', 'inv_gamma')
-    d = {k: dev(hip, g[k][si]) for k in names}            # sorted particle arrays
+    if not presort:                                       # result must not depend on the order
+        si = np.random.default_rng(1).permutation(g['x'].size)
+    d = {k: dev(hip, g[k][si]) for k in names}            # (sorted) particle arrays
     dpre = dev(hip, pre)
     ncomp = 1 if what == 'rho' else 3
     if slab:
@@ -209,6 +217,8 @@ def test_deposit_vs_oracle_and_golden(hip, oracle, shape, Nm):
             oracle.sum_reduce(glob, m, red[m])
         got = _deposit_gpu(hip, g, shape, Nm, 'rho', b0, bh, slab=bool(ruy))
         assert rel_err(got, red) < TOL
+        got_u = _deposit_gpu(hip, g, shape, Nm, 'rho', b0, bh, slab=bool(ruy), presort=False)
+        assert rel_err(got_u, red) < TOL
         gl = oracle.deposit_J_global(shape, Nm, g['x'], g['y'], g['z'], g['w'], float(g['q']),
                                      g['ux'], g['uy'], g['uz'], g['inv_gamma'], *geom, b0, bh, 1)
         gotJ = _deposit_gpu(hip, g, shape, Nm, 'J', b0, bh, slab=bool(ruy)).reshape(Nm, 3, Nz, Nr)
