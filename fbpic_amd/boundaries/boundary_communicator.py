@@ -207,9 +207,8 @@ class BoundaryCommunicator(object):
         ng = self.n_guard
         names = {'E': ('Er', 'Et', 'Ez'), 'B': ('Br', 'Bt', 'Bz'), 'J': ('Jr', 'Jt', 'Jz'),
                  'rho': ('rho',)}[fldtype]
-        arrs = [getattr(g, k) for g in interp for k in names]
         t = _capi.torch()
-        Nz = arrs[0].shape[0]
+        Nz = getattr(interp[0], names[0]).shape[0]
         if method == 'replace':
             s_l = slice(ng, 2 * ng); s_r = slice(Nz - 2 * ng, Nz - ng)
             d_l = slice(0, ng); d_r = slice(Nz - ng, Nz)
@@ -218,48 +217,78 @@ class BoundaryCommunicator(object):
             d_l, d_r = s_l, s_r
         else:
             raise ValueError('Unknown method: %s' % method)
-        send_l = t.stack([a[s_l] for a in arrs]).contiguous() if self.left_proc is not None else None
-        send_r = t.stack([a[s_r] for a in arrs]).contiguous() if self.right_proc is not None else None
-        recv_l = t.empty_like(send_l) if send_l is not None else None
-        recv_r = t.empty_like(send_r) if send_r is not None else None
+        owner = getattr(interp[0], '_owner', None)
+        if owner is not None and owner.data_is_on_gpu and len(interp) == owner.Nm:
+            # z-major slab: the whole group (all modes and components) is one strided
+            # block slab[z0:z1, f0:f0+nf, :] -> one copy to pack, one to unpack
+            f0, _, nf, _ = owner._group('rho_prev' if fldtype == 'rho' else fldtype)
+            region = owner.d_interp[:, f0:f0 + nf, :]
+            targets = [region]
+        else:
+            targets = [getattr(g, k) for g in interp for k in names]
+        has_l, has_r = self.left_proc is not None, self.right_proc is not None
+        send_l = t.stack([a[s_l] for a in targets]).contiguous() if has_l else None
+        send_r = t.stack([a[s_r] for a in targets]).contiguous() if has_r else None
+        recv_l = t.empty_like(send_l) if has_l else None
+        recv_r = t.empty_like(send_r) if has_r else None
         self.exchange_domains(send_l, send_r, recv_l, recv_r)
-        for i, a in enumerate(arrs):
-            if recv_l is not None:
+        for i, a in enumerate(targets):
+            if has_l:
                 if method == 'replace':
                     a[d_l] = recv_l[i]
                 else:
                     a[d_l] += recv_l[i]
-            if recv_r is not None:
+            if has_r:
                 if method == 'replace':
                     a[d_r] = recv_r[i]
                 else:
                     a[d_r] += recv_r[i]
 
-    def exchange_domains(self, send_left, send_right, recv_left, recv_right):
+    def exchange_domains(self, send_left, send_right, recv_left, recv_right, skip_empty=False):
         """Nearest-neighbour exchange (boundary_communicator.py:674-707) as one batch of
-        point-to-point operations.  Complex tensors travel as their real view."""
+        point-to-point operations.  Complex tensors travel as their real view.  With
+        `skip_empty`, zero-length messages are not posted (both sides know the lengths)."""
         dist = _dist()
         t = _capi.torch()
+        # RCCL moves device buffers directly over xGMI.  Under the gloo backend (CPU tests,
+        # or several ranks sharing one GPU) device tensors are staged through the host.
+        stage = (dist.get_backend() == 'gloo')
+        staged = []
 
-        def rv(x):
-            return t.view_as_real(x) if x.is_complex() else x
-        ops = []
+        def rv(x, receiving=False):
+            y = t.view_as_real(x) if x.is_complex() else x
+            if stage and y.is_cuda:
+                h = y.cpu()
+                if receiving:
+                    staged.append((y, h))
+                return h
+            return y
+
+        def want(x):
+            return x is not None and not (skip_empty and x.numel() == 0)
+        sends, recvs = [], []
         if self.left_proc is not None:
-            ops.append(dist.P2POp(dist.isend, rv(send_left), self.left_proc))
-            ops.append(dist.P2POp(dist.irecv, rv(recv_left), self.left_proc))
+            if want(send_left):
+                sends.append(dist.P2POp(dist.isend, rv(send_left), self.left_proc))
+            if want(recv_left):
+                recvs.append(dist.P2POp(dist.irecv, rv(recv_left, True), self.left_proc))
         if self.right_proc is not None:
-            ops.append(dist.P2POp(dist.isend, rv(send_right), self.right_proc))
-            ops.append(dist.P2POp(dist.irecv, rv(recv_right), self.right_proc))
-        if self.size == 2 and self.left_proc == self.right_proc and self.left_proc is not None:
-            # periodic ring of two ranks: both neighbours are the same peer; order the
-            # operations so that "to-left" pairs with the peer's "from-right".
-            ops = [dist.P2POp(dist.isend, rv(send_left), self.left_proc),
-                   dist.P2POp(dist.isend, rv(send_right), self.right_proc),
-                   dist.P2POp(dist.irecv, rv(recv_right), self.right_proc),
-                   dist.P2POp(dist.irecv, rv(recv_left), self.left_proc)]
+            if want(send_right):
+                sends.append(dist.P2POp(dist.isend, rv(send_right), self.right_proc))
+            if want(recv_right):
+                # a 2-rank periodic ring has the same peer on both sides: messages between
+                # one pair of ranks match in posting order, so the receive that pairs with
+                # the peer's FIRST send (its send-to-left = my from-right) must come first
+                if self.size == 2 and self.left_proc == self.right_proc:
+                    recvs.insert(0, dist.P2POp(dist.irecv, rv(recv_right, True), self.right_proc))
+                else:
+                    recvs.append(dist.P2POp(dist.irecv, rv(recv_right, True), self.right_proc))
+        ops = sends + recvs
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
+        for dev_t, host_t in staged:
+            dev_t.copy_(host_t)
 
     # ---------------------------------------------------------------- particle exchange
     def exchange_particles(self, species, fld, time):

@@ -1,0 +1,59 @@
+"""Particle hand-over between neighbouring z-slabs (one rank per GPU).
+
+Semantics of fbpic/boundaries/particle_buffer_handling.py:17-172 (remove_outside_particles)
+and :289-417 (add_buffers_to_particles) + boundary_communicator.py:750-826: particles whose
+z left the local *physical* range [zmin + ng dz, zmax - ng dz] are removed and sent to the
+left / right neighbour (dropped at an open end); received particles are appended as
+(from-left | stayed | from-right); particles that wrapped around the periodic box are
+shifted by +-L.  The selection is expressed with device-agnostic tensor operations
+(boolean masks on the SoA tensors) so that the same code runs on RCCL/GPU tensors and on
+gloo/CPU tensors in the tests; it runs once every `exchange_period` (~14) steps.
+"""
+from .. import _capi
+
+_STATE = ('x', 'y', 'z', 'ux', 'uy', 'uz', 'inv_gamma', 'w')     # reference buffer order
+_FIELDS = ('Ex', 'Ey', 'Ez', 'Bx', 'By', 'Bz')
+
+
+def exchange_particles_between_ranks(comm, species, fld, time):
+    t = _capi.torch()
+    g0 = fld.interp[0]
+    ng = comm.n_guard
+    zbox_min = g0.zmin + ng * g0.dz
+    zbox_max = g0.zmax - ng * g0.dz
+    z = species.z
+    sel_l = z < zbox_min
+    sel_r = z > zbox_max
+    stay = ~(sel_l | sel_r)
+    arrs = [getattr(species, k) for k in _STATE]
+    dev = z.device
+
+    def pack(sel, proc):
+        if proc is None:
+            return t.empty((len(_STATE), 0), dtype=t.float64, device=dev)
+        return t.stack([a[sel] for a in arrs]).contiguous()
+    send_l = pack(sel_l, comm.left_proc)
+    send_r = pack(sel_r, comm.right_proc)
+    # 1) counts, 2) payloads (boundary_communicator.py:782-801)
+    n_sl = t.tensor([send_l.shape[1]], dtype=t.int64, device=dev)
+    n_sr = t.tensor([send_r.shape[1]], dtype=t.int64, device=dev)
+    n_rl = t.zeros(1, dtype=t.int64, device=dev)
+    n_rr = t.zeros(1, dtype=t.int64, device=dev)
+    comm.exchange_domains(n_sl, n_sr, n_rl, n_rr)
+    n_rl, n_rr = int(n_rl.item()), int(n_rr.item())
+    recv_l = t.empty((len(_STATE), n_rl), dtype=t.float64, device=dev)
+    recv_r = t.empty((len(_STATE), n_rr), dtype=t.float64, device=dev)
+    comm.exchange_domains(send_l, send_r, recv_l, recv_r, skip_empty=True)
+    # periodic wrap of the hand-over across the ends of the global box
+    Ltot = comm._Nz_global_domain * comm.dz
+    if comm.right_proc == 0 and n_rr:
+        recv_r[2] += Ltot
+    if comm.left_proc == comm.size - 1 and n_rl:
+        recv_l[2] -= Ltot
+    for i, k in enumerate(_STATE):
+        setattr(species, k, t.cat((recv_l[i], arrs[i][stay], recv_r[i])).contiguous())
+    species.Ntot = int(species.x.shape[0])
+    for k in _FIELDS:
+        setattr(species, k, t.zeros(species.Ntot, dtype=t.float64, device=dev))
+    species.sorted = False
+    species.on_particle_number_changed()

@@ -54,6 +54,8 @@ class Fields(object):
                                          use_cuda=use_cuda, use_ruyten_shapes=use_ruyten_shapes,
                                          use_modified_volume=use_modified_volume)
                        for m in range(Nm)]
+        for g in self.interp:
+            g._owner = self
         dz = (zmax - zmin) / Nz
         kz_true = 2 * np.pi * np.fft.fftfreq(Nz, dz)
         kz_modified = get_modified_k(kz_true, n_order, dz)

@@ -105,6 +105,13 @@ class Particles(object):
             setattr(self, k, _capi.to_host(getattr(self, k)))
         self.data_is_on_gpu = False
 
+    def on_particle_number_changed(self):
+        """Re-size the device helpers after particles were added / removed."""
+        self.sorted = False
+        self._moved_since_sort = np.inf
+        if self.data_is_on_gpu and self.x.is_cuda:
+            self._alloc_device_helpers()
+
     def _need_gpu(self):
         if not self.data_is_on_gpu:
             raise _capi.BackendError(

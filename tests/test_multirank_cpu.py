@@ -1,0 +1,183 @@
+"""N > 1 path on CPU: two ranks over the gloo backend (world_size 2).  Exercises the
+z-slab decomposition arithmetic, the guard-cell exchange ('replace' for E/B, 'add' for
+J/rho), and the particle hand-over incl. the periodic wrap -- the same code that runs on
+RCCL with one rank per MI355X (torch tensors, backend-agnostic)."""
+import os
+import socket
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from scipy.constants import c
+
+NZ, NR, NM, NG = 48, 6, 2, 4
+DZ = 0.5e-6
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _Grid:
+    pass
+
+
+def _make_comm(boundary):
+    from fbpic_amd.boundaries.boundary_communicator import BoundaryCommunicator
+    return BoundaryCommunicator(NZ, 0., NZ * DZ, NR, NR * DZ, NM, DZ / c, None, False,
+                                {'z': boundary, 'r': 'reflective'}, 8, NG, {'z': 8, 'r': 4},
+                                1., None, 1, True)
+
+
+def _global_field(seed, nz):
+    rng = np.random.default_rng(seed)
+    return rng.normal(size=(nz, NR)) + 1j * rng.normal(size=(nz, NR))
+
+
+def _worker(rank, world, port, boundary, q):
+    try:
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank,
+                                world_size=world)
+        comm = _make_comm(boundary)
+        assert (comm.rank, comm.size) == (rank, world)
+        Nz_l, iz0 = comm.get_Nz_and_iz(local=True, with_damp=True, with_guard=True, rank=rank)
+        zmin_l, zmax_l, Nz_chk = comm.divide_into_domain()
+        assert Nz_chk == Nz_l and abs((zmax_l - zmin_l) / DZ - Nz_l) < 1e-9
+        # ---------------- 'replace': guards must receive the neighbour's valid cells
+        Nz_phys = NZ // world
+        names = ('Er', 'Et', 'Ez')
+        interp = []
+        for m in range(NM):
+            g = _Grid()
+            for i, k in enumerate(names):
+                G = _global_field(10 * m + i, NZ)
+                idx = (np.arange(Nz_l) + iz0) % NZ if boundary == 'periodic' else None
+                if boundary == 'periodic':
+                    loc = G[idx].copy()
+                    loc[:NG] = 99.; loc[-NG:] = 99.          # garbage in the guard cells
+                    setattr(g, k, torch.from_numpy(loc))
+                    setattr(g, k + '_expect', G[idx])
+            interp.append(g)
+        if boundary == 'periodic':
+            comm.exchange_fields(interp, 'E', 'replace')
+            for g in interp:
+                for k in names:
+                    assert np.array_equal(getattr(g, k).numpy(), getattr(g, k + '_expect')), k
+        # ---------------- 'add': overlapping [0,2ng) / [Nz-2ng,Nz) regions are summed
+        def local_J(r, m, i, nz):
+            return _global_field(1000 + 100 * r + 10 * m + i, nz)
+        Nz_of = [comm.get_Nz_and_iz(True, True, True, rank=r)[0] for r in range(world)]
+        interp = []
+        for m in range(NM):
+            g = _Grid()
+            for i, k in enumerate(('Jr', 'Jt', 'Jz')):
+                setattr(g, k, torch.from_numpy(local_J(rank, m, i, Nz_l).copy()))
+            interp.append(g)
+        comm.exchange_fields(interp, 'J', 'add')
+        for m in range(NM):
+            for i, k in enumerate(('Jr', 'Jt', 'Jz')):
+                exp = local_J(rank, m, i, Nz_l).copy()
+                if comm.left_proc is not None:
+                    exp[:2 * NG] += local_J(comm.left_proc, m, i, Nz_of[comm.left_proc])[-2 * NG:]
+                if comm.right_proc is not None:
+                    exp[-2 * NG:] += local_J(comm.right_proc, m, i, Nz_of[comm.right_proc])[:2 * NG]
+                assert np.allclose(getattr(interp[m], k).numpy(), exp, rtol=0, atol=1e-14), k
+        # ---------------- particle hand-over
+        from fbpic_amd.boundaries.particle_buffer_handling import exchange_particles_between_ranks
+
+        class _Sp:
+            def on_particle_number_changed(self):
+                self.changed = True
+        sp = _Sp()
+        rng = np.random.default_rng(77 + rank)
+        n = 500
+        zlo, zhi = zmin_l + NG * DZ, zmax_l - NG * DZ          # local physical range
+        z = rng.uniform(zlo - 1.5 * DZ, zhi + 1.5 * DZ, n)
+        ids = rank * 10000 + np.arange(n, dtype=np.float64)
+        for k in ('x', 'y', 'ux', 'uy', 'uz', 'inv_gamma'):
+            setattr(sp, k, torch.from_numpy(rng.normal(size=n)))
+        sp.z = torch.from_numpy(z.copy())
+        sp.w = torch.from_numpy(ids.copy())
+        sp.Ntot = n
+
+        class _F:
+            pass
+        fld = _F()
+        g0 = _Grid()
+        g0.zmin, g0.zmax, g0.dz = zmin_l, zmax_l, DZ
+        fld.interp = [g0]
+        exchange_particles_between_ranks(comm, sp, fld, 0.)
+        znew = sp.z.numpy()
+        assert sp.Ntot == znew.size == sp.Ex.shape[0] and sp.changed
+        assert np.all(znew >= zlo - 1e-12) and np.all(znew <= zhi + 1e-12)
+        # global conservation: every particle that had a neighbour to go to still exists once
+        mine = torch.zeros(2 * 10000, dtype=torch.float64)
+        mine[sp.w.numpy().astype(int)] = 1.
+        dist.all_reduce(mine)
+        expected_lost = 0
+        if boundary == 'open':
+            # particles leaving through an open end are dropped
+            tot = torch.tensor([float(((z < zlo) & (comm.left_proc is None)).sum()
+                                      + ((z > zhi) & (comm.right_proc is None)).sum())])
+            dist.all_reduce(tot)
+            expected_lost = int(tot.item())
+        assert int(mine.sum().item()) == world * n - expected_lost
+        assert mine.max().item() == 1.
+        # positions are unchanged modulo the box length
+        L = NZ * DZ
+        own = (sp.w.numpy().astype(int) // 10000) == rank
+        z0 = z[(sp.w.numpy()[own].astype(int)) % 10000]
+        assert np.allclose((znew[own] - z0 + L / 2) % L - L / 2, 0., atol=1e-18)
+        q.put((rank, 'ok'))
+    except Exception as ex:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('boundary', ['periodic', 'open'])
+def test_two_rank_exchange_gloo(boundary):
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, boundary, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(30)
+    for rank, msg in res:
+        assert msg == 'ok', 'rank %d:\n%s' % (rank, msg)
+
+
+def test_decomposition_arithmetic_single_process():
+    """get_Nz_and_iz / get_zmin_zmax for every rank of a 4-rank open-boundary split,
+    evaluated without a process group (rank passed explicitly)."""
+    from fbpic_amd.boundaries.boundary_communicator import BoundaryCommunicator
+    comm = BoundaryCommunicator(1026, -1e-6, -1e-6 + 1026 * DZ, 8, 8 * DZ, 2, DZ / c, None, False,
+                                {'z': 'open', 'r': 'reflective'}, 32, None, {'z': 64, 'r': 32},
+                                1., None, None, False)
+    assert comm.n_guard == 63 and comm.n_inject == 31       # ng = reach + 1
+    assert comm.exchange_period == int((63 / 2 - 3) / 2.)
+    comm.size = 4       # decomposition arithmetic only
+    per = 1026 // 4
+    tot = 0
+    for r in range(4):
+        Nz, iz = comm.get_Nz_and_iz(local=True, with_damp=False, with_guard=False, rank=r)
+        assert iz == r * per and Nz == per + (2 if r == 3 else 0)
+        tot += Nz
+        Nzg, izg = comm.get_Nz_and_iz(local=True, with_damp=True, with_guard=True, rank=r)
+        extra = (64 + 31 if r in (0, 3) else 0)
+        assert Nzg == Nz + 2 * 63 + extra and izg == iz - 63 - (64 + 31 if r == 0 else 0)
+    assert tot == 1026
+    d = comm.generate_damp_array(63, 64, 31)
+    assert d.shape == (158,) and np.all(d[:94] == 0.) and np.all(d[126:] == 1.)
+    assert np.all(np.diff(d[94:126]) > 0)
