@@ -36,6 +36,8 @@ WORK = {
     'fb_push_x': ('hbm', lambda a: 80.0 * a[0]),
     'fb_push_p': ('hbm', lambda a: 112.0 * a[0]),
     'fb_gather': ('hbm', lambda a: 72.0 * a[2]),
+    # fused gather+push_p+push_x: 56 B read + 56 B written + 48 B of stored E,B (union rule)
+    'fb_gather_push': ('hbm', lambda a: 160.0 * a[2]),
     'fb_deposit_rho': ('hbm', lambda a: 32.0 * a[2]),
     'fb_deposit_J': ('hbm', lambda a: 64.0 * a[2]),
     'fb_cell_index': ('hbm', lambda a: 32.0 * a[0]),
@@ -72,11 +74,18 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
-    torch.cuda.set_device(local_rank)
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        # 'nccl' is RCCL on ROCm (xGMI).  FBPIC_AMD_DIST_BACKEND=gloo exists only to smoke-test
+        # the multi-rank path on a single-GPU box (host-staged transport).
+        backend = os.environ.get('FBPIC_AMD_DIST_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node == --gpus'
     from fbpic_amd import _capi
     from fbpic_amd.main import GpuMemoryManager
@@ -84,11 +93,12 @@ def main():
     n_order = -1 if world == 1 else 32
     # weak scaling: every rank owns args.Nz cells; the Simulation is given the global box
     sim = helpers.uniform_plasma_sim(args.Nz * world, args.Nr, args.Nm, ppc, args.shape, seed=0,
-                                     n_order=n_order)
+                                     n_order=n_order, n_guard=(None if world == 1 else 64))
     n_local = sum(s.Ntot for s in sim.ptcl)
     n_total = n_local
     if world > 1:
-        tcount = torch.tensor([n_local], dtype=torch.int64, device='cuda')
+        tcount = torch.tensor([n_local], dtype=torch.int64,
+                              device=('cuda' if dist.get_backend() == 'nccl' else 'cpu'))
         dist.all_reduce(tcount)
         n_total = int(tcount.item())
     cpu_base = None
@@ -114,7 +124,8 @@ def main():
             sim.step(3)
             kern = _capi.collect_timing()
     if world > 1:
-        tt = torch.tensor([dt_wall], dtype=torch.float64, device='cuda')
+        tt = torch.tensor([dt_wall], dtype=torch.float64,
+                          device=('cuda' if dist.get_backend() == 'nccl' else 'cpu'))
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt_wall = float(tt.item())
     if rank != 0:

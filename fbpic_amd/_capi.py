@@ -24,13 +24,15 @@ _SIGNATURES = {
     'fb_push_p': (I, [L, P, P, P, P, P, P, P, P, P, P, D, D, D, D, P]),
     'fb_shift_periodic': (I, [L, P, D, D, P]),
     'fb_gather': (I, [I, I, L, P, P, P, D, D, D, I, D, D, I, _PP, L, P, P, P, P, P, P, P]),
+    'fb_gather_push': (I, [I, I, L, P, P, P, P, P, P, P, D, D, D, I, D, D, I, _PP, L,
+                           P, P, P, P, P, P, D, D, D, D, D, P]),
     'fb_cell_index': (I, [L, P, P, P, D, D, I, D, D, I, P, P, P]),
     'fb_sort_workspace_bytes': (Z, [L, I]),
     'fb_sort_by_cell': (I, [L, I, P, P, P, P, ctypes.POINTER(I), P, P, Z, P]),
     'fb_permute': (I, [L, P, I, _PP, _PP, P]),
-    'fb_deposit_rho': (I, [I, I, L, P, P, P, P, D, D, D, I, D, D, I, _PP, L, P, P, P, P]),
+    'fb_deposit_rho': (I, [I, I, L, P, P, P, P, D, D, D, I, D, D, I, _PP, L, P, P, P, P, P]),
     'fb_deposit_J': (I, [I, I, L, P, P, P, P, D, P, P, P, P, D, D, D, I, D, D, I, _PP, L,
-                         P, P, P, P]),
+                         P, P, P, P, P]),
     'fb_erase': (I, [I, _PP, L, I, I, P]),
     'fb_divide_by_volume': (I, [I, _PP, L, P, I, I, P]),
     'fb_filter': (I, [I, _PP, L, P, P, I, I, P]),
@@ -44,6 +46,8 @@ _SIGNATURES = {
     'fb_fft_exec': (I, [P, I, P, P, P]),
     'fb_fft_plan_destroy': (I, [P]),
     'fb_hankel': (I, [I, _PP, L, _PP, L, _PP, D, I, I, P]),
+    'fb_hankel_scaled': (I, [I, _PP, L, _PP, L, _PP, _PP, _PP, _PP, D, I, I, P]),
+    'fb_psatd_step_standard': (I, [I, _PP, L, _PP, D, I, I, D, D, D, I, I, P]),
 }
 
 EXPORTS = tuple(_SIGNATURES)
@@ -111,9 +115,9 @@ def ptr(t):
 
 
 def ptr_array(tensors):
-    """Host array of device pointers."""
+    """Host array of device pointers (None entries become NULL)."""
     n = len(tensors)
-    return (P * n)(*[t.data_ptr() for t in tensors])
+    return (P * n)(*[(t.data_ptr() if t is not None else None) for t in tensors])
 
 
 def row_stride(t):

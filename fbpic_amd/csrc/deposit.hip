@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
         double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
         DepGrids G, long rs, int m0,
         const double *__restrict__ beta0, const double *__restrict__ betah,
-        int chunks_per_wave)
+        int chunks_per_wave, unsigned long long *__restrict__ nflush)
 {
     using L = DepLayout<SHAPE, NCOMP, NM>;
     constexpr int S = L::S, H = ShapeTraits<SHAPE>::H;
@@ -151,9 +151,11 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
 #pragma unroll
     for (int j = 0; j < OPL; j++) acc[j] = 0.;
     int cur_z = DEP_NOKEY, cur_r = DEP_NOKEY;
+    unsigned int my_flushes = 0;      // wave-uniform: runs of equal cells seen by this wave
 
     auto flush = [&]() {
         if (cur_z == DEP_NOKEY) return;
+        my_flushes++;
 #pragma unroll
         for (int j = 0; j < OPL; j++) {
             if (!o_ok[j] || acc[j] == 0.) continue;
@@ -165,15 +167,29 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
     };
 
     const long chunk0 = ((long)blockIdx.x * nwaves + wave) * chunks_per_wave;
+    // software pipeline: particle data of chunk ch+1 is requested before chunk ch is
+    // processed, hiding the HBM latency behind the staging + accumulation work
+    double pn[NCOMP == 1 ? 4 : 8];
+    auto prefetch = [&](long ip) {
+        if (ip < n) {
+            pn[0] = x[ip]; pn[1] = y[ip]; pn[2] = z[ip]; pn[3] = w[ip];
+            if constexpr (NCOMP == 3) { pn[4] = ux[ip]; pn[5] = uy[ip]; pn[6] = uz[ip]; pn[7] = inv_gamma[ip]; }
+        }
+    };
+    prefetch(chunk0 * 64 + lane);
     for (int ch = 0; ch < chunks_per_wave; ch++) {
         const long base = (chunk0 + ch) * 64;
         if (base >= n) break;
         const long ip = base + lane;
         // ---- phase 1: lane = particle; stage weights / amplitudes, keep the cell key
         int my_kz = DEP_NOKEY, my_kr = DEP_NOKEY, my_nb = 0;
+        double pc[NCOMP == 1 ? 4 : 8];
+#pragma unroll
+        for (int k = 0; k < (NCOMP == 1 ? 4 : 8); k++) pc[k] = pn[k];
+        if (ch + 1 < chunks_per_wave) prefetch(ip + 64);
         if (ip < n) {
-            const double xj = x[ip], yj = y[ip], zj = z[ip];
-            const double wj = q * w[ip];
+            const double xj = pc[0], yj = pc[1], zj = pc[2];
+            const double wj = q * pc[3];
             const double rj = sqrt(xj * xj + yj * yj);
             double cs, sn;
             if (rj != 0.) { double invr = 1. / rj; cs = xj * invr; sn = yj * invr; }
@@ -182,10 +198,10 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
             if constexpr (NCOMP == 1) {
                 are[0] = wj; aim[0] = 0.;
             } else {
-                const double ig = inv_gamma[ip];
-                are[0] = wj * c_light * ig * (cs * ux[ip] + sn * uy[ip]); aim[0] = 0.;
-                are[1] = wj * c_light * ig * (cs * uy[ip] - sn * ux[ip]); aim[1] = 0.;
-                are[2] = wj * c_light * ig * uz[ip]; aim[2] = 0.;
+                const double ig = pc[7];
+                are[0] = wj * c_light * ig * (cs * pc[4] + sn * pc[5]); aim[0] = 0.;
+                are[1] = wj * c_light * ig * (cs * pc[5] - sn * pc[4]); aim[1] = 0.;
+                are[2] = wj * c_light * ig * pc[6]; aim[2] = 0.;
             }
             // mode recurrence (cos + i sin)^m, threading_methods.py:119-121, 264-267
             for (int m = 0; m < m0; m++) {
@@ -272,13 +288,18 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
         __builtin_amdgcn_wave_barrier();
     }
     flush();
+    // fragmentation statistic for the host's sort policy: 1024 counters (same-address
+    // device atomics serialise at ~10 ns each; one shared counter would cost > 100 us)
+    if (nflush && lane == 0)
+        atomicAdd(nflush + ((blockIdx.x * nwaves + wave) & 1023), (unsigned long long)my_flushes);
 }
 
 template <int SHAPE, int NCOMP, int NM>
 static int launch_one(long n, const double *x, const double *y, const double *z, const double *w,
         double q, const double *ux, const double *uy, const double *uz, const double *ig,
         double c, double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
-        const DepGrids &G, long rs, int m0, const double *b0, const double *bh, hipStream_t s)
+        const DepGrids &G, long rs, int m0, const double *b0, const double *bh,
+        unsigned long long *nflush, hipStream_t s)
 {
     using L = DepLayout<SHAPE, NCOMP, NM>;
     // waves per workgroup: keep the LDS panel <= 64 KiB
@@ -287,7 +308,7 @@ static int launch_one(long n, const double *x, const double *y, const double *z,
     const long nchunks = (n + 63) / 64;
     // ~8 waves per SIMD-quad in flight over 256 CUs, each walking consecutive chunks so
     // that a cell straddling two chunks is not flushed twice
-    long target_waves = 256L * 32;
+    long target_waves = 256L * 64;
     int cpw = (int)((nchunks + target_waves - 1) / target_waves);
     if (cpw < 1) cpw = 1;
     if (cpw > 64) cpw = 64;
@@ -296,7 +317,7 @@ static int launch_one(long n, const double *x, const double *y, const double *z,
     auto kern = k_deposit<SHAPE, NCOMP, NM>;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(64 * nwaves),
                        L::wave_bytes() * nwaves, s, n, x, y, z, w, q, ux, uy, uz, ig, c,
-                       invdz, zmin, Nz, invdr, rmin, Nr, G, rs, m0, b0, bh, cpw);
+                       invdz, zmin, Nz, invdr, rmin, Nr, G, rs, m0, b0, bh, cpw, (m0 == 0) ? nflush : nullptr);
     return check(hipGetLastError(), "fb_deposit");
 }
 
@@ -304,12 +325,13 @@ template <int SHAPE, int NCOMP>
 static int launch_modes(int Nm, long n, const double *x, const double *y, const double *z,
         const double *w, double q, const double *ux, const double *uy, const double *uz,
         const double *ig, double c, double invdz, double zmin, int Nz, double invdr, double rmin,
-        int Nr, const DepGrids &G, long rs, const double *b0, const double *bh, hipStream_t s)
+        int Nr, const DepGrids &G, long rs, const double *b0, const double *bh,
+        unsigned long long *nflush, hipStream_t s)
 {
     int m0 = 0;
     while (m0 < Nm) {
         int left = Nm - m0, r;
-#define ARGS n, x, y, z, w, q, ux, uy, uz, ig, c, invdz, zmin, Nz, invdr, rmin, Nr, G, rs, m0, b0, bh, s
+#define ARGS n, x, y, z, w, q, ux, uy, uz, ig, c, invdz, zmin, Nz, invdr, rmin, Nr, G, rs, m0, b0, bh, nflush, s
         if (left >= 4) { r = launch_one<SHAPE, NCOMP, 4>(ARGS); m0 += 4; }
         else if (left == 3) { r = launch_one<SHAPE, NCOMP, 3>(ARGS); m0 += 3; }
         else if (left == 2) { r = launch_one<SHAPE, NCOMP, 2>(ARGS); m0 += 2; }
@@ -327,7 +349,8 @@ using namespace fb;
 extern "C" int fb_deposit_rho(int shape, int Nm, long n, const double *x, const double *y,
         const double *z, const double *w, double q, double invdz, double zmin, int Nz,
         double invdr, double rmin, int Nr, void *const *rho, long row_stride,
-        const int *prefix_sum, const double *ruyten_m0, const double *ruyten_mh, void *stream)
+        const int *prefix_sum, const double *ruyten_m0, const double *ruyten_mh,
+        unsigned long long *nflush, void *stream)
 {
     (void)prefix_sum;
     if (n <= 0) return 0;
@@ -338,11 +361,11 @@ extern "C" int fb_deposit_rho(int shape, int Nm, long n, const double *x, const 
     if (shape == FB_SHAPE_LINEAR)
         return launch_modes<FB_SHAPE_LINEAR, 1>(Nm, n, x, y, z, w, q, nullptr, nullptr, nullptr,
                 nullptr, 0., invdz, zmin, Nz, invdr, rmin, Nr, G, row_stride, ruyten_m0,
-                ruyten_mh, s);
+                ruyten_mh, nflush, s);
     if (shape == FB_SHAPE_CUBIC)
         return launch_modes<FB_SHAPE_CUBIC, 1>(Nm, n, x, y, z, w, q, nullptr, nullptr, nullptr,
                 nullptr, 0., invdz, zmin, Nz, invdr, rmin, Nr, G, row_stride, ruyten_m0,
-                ruyten_mh, s);
+                ruyten_mh, nflush, s);
     set_error("fb_deposit_rho", "unknown shape");
     return -1;
 }
@@ -351,7 +374,8 @@ extern "C" int fb_deposit_J(int shape, int Nm, long n, const double *x, const do
         const double *z, const double *w, double q, const double *ux, const double *uy,
         const double *uz, const double *inv_gamma, double c, double invdz, double zmin, int Nz,
         double invdr, double rmin, int Nr, void *const *J, long row_stride,
-        const int *prefix_sum, const double *ruyten_m0, const double *ruyten_mh, void *stream)
+        const int *prefix_sum, const double *ruyten_m0, const double *ruyten_mh,
+        unsigned long long *nflush, void *stream)
 {
     (void)prefix_sum;
     if (n <= 0) return 0;
@@ -361,10 +385,10 @@ extern "C" int fb_deposit_J(int shape, int Nm, long n, const double *x, const do
     hipStream_t s = (hipStream_t)stream;
     if (shape == FB_SHAPE_LINEAR)
         return launch_modes<FB_SHAPE_LINEAR, 3>(Nm, n, x, y, z, w, q, ux, uy, uz, inv_gamma, c,
-                invdz, zmin, Nz, invdr, rmin, Nr, G, row_stride, ruyten_m0, ruyten_mh, s);
+                invdz, zmin, Nz, invdr, rmin, Nr, G, row_stride, ruyten_m0, ruyten_mh, nflush, s);
     if (shape == FB_SHAPE_CUBIC)
         return launch_modes<FB_SHAPE_CUBIC, 3>(Nm, n, x, y, z, w, q, ux, uy, uz, inv_gamma, c,
-                invdz, zmin, Nz, invdr, rmin, Nr, G, row_stride, ruyten_m0, ruyten_mh, s);
+                invdz, zmin, Nz, invdr, rmin, Nr, G, row_stride, ruyten_m0, ruyten_mh, nflush, s);
     set_error("fb_deposit_J", "unknown shape");
     return -1;
 }

@@ -159,6 +159,69 @@ __global__ __launch_bounds__(256) void k_push_eb(cplx *__restrict__ Ep, cplx *__
     }
 }
 
+// Fused spectral step for ALL modes in one launch (single-domain fast path):
+// curl-free current correction (numba_methods.py:63-85) -> PSATD push of E,B
+// (:118-185) -> rho_prev <- rho_next, rho_next <- 0 (spectral_grid.py:407-421).
+// All three are cell-local, so the corrected J never leaves registers.  Per mode:
+// 11 field pointers in SpectralGrid order and 8 table pointers.
+struct PsatdModes {
+    cplx *f[11 * FB_MAX_MODES];
+    const double *t[8 * FB_MAX_MODES];   // rho_prev_coef, rho_next_coef, j_coef, C, S_w, kr, kz, inv_k2
+};
+
+__global__ __launch_bounds__(256) void k_psatd_step(PsatdModes M, long rs, double dt, double inv_dt,
+        int correct, int use_true_rho, double c2, double eps0, double mu0, int Nz, int Nr)
+{
+    const int m = blockIdx.y;
+    cplx *const *f = M.f + 11 * m;
+    const double *const *t = M.t + 8 * m;
+    FB_GRID_LOOP(idx, iz, ir) {
+        const long o = (long)iz * rs + ir;
+        const double rpc = t[0][idx], rnc = t[1][idx], jc = t[2][idx], Cc = t[3][idx], Sw = t[4][idx];
+        const double krr = t[5][idx], kzz = t[6][idx];
+        const cplx ep = ld(f[0] + o), em = ld(f[1] + o), ez = ld(f[2] + o);
+        const cplx bp = ld(f[3] + o), bm = ld(f[4] + o), bz = ld(f[5] + o);
+        cplx jp = ld(f[6] + o), jm = ld(f[7] + o), jz = ld(f[8] + o);
+        const cplx rp = ld(f[9] + o), rn = ld(f[10] + o);
+        if (correct) {
+            cplx t1 = rmul(inv_dt, csub(rn, rp));
+            cplx t2 = rmul(kzz, imul(jz));
+            cplx t3 = rmul(krr, csub(jp, jm));
+            cplx F = rmul(-t[7][idx], cadd(cadd(t1, t2), t3));
+            jp = cadd(jp, rmul(0.5 * krr, F));
+            jm = cadd(jm, rmul(-0.5 * krr, F));
+            jz = cadd(jz, rmul(kzz, imul(rmul(-1., F))));
+            st(f[6] + o, jp); st(f[7] + o, jm); st(f[8] + o, jz);
+        }
+        cplx rho_diff;
+        if (use_true_rho) {
+            rho_diff = csub(rmul(rnc, rn), rmul(rpc, rp));
+        } else {
+            cplx divE = cadd(rmul(krr, csub(ep, em)), rmul(kzz, imul(ez)));
+            cplx divJ = cadd(rmul(krr, csub(jp, jm)), rmul(kzz, imul(jz)));
+            rho_diff = csub(rmul((rnc - rpc) * eps0, divE), rmul(rnc * dt, divJ));
+        }
+        const cplx mihkBz = rmul(0.5 * krr, imul(rmul(-1., bz)));
+        st(f[0] + o, cadd(cadd(rmul(Cc, ep), rmul(0.5 * krr, rho_diff)),
+                          rmul(c2 * Sw, csub(cadd(mihkBz, rmul(kzz, bp)), rmul(mu0, jp)))));
+        st(f[1] + o, cadd(csub(rmul(Cc, em), rmul(0.5 * krr, rho_diff)),
+                          rmul(c2 * Sw, csub(csub(mihkBz, rmul(kzz, bm)), rmul(mu0, jm)))));
+        st(f[2] + o, cadd(csub(rmul(Cc, ez), rmul(kzz, imul(rho_diff))),
+                          rmul(c2 * Sw, csub(cadd(rmul(krr, imul(bp)), rmul(krr, imul(bm))),
+                                             rmul(mu0, jz)))));
+        const cplx mihkEz = rmul(0.5 * krr, imul(rmul(-1., ez)));
+        const cplx mihkJz = rmul(0.5 * krr, imul(rmul(-1., jz)));
+        st(f[3] + o, cadd(csub(rmul(Cc, bp), rmul(Sw, cadd(mihkEz, rmul(kzz, ep)))),
+                          rmul(jc, cadd(mihkJz, rmul(kzz, jp)))));
+        st(f[4] + o, cadd(csub(rmul(Cc, bm), rmul(Sw, csub(mihkEz, rmul(kzz, em)))),
+                          rmul(jc, csub(mihkJz, rmul(kzz, jm)))));
+        st(f[5] + o, cadd(csub(rmul(Cc, bz), rmul(Sw, cadd(rmul(krr, imul(ep)), rmul(krr, imul(em))))),
+                          rmul(jc, cadd(rmul(krr, imul(jp)), rmul(krr, imul(jm))))));
+        st(f[9] + o, rn);
+        st(f[10] + o, {0., 0.});
+    }
+}
+
 // fields/spectral_grid.py:407-421
 __global__ __launch_bounds__(256) void k_push_rho(cplx *__restrict__ rho_prev,
                                                   cplx *__restrict__ rho_next, long rs, int Nz, int Nr)
@@ -283,4 +346,18 @@ extern "C" int fb_push_rho(void *rho_prev, void *rho_next, long rs, int Nz, int 
     hipLaunchKernelGGL(k_push_rho, dim3(grid_for(Nz, Nr)), dim3(256), 0, (hipStream_t)stream,
                        (cplx *)rho_prev, (cplx *)rho_next, rs, Nz, Nr);
     FB_CHECK_LAUNCH("fb_push_rho");
+}
+
+extern "C" int fb_psatd_step_standard(int Nm, void *const *fields, long rs,
+        const double *const *tables, double dt, int correct_currents, int use_true_rho,
+        double c, double epsilon_0, double mu_0, int Nz, int Nr, void *stream)
+{
+    if (Nm < 1 || Nm > FB_MAX_MODES) { set_error("fb_psatd_step_standard", "Nm out of range"); return -1; }
+    PsatdModes M;
+    for (int i = 0; i < 11 * FB_MAX_MODES; i++) M.f[i] = i < 11 * Nm ? (cplx *)fields[i] : nullptr;
+    for (int i = 0; i < 8 * FB_MAX_MODES; i++) M.t[i] = i < 8 * Nm ? tables[i] : nullptr;
+    dim3 grid(stream_grid((long)Nz * Nr, 256, 256 * 4), Nm);
+    hipLaunchKernelGGL(k_psatd_step, grid, dim3(256), 0, (hipStream_t)stream, M, rs, dt, 1. / dt,
+                       correct_currents, use_true_rho, c * c, epsilon_0, mu_0, Nz, Nr);
+    FB_CHECK_LAUNCH("fb_psatd_step_standard");
 }

@@ -1,6 +1,9 @@
 // Discrete Hankel transform along r as an fp64 MFMA GEMM on gfx950.
 //
-// out[iz, n] = alpha * sum_k in[iz, k] * mat[k, n]   (complex row x real (Nr,Nr) matrix)
+// out[iz, n] = alpha * fz[iz] * fr[n] * sum_k ( in[iz, k] * sk[k] ) * mat[k, n]
+//   (complex row x real (Nr,Nr) matrix; the optional real scalings sk / fz / fr fuse the
+//    reference's divide-by-volume pass -- it commutes with the z-FFT -- and its spectral
+//    filter pass into the transform; all three default to 1)
 //
 // The reference splits the complex (Nz,Nr) array into a real (2Nz,Nr) one, calls cuBLAS
 // dgemm and re-interleaves (fbpic/fields/spectral_transform/hankel.py:196-205).  Here the
@@ -10,12 +13,12 @@
 // in the same lane/register, so the store is again one 16-B complex write.
 //
 // Tiling: workgroup = 4 waves = 64 z rows x 64 output columns; wave w owns rows
-// [16w,16w+16) and 4 column sub-tiles -> 8 independent accumulator chains (64 VGPRs),
-// enough to keep the 64-cycle f64 MFMA pipe full from one wave per SIMD.  B (the Hankel
-// matrix, <= 2 MiB) is read through L1/L2: one f64 MFMA consumes 1 KiB of operands per
-// 64 cycles, far below the cache bandwidth, so no LDS staging is needed.
-// Jobs (field x mode) are batched along gridDim.z so that one launch carries enough
-// tiles to fill 256 CUs.
+// [16w,16w+16) and 4 column sub-tiles -> 8 independent accumulator chains (64 VGPRs): one
+// wave per SIMD keeps the 64-cycle f64 MFMA pipe busy as long as its operands arrive.
+// Operands are double-buffered through LDS (see k_hankel): fragment-shaped loads straight
+// from global memory touch 16 half-used cache lines per instruction and saturate the
+// texture-address path long before the MFMA pipe (measured: 12% of peak).
+// Jobs (field x mode) are batched along gridDim.z so one launch fills 256 CUs.
 //
 // Fragment layouts (cdna_hip_programming.md section 3, f64 row formula):
 //   A: lane l -> A[i = l & 15][k = l >> 4]      B: lane l -> B[k = l >> 4][j = l & 15]
@@ -26,69 +29,180 @@ namespace fb {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+constexpr int HK_MAXJOBS = 48;
 struct HankelJobs {
-    const cplx *in[48];
-    cplx *out[48];
-    const double *mat[48];
+    const cplx *in[HK_MAXJOBS];
+    cplx *out[HK_MAXJOBS];
+    const double *mat[HK_MAXJOBS];
+};
+struct HankelScales {
+    const double *sk[HK_MAXJOBS];     // per input column k (e.g. 1/volume), or null
+    const double *fz[HK_MAXJOBS];     // per output row iz (filter along z), or null
+    const double *fr[HK_MAXJOBS];     // per output column n (filter along r), or null
 };
 
-__global__ __launch_bounds__(256) void k_hankel(HankelJobs J, long irs, long ors, double alpha,
-                                                int Nz, int Nr)
+constexpr int HK_KC = 32;                 // k-chunk staged per pipeline stage
+constexpr int HK_RSA = HK_KC * 2 + 2;     // A panel row stride in doubles (16-B pad: rows rotate banks)
+constexpr int HK_RSB = 64 + 16;           // B panel row stride in doubles (+128 B: k rows alternate bank halves)
+constexpr int HK_TZ = 32;                 // z rows per workgroup
+constexpr int HK_ABUF = HK_TZ * HK_RSA;   // doubles per A buffer
+constexpr int HK_BBUF = HK_KC * HK_RSB;   // doubles per B buffer
+constexpr size_t HK_LDS_BYTES = (size_t)2 * (HK_ABUF + HK_BBUF) * 8;
+
+// Workgroup = 4 waves (2 x 2) = 32 z rows x 64 output columns; wave (wz, wn) owns rows
+// [16 wz, +16) and columns [32 wn, +32): 2 column sub-tiles x (re, im) = 4 accumulator
+// chains.  The small tile keeps the launch balanced over 256 CUs (C2: 768 workgroups for
+// E+B, 3 per CU, two co-resident so one's load latency hides under the other's MFMAs).
+// K is walked in chunks of 32:
+//   global -> registers (coalesced: full 512-B row segments of the complex input and of the
+//   matrix) for chunk c+1 is issued BEFORE the 32 MFMAs (2048 cycles) of chunk c, then
+//   written to the other LDS buffer; one barrier per chunk.  MFMA operands come from LDS
+//   (padded panels, conflict-free ds_read_b128 / ds_read_b64), so the vector-memory path
+//   only sees coalesced traffic and each matrix element is fetched once per workgroup.
+template <bool SCALED>
+__global__ __launch_bounds__(256) void k_hankel(HankelJobs J, HankelScales Sc, long irs, long ors,
+                                                double alpha, int Nz, int Nr)
 {
+    extern __shared__ double hk_lds[];
     const int job = blockIdx.z;
     const cplx *__restrict__ in = J.in[job];
     cplx *__restrict__ out = J.out[job];
     const double *__restrict__ mat = J.mat[job];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    const int z0 = blockIdx.x * 64 + wave * 16;
-    const int n0 = blockIdx.y * 64;
-    if (z0 >= Nz) return;   // whole wave out of range (no barriers in this kernel)
+    const int wz = wave >> 1, wn = wave & 1;
+    const int zb = blockIdx.x * HK_TZ, n0 = blockIdx.y * 64;
+    const double *sk = SCALED ? Sc.sk[job] : nullptr;
 
-    double4_t acc_re[4], acc_im[4];
+    double4_t acc_re[2], acc_im[2];
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
+    for (int t = 0; t < 2; t++) {
         acc_re[t] = (double4_t){0., 0., 0., 0.};
         acc_im[t] = (double4_t){0., 0., 0., 0.};
     }
-    const int za = z0 + li;
-    const bool za_ok = za < Nz;
-    const cplx *arow = in + (long)(za_ok ? za : 0) * irs;
-    bool n_ok[4];
-    int ncol[4];
+    // staging registers: A chunk = 32 rows x 32 complex (4 per thread), B chunk = 32 x 64
+    // doubles (8 per thread)
+    double2 ra[4];
+    double rb[8];
+    auto gload = [&](int k0) {
 #pragma unroll
-    for (int t = 0; t < 4; t++) { ncol[t] = n0 + 16 * t + li; n_ok[t] = ncol[t] < Nr; if (!n_ok[t]) ncol[t] = 0; }
-
-    const int ksteps = (Nr + 3) / 4;
-#pragma unroll 2
-    for (int ks = 0; ks < ksteps; ks++) {
-        const int k = ks * 4 + lk;
-        const bool k_ok = k < Nr;
-        const int kc = k_ok ? k : 0;
-        double2 a = *(const double2 *)(arow + kc);
-        if (!(k_ok && za_ok)) { a.x = 0.; a.y = 0.; }
-        const double *brow = mat + (long)kc * Nr;
-        double b[4];
-#pragma unroll
-        for (int t = 0; t < 4; t++) { b[t] = brow[ncol[t]]; if (!(k_ok && n_ok[t])) b[t] = 0.; }
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            acc_re[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b[t], acc_re[t], 0, 0, 0);
-            acc_im[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b[t], acc_im[t], 0, 0, 0);
+        for (int j = 0; j < 4; j++) {
+            const int idx = j * 256 + tid;
+            const int row = idx >> 5, kk = idx & 31;
+            const int zz = zb + row, k = k0 + kk;
+            double2 v = make_double2(0., 0.);
+            if (zz < Nz && k < Nr) {
+                v = *(const double2 *)(in + (long)zz * irs + k);
+                if (SCALED && sk) { const double s_ = sk[k]; v.x *= s_; v.y *= s_; }
+            }
+            ra[j] = v;
         }
-    }
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-        const int n = n0 + 16 * t + li;
+        for (int j = 0; j < 8; j++) {
+            const int idx = j * 256 + tid;
+            const int kr = idx >> 6, nn = idx & 63;
+            const int k = k0 + kr, n = n0 + nn;
+            rb[j] = (k < Nr && n < Nr) ? mat[(long)k * Nr + n] : 0.;
+        }
+    };
+    auto lstore = [&](int buf) {
+        double *A = hk_lds + buf * (HK_ABUF + HK_BBUF);
+        double *B = A + HK_ABUF;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int idx = j * 256 + tid;
+            *(double2 *)(A + (idx >> 5) * HK_RSA + 2 * (idx & 31)) = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int idx = j * 256 + tid;
+            B[(idx >> 6) * HK_RSB + (idx & 63)] = rb[j];
+        }
+    };
+    const int nchunks = (Nr + HK_KC - 1) / HK_KC;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; c++) {
+        const int cur = c & 1;
+        if (c + 1 < nchunks) gload((c + 1) * HK_KC);
+        const double *A = hk_lds + cur * (HK_ABUF + HK_BBUF) + (wz * 16 + li) * HK_RSA;
+        const double *B = hk_lds + cur * (HK_ABUF + HK_BBUF) + HK_ABUF + 32 * wn;
+#pragma unroll
+        for (int s = 0; s < HK_KC / 4; s++) {
+            const double2 a = *(const double2 *)(A + 2 * (4 * s + lk));
+            const double *brow = B + (4 * s + lk) * HK_RSB + li;
+            double b[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) b[t] = brow[16 * t];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                acc_re[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b[t], acc_re[t], 0, 0, 0);
+                acc_im[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b[t], acc_im[t], 0, 0, 0);
+            }
+        }
+        if (c + 1 < nchunks) lstore(cur ^ 1);
+        __syncthreads();
+    }
+    const int z0 = zb + wz * 16;
+    const double *fz = SCALED ? Sc.fz[job] : nullptr;
+    const double *fr = SCALED ? Sc.fr[job] : nullptr;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int n = n0 + 32 * wn + 16 * t + li;
         if (n >= Nr) continue;
+        double cn = alpha;
+        if (SCALED && fr) cn *= fr[n];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int zz = z0 + lk + 4 * r;
-            if (zz < Nz)
+            if (zz < Nz) {
+                double cz = cn;
+                if (SCALED && fz) cz = fz[zz] * cn;     // fz[iz]*fr[ir]*F as in numba_filter_*
                 *(double2 *)(out + (long)zz * ors + n) =
-                    make_double2(alpha * acc_re[t][r], alpha * acc_im[t][r]);
+                    make_double2(cz * acc_re[t][r], cz * acc_im[t][r]);
+            }
         }
     }
+}
+
+static int launch(int njobs, const void *const *in, long irs, void *const *out, long ors,
+                  const double *const *mat, const double *const *sk, const double *const *fz,
+                  const double *const *fr, double alpha, int Nz, int Nr, hipStream_t s)
+{
+    const bool scaled = sk || fz || fr;
+    for (int j0 = 0; j0 < njobs; j0 += HK_MAXJOBS) {
+        const int nj = njobs - j0 < HK_MAXJOBS ? njobs - j0 : HK_MAXJOBS;
+        HankelJobs J;
+        HankelScales Sc;
+        for (int j = 0; j < HK_MAXJOBS; j++) {
+            const bool v = j < nj;
+            J.in[j] = v ? (const cplx *)in[j0 + j] : nullptr;
+            J.out[j] = v ? (cplx *)out[j0 + j] : nullptr;
+            J.mat[j] = v ? mat[j0 + j] : nullptr;
+            Sc.sk[j] = (v && sk) ? sk[j0 + j] : nullptr;
+            Sc.fz[j] = (v && fz) ? fz[j0 + j] : nullptr;
+            Sc.fr[j] = (v && fr) ? fr[j0 + j] : nullptr;
+        }
+        dim3 grid((Nz + HK_TZ - 1) / HK_TZ, (Nr + 63) / 64, nj);
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e1 = hipFuncSetAttribute((const void *)k_hankel<true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)HK_LDS_BYTES);
+            hipError_t e2 = hipFuncSetAttribute((const void *)k_hankel<false>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)HK_LDS_BYTES);
+            if (e1 != hipSuccess) return check(e1, "fb_hankel(attr)");
+            if (e2 != hipSuccess) return check(e2, "fb_hankel(attr)");
+            attr_done = true;
+        }
+        if (scaled)
+            hipLaunchKernelGGL(k_hankel<true>, grid, dim3(256), HK_LDS_BYTES, s, J, Sc, irs, ors, alpha, Nz, Nr);
+        else
+            hipLaunchKernelGGL(k_hankel<false>, grid, dim3(256), HK_LDS_BYTES, s, J, Sc, irs, ors, alpha, Nz, Nr);
+        int r = check(hipGetLastError(), "fb_hankel");
+        if (r) return r;
+    }
+    return 0;
 }
 
 }  // namespace fb
@@ -100,20 +214,17 @@ extern "C" int fb_hankel(int njobs, const void *const *in, long in_row_stride, v
                          int Nr, void *stream)
 {
     if (njobs <= 0) return 0;
-    hipStream_t s = (hipStream_t)stream;
-    for (int j0 = 0; j0 < njobs; j0 += 48) {
-        int nj = njobs - j0 < 48 ? njobs - j0 : 48;
-        HankelJobs J;
-        for (int j = 0; j < 48; j++) {
-            J.in[j] = j < nj ? (const cplx *)in[j0 + j] : nullptr;
-            J.out[j] = j < nj ? (cplx *)out[j0 + j] : nullptr;
-            J.mat[j] = j < nj ? mat[j0 + j] : nullptr;
-        }
-        dim3 grid((Nz + 63) / 64, (Nr + 63) / 64, nj);
-        hipLaunchKernelGGL(k_hankel, grid, dim3(256), 0, s, J, in_row_stride, out_row_stride,
-                           alpha, Nz, Nr);
-        int r = check(hipGetLastError(), "fb_hankel");
-        if (r) return r;
-    }
-    return 0;
+    return launch(njobs, in, in_row_stride, out, out_row_stride, mat, nullptr, nullptr, nullptr,
+                  alpha, Nz, Nr, (hipStream_t)stream);
+}
+
+extern "C" int fb_hankel_scaled(int njobs, const void *const *in, long in_row_stride,
+                                void *const *out, long out_row_stride, const double *const *mat,
+                                const double *const *in_col_scale, const double *const *out_row_scale,
+                                const double *const *out_col_scale, double alpha, int Nz, int Nr,
+                                void *stream)
+{
+    if (njobs <= 0) return 0;
+    return launch(njobs, in, in_row_stride, out, out_row_stride, mat, in_col_scale, out_row_scale,
+                  out_col_scale, alpha, Nz, Nr, (hipStream_t)stream);
 }

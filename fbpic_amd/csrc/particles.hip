@@ -105,14 +105,42 @@ __global__ __launch_bounds__(256) void k_shift_periodic(long n, double *__restri
 }
 
 // ------------------------------------------------------------------ gather
-// Field gather for any number of azimuthal modes in ONE pass over the particles
-// (the reference needs Nm launches + an erase for Nm != 2).  Semantics:
+// Field gather for any number of azimuthal modes in ONE pass over the particles (the
+// reference needs Nm launches + an erase for Nm != 2).  Semantics:
 // fbpic/particles/gathering/threading_methods.py:25-201 (linear), :207-367 (cubic),
 // inline_functions.py:9-187; exptheta_m by recurrence; modes are summed before the
 // (r,t)->(x,y) rotation as in the Nm==2 kernels.
+//
+// MI355X design: particles arrive cell-sorted, so the 64 particles of a wave span only a
+// few cells ("segments").  All particles of a cell read the SAME S x S grid nodes of the
+// 6*Nm field arrays.  Instead of 48 (linear, Nm=2) 16-byte global loads per lane through
+// the 64 B/clk vector-L1 path, the wave
+//   1. finds its segments with one ballot on the (iz, ir) stencil origin,
+//   2. stages, per segment, the S*S*6*Nm complex node values ONCE into an LDS panel
+//      (lane = node value; below-axis mirror sign, r clamp and z wrap applied here),
+//   3. lets every lane evaluate its stencil from its segment's panel with broadcast
+//      ds_read_b128 (256 B/clk), so the kernel is bound by the particle streams
+//      (24 B read + 48 B written per particle).
+// Any order of particles gives the same result; an unsorted stream just has more segments.
 struct GatherGrids { const cplx *g[6 * FB_MAX_MODES]; };
 
+// Optional fusion of the two kernels that follow the gather in the PIC cycle
+// (main.py:469-490): Vay push_p with the fields still in registers, then push_x over dt_x.
+// The particle E,B arrays are still written when their pointers are non-null.
+struct PushArgs {
+    double *x, *y, *z;            // writable aliases of the position arrays (push_x)
+    double *ux, *uy, *uz, *ig;    // null -> gather only
+    double econst, bconst;        // q dt / (m c), q dt / (2 m)
+    double chdt;                  // c * dt_x ; 0 -> no position push
+};
+
 __device__ __forceinline__ double2 ldc(const cplx *p) { return *(const double2 *)p; }
+
+template <int SHAPE> struct GShape;
+template <> struct GShape<FB_SHAPE_LINEAR> { static constexpr int S = 2, OFF = 0; };
+template <> struct GShape<FB_SHAPE_CUBIC> { static constexpr int S = 4, OFF = 1; };
+
+constexpr int G_NOKEY = -0x40000000;
 
 template <int SHAPE>
 __global__ __launch_bounds__(256) void k_gather(int Nm, long n,
@@ -121,132 +149,154 @@ __global__ __launch_bounds__(256) void k_gather(int Nm, long n,
         double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
         GatherGrids G, long rs,
         double *__restrict__ Ex, double *__restrict__ Ey, double *__restrict__ Ez,
-        double *__restrict__ Bx, double *__restrict__ By, double *__restrict__ Bz)
+        double *__restrict__ Bx, double *__restrict__ By, double *__restrict__ Bz,
+        int maxseg, int chunks_per_wave, PushArgs PA)
 {
-    long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        double xj = x[i], yj = y[i], zj = z[i];
-        double rj = sqrt(xj * xj + yj * yj);
-        double cs, sn;
-        if (rj != 0.) { double invr = 1. / rj; cs = xj * invr; sn = yj * invr; }
-        else { cs = 1.; sn = 0.; }
-        double r_cell = invdr * (rj - rmin) - 0.5;
-        double z_cell = invdz * (zj - zmin) - 0.5;
-        double F[6] = {0., 0., 0., 0., 0., 0.};   // Er,Et,Ez,Br,Bt,Bz summed over modes
-        if (rj < rmax_gather) {
+    constexpr int S = GShape<SHAPE>::S, OFF = GShape<SHAPE>::OFF;
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int NV = S * S * 6 * Nm;                 // complex node values of one segment
+    const int PSTR = 2 * NV + 2;                   // panel stride in doubles (16-B pad)
+    double *panel = lds + (size_t)wave * ((size_t)maxseg * PSTR + 2 * 8);
+    int *segkz = (int *)(panel + (size_t)maxseg * PSTR);
+    int *segkr = segkz + 8;
+
+    const long chunk0 = ((long)blockIdx.x * nwaves + wave) * chunks_per_wave;
+    // software pipeline: the particle coordinates of chunk ch+1 are requested before the
+    // work on chunk ch starts, so their HBM latency hides behind staging + stencil math
+    double xn = 0., yn = 0., zn = 0.;
+    if (chunk0 * 64 + lane < n) { xn = x[chunk0 * 64 + lane]; yn = y[chunk0 * 64 + lane]; zn = z[chunk0 * 64 + lane]; }
+    for (int ch = 0; ch < chunks_per_wave; ch++) {
+        const long base = (chunk0 + ch) * 64;
+        if (base >= n) break;
+        const long i = base + lane;
+        const bool act = i < n;
+        double cs = 1., sn = 0., Sz[S], Sr[S];
+        int kz = G_NOKEY, kr = G_NOKEY;
+        bool inside = false;
+        const double xj = xn, yj = yn, zj = zn;
+        if (ch + 1 < chunks_per_wave && i + 64 < n) { xn = x[i + 64]; yn = y[i + 64]; zn = z[i + 64]; }
+        double pux = 0., puy = 0., puz = 0., pig = 0.;
+        if (PA.ux && act) { pux = PA.ux[i]; puy = PA.uy[i]; puz = PA.uz[i]; pig = PA.ig[i]; }
+        if (act) {
+            const double rj = sqrt(xj * xj + yj * yj);
+            if (rj != 0.) { double invr = 1. / rj; cs = xj * invr; sn = yj * invr; }
+            const double r_cell = invdr * (rj - rmin) - 0.5;
+            const double z_cell = invdz * (zj - zmin) - 0.5;
+            inside = rj < rmax_gather;
+            kr = (int)floor(r_cell) - OFF;
+            kz = (int)floor(z_cell) - OFF;
             if constexpr (SHAPE == FB_SHAPE_LINEAR) {
-                int irl = (int)floor(r_cell), iru = irl + 1;
-                int izl = (int)floor(z_cell), izu = izl + 1;
-                double Srl = iru - r_cell, Sru = r_cell - irl;
-                double Szl = izu - z_cell, Szu = z_cell - izl;
-                double Srg = 0.;
-                if (irl < 0) { Srg = Srl; Srl = 0.; irl = 0; }
-                if (irl > Nr - 1) irl = Nr - 1;
-                if (iru > Nr - 1) iru = Nr - 1;
-                if (izl < 0) izl += Nz;
-                if (izu < 0) izu += Nz;
-                if (izl > Nz - 1) izl -= Nz;
-                if (izu > Nz - 1) izu -= Nz;
-                const double S_ll = Szl * Srl, S_lu = Szl * Sru, S_ul = Szu * Srl,
-                             S_uu = Szu * Sru, S_lg = Szl * Srg, S_ug = Szu * Srg;
-                const bool guard = (irl == 0 && iru == 0);
-                const long o_ll = (long)izl * rs + irl, o_lu = (long)izl * rs + iru,
-                           o_ul = (long)izu * rs + irl, o_uu = (long)izu * rs + iru,
-                           o_lg = (long)izl * rs, o_ug = (long)izu * rs;
-                double er = 1., ei = 0.;   // exptheta_m = (cos - i sin)^m
-                for (int m = 0; m < Nm; m++) {
-                    const double flip = m1pow(m);
-                    const double factor = (m == 0) ? 1. : 2.;
-#pragma unroll
-                    for (int k = 0; k < 6; k++) {
-                        const cplx *g = G.g[6 * m + k];
-                        double2 a = ldc(g + o_ll), b = ldc(g + o_lu), cc = ldc(g + o_ul),
-                                d = ldc(g + o_uu);
-                        double fr = 0., fi = 0.;
-                        fr += S_ll * a.x; fi += S_ll * a.y;
-                        fr += S_lu * b.x; fi += S_lu * b.y;
-                        fr += S_ul * cc.x; fi += S_ul * cc.y;
-                        fr += S_uu * d.x; fi += S_uu * d.y;
-                        if (guard) {
-                            // r,t components: -(-1)^m ; z component: +(-1)^m
-                            const double sg = (k % 3 == 2) ? flip : -flip;
-                            double2 gl = ldc(g + o_lg), gu = ldc(g + o_ug);
-                            fr += sg * S_lg * gl.x; fi += sg * S_lg * gl.y;
-                            fr += sg * S_ug * gu.x; fi += sg * S_ug * gu.y;
-                        }
-                        F[k] += factor * (fr * er - fi * ei);
-                    }
-                    // next mode: (er + i ei) *= (cos - i sin)
-                    double nr_ = er * cs - ei * (-sn);
-                    double ni_ = er * (-sn) + ei * cs;
-                    er = nr_; ei = ni_;
-                }
+                // threading_methods.py:108-117
+                Sr[0] = (kr + 1) - r_cell; Sr[1] = r_cell - kr;
+                Sz[0] = (kz + 1) - z_cell; Sz[1] = z_cell - kz;
             } else {
-                double Sr[4], Sz[4];
-                const long ir_lowest = (long)floor(r_cell) - 1;
-                const long iz_lowest = (long)floor(z_cell) - 1;
-                {
-                    double l = r_cell - ir_lowest;
-                    double a = l - 2., b = l - 1., cc = 2. - l, d = 1. - l;
-                    Sr[0] = -1. / 6. * (a * (a * a));
-                    Sr[1] = 1. / 6. * (3. * (b * (b * b)) - 6. * (b * b) + 4.);
-                    Sr[2] = 1. / 6. * (3. * (cc * (cc * cc)) - 6. * (cc * cc) + 4.);
-                    Sr[3] = -1. / 6. * (d * (d * d));
-                    l = z_cell - iz_lowest;
-                    a = l - 2.; b = l - 1.; cc = 2. - l; d = 1. - l;
-                    Sz[0] = -1. / 6. * (a * (a * a));
-                    Sz[1] = 1. / 6. * (3. * (b * (b * b)) - 6. * (b * b) + 4.);
-                    Sz[2] = 1. / 6. * (3. * (cc * (cc * cc)) - 6. * (cc * cc) + 4.);
-                    Sz[3] = -1. / 6. * (d * (d * d));
-                }
-                long irs[4], izs[4];
-                bool below[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    long ir = ir_lowest + j;
-                    below[j] = ir < 0;
-                    if (ir < 0) ir = -ir - 1;
-                    else if (ir > Nr - 1) ir = Nr - 1;
-                    irs[j] = ir;
-                    long iz = iz_lowest + j;
-                    if (iz < 0) iz += Nz;
-                    else if (iz > Nz - 1) iz -= Nz;
-                    izs[j] = iz * rs;
-                }
-                double er = 1., ei = 0.;
-                for (int m = 0; m < Nm; m++) {
+                // threading_methods.py:312-321
+                double l = r_cell - kr;
+                double a = l - 2., b = l - 1., cc = 2. - l, d = 1. - l;
+                Sr[0] = -1. / 6. * (a * (a * a));
+                Sr[1] = 1. / 6. * (3. * (b * (b * b)) - 6. * (b * b) + 4.);
+                Sr[2] = 1. / 6. * (3. * (cc * (cc * cc)) - 6. * (cc * cc) + 4.);
+                Sr[3] = -1. / 6. * (d * (d * d));
+                l = z_cell - kz;
+                a = l - 2.; b = l - 1.; cc = 2. - l; d = 1. - l;
+                Sz[0] = -1. / 6. * (a * (a * a));
+                Sz[1] = 1. / 6. * (3. * (b * (b * b)) - 6. * (b * b) + 4.);
+                Sz[2] = 1. / 6. * (3. * (cc * (cc * cc)) - 6. * (cc * cc) + 4.);
+                Sz[3] = -1. / 6. * (d * (d * d));
+            }
+            if (!inside) { kz = G_NOKEY; kr = G_NOKEY; }   // gathers nothing: no segment
+        }
+        // segments = runs of equal stencil origin among the lanes that gather
+        const int pkz = __shfl_up(kz, 1), pkr = __shfl_up(kr, 1);
+        const bool is_start = inside && (lane == 0 || kz != pkz || kr != pkr);
+        const unsigned long long starts = __ballot(is_start);
+        const int nseg = __popcll(starts);
+        const int myseg = __popcll(starts & ((2ull << lane) - 1ull)) - 1;   // valid if inside
+        double F[6] = {0., 0., 0., 0., 0., 0.};
+        for (int s0 = 0; s0 < nseg; s0 += maxseg) {
+            const int ns = min(maxseg, nseg - s0);
+            // publish the keys of this round's segments
+            if (is_start && myseg >= s0 && myseg < s0 + ns) {
+                segkz[myseg - s0] = kz;
+                segkr[myseg - s0] = kr;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // stage node values: lane = (segment, field, jz, jr)
+            for (int sg = 0; sg < ns; sg++)
+            for (int o = lane; o < NV; o += 64) {
+                const int jr = o % S, jz = (o / S) % S, f = o / (S * S);
+                int row = segkz[sg] + jz, col = segkr[sg] + jr;
+                if (row < 0) row += Nz; else if (row > Nz - 1) row -= Nz;
+                double sgn = 1.;
+                if (col < 0) {
+                    // mirror below the axis: -(-1)^m for r,t components, +(-1)^m for z
+                    // (inline_functions.py:70-79, 151-158)
+                    col = -col - 1;
+                    const int m = f / 6, k = f - 6 * m;
                     const double flip = m1pow(m);
+                    sgn = (k % 3 == 2) ? flip : -flip;
+                } else if (col > Nr - 1) col = Nr - 1;
+                double2 v = ldc(G.g[f] + (long)row * rs + col);
+                v.x *= sgn; v.y *= sgn;
+                *(double2 *)(panel + (size_t)sg * PSTR + 2 * o) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (inside && myseg >= s0 && myseg < s0 + ns) {
+                const double *P = panel + (size_t)(myseg - s0) * PSTR;
+                double er = 1., ei = 0.;            // exptheta_m = (cos - i sin)^m
+                for (int m = 0; m < Nm; m++) {
                     const double factor = (m == 0) ? 1. : 2.;
 #pragma unroll
                     for (int k = 0; k < 6; k++) {
-                        const cplx *g = G.g[6 * m + k];
-                        const double sg = (k % 3 == 2) ? flip : -flip;
+                        const double *Pf = P + 2 * (m * 6 + k) * S * S;
                         double fr = 0., fi = 0.;
+                        if constexpr (SHAPE == FB_SHAPE_LINEAR) {
 #pragma unroll
-                        for (int jr = 0; jr < 4; jr++) {
-                            double sr = Sr[jr];
-                            if (below[jr]) sr *= sg;
+                            for (int jz = 0; jz < S; jz++)
 #pragma unroll
-                            for (int jz = 0; jz < 4; jz++) {
-                                double2 v = ldc(g + izs[jz] + irs[jr]);
-                                double s = Sz[jz] * sr;
-                                fr += s * v.x; fi += s * v.y;
-                            }
+                                for (int jr = 0; jr < S; jr++) {
+                                    const double2 v = *(const double2 *)(Pf + 2 * (jz * S + jr));
+                                    const double w_ = Sz[jz] * Sr[jr];
+                                    fr = __builtin_fma(w_, v.x, fr); fi = __builtin_fma(w_, v.y, fi);
+                                }
+                        } else {
+#pragma unroll
+                            for (int jr = 0; jr < S; jr++)
+#pragma unroll
+                                for (int jz = 0; jz < S; jz++) {
+                                    const double2 v = *(const double2 *)(Pf + 2 * (jz * S + jr));
+                                    const double w_ = Sz[jz] * Sr[jr];
+                                    fr = __builtin_fma(w_, v.x, fr); fi = __builtin_fma(w_, v.y, fi);
+                                }
                         }
                         F[k] += factor * (fr * er - fi * ei);
                     }
-                    double nr_ = er * cs - ei * (-sn);
-                    double ni_ = er * (-sn) + ei * cs;
+                    const double nr_ = er * cs - ei * (-sn);
+                    const double ni_ = er * (-sn) + ei * cs;
                     er = nr_; ei = ni_;
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        Ex[i] = cs * F[0] - sn * F[1];
-        Ey[i] = sn * F[0] + cs * F[1];
-        Ez[i] = F[2];
-        Bx[i] = cs * F[3] - sn * F[4];
-        By[i] = sn * F[3] + cs * F[4];
-        Bz[i] = F[5];
+        if (act) {
+            const double ex = cs * F[0] - sn * F[1], ey = sn * F[0] + cs * F[1], ez = F[2];
+            const double bx = cs * F[3] - sn * F[4], by = sn * F[3] + cs * F[4], bz = F[5];
+            if (Ex) { Ex[i] = ex; Ey[i] = ey; Ez[i] = ez; Bx[i] = bx; By[i] = by; Bz[i] = bz; }
+            if (PA.ux) {
+                vay(pux, puy, puz, pig, ex, ey, ez, bx, by, bz, PA.econst, PA.bconst);
+                PA.ux[i] = pux; PA.uy[i] = puy; PA.uz[i] = puz; PA.ig[i] = pig;
+                if (PA.chdt != 0.) {
+                    // numba_methods.py:28-30 with push_x = push_y = push_z = 1
+                    PA.x[i] = xj + PA.chdt * pig * 1. * pux;
+                    PA.y[i] = yj + PA.chdt * pig * 1. * puy;
+                    PA.z[i] = zj + PA.chdt * pig * 1. * puz;
+                }
+            }
+        }
     }
 }
 
@@ -306,26 +356,74 @@ extern "C" int fb_shift_periodic(long n, double *z, double zmin, double zmax, vo
     FB_CHECK_LAUNCH("fb_shift_periodic");
 }
 
+static int launch_gather(int shape, int Nm, long n, const double *x, const double *y,
+        const double *z, double rmax_gather, double invdz, double zmin, int Nz, double invdr,
+        double rmin, int Nr, const void *const *grids, long row_stride,
+        double *Ex, double *Ey, double *Ez, double *Bx, double *By, double *Bz,
+        const PushArgs &PA, hipStream_t s, const char *where)
+{
+    if (n <= 0) return 0;
+    if (Nm < 1 || Nm > FB_MAX_MODES) { set_error(where, "Nm out of range"); return -1; }
+    if (shape != FB_SHAPE_LINEAR && shape != FB_SHAPE_CUBIC) {
+        set_error(where, "unknown shape");
+        return -1;
+    }
+    GatherGrids G;
+    for (int i = 0; i < 6 * Nm; i++) G.g[i] = (const cplx *)grids[i];
+    for (int i = 6 * Nm; i < 6 * FB_MAX_MODES; i++) G.g[i] = nullptr;
+    const int S = (shape == FB_SHAPE_LINEAR) ? 2 : 4;
+    const size_t panel_bytes = (size_t)(2 * S * S * 6 * Nm + 2) * 8;
+    // segments staged per round: up to 8, within ~16 KiB of LDS per wave
+    int maxseg = (int)((16 * 1024) / panel_bytes);
+    if (maxseg > 8) maxseg = 8;
+    if (maxseg < 1) maxseg = 1;
+    const size_t wave_bytes = maxseg * panel_bytes + 2 * 8 * 8;
+    int nwaves = 4;
+    while (nwaves > 1 && wave_bytes * nwaves > 64 * 1024) nwaves >>= 1;
+    const long nchunks = (n + 63) / 64;
+    // several rounds of waves (small tail), each long enough to pipeline its loads
+    const long target_waves = 256L * 64;
+    int cpw = (int)((nchunks + target_waves - 1) / target_waves);
+    if (cpw < 1) cpw = 1;
+    if (cpw > 64) cpw = 64;
+    const long total_waves = (nchunks + cpw - 1) / cpw;
+    dim3 grid((unsigned)((total_waves + nwaves - 1) / nwaves)), block(64 * nwaves);
+    if (shape == FB_SHAPE_LINEAR)
+        hipLaunchKernelGGL(k_gather<FB_SHAPE_LINEAR>, grid, block, wave_bytes * nwaves, s, Nm, n,
+                           x, y, z, rmax_gather, invdz, zmin, Nz, invdr, rmin, Nr, G, row_stride,
+                           Ex, Ey, Ez, Bx, By, Bz, maxseg, cpw, PA);
+    else
+        hipLaunchKernelGGL(k_gather<FB_SHAPE_CUBIC>, grid, block, wave_bytes * nwaves, s, Nm, n,
+                           x, y, z, rmax_gather, invdz, zmin, Nz, invdr, rmin, Nr, G, row_stride,
+                           Ex, Ey, Ez, Bx, By, Bz, maxseg, cpw, PA);
+    return check(hipGetLastError(), where);
+}
+
 extern "C" int fb_gather(int shape, int Nm, long n, const double *x, const double *y,
         const double *z, double rmax_gather, double invdz, double zmin, int Nz, double invdr,
         double rmin, int Nr, const void *const *grids, long row_stride,
         double *Ex, double *Ey, double *Ez, double *Bx, double *By, double *Bz, void *stream)
 {
-    if (n <= 0) return 0;
-    if (Nm < 1 || Nm > FB_MAX_MODES) { set_error("fb_gather", "Nm out of range"); return -1; }
-    GatherGrids G;
-    for (int i = 0; i < 6 * Nm; i++) G.g[i] = (const cplx *)grids[i];
-    for (int i = 6 * Nm; i < 6 * FB_MAX_MODES; i++) G.g[i] = nullptr;
-    hipStream_t s = (hipStream_t)stream;
-    dim3 grid(stream_grid(n, 256, 256 * 16)), block(256);
-    if (shape == FB_SHAPE_LINEAR)
-        hipLaunchKernelGGL(k_gather<FB_SHAPE_LINEAR>, grid, block, 0, s, Nm, n, x, y, z,
-                           rmax_gather, invdz, zmin, Nz, invdr, rmin, Nr, G, row_stride,
-                           Ex, Ey, Ez, Bx, By, Bz);
-    else if (shape == FB_SHAPE_CUBIC)
-        hipLaunchKernelGGL(k_gather<FB_SHAPE_CUBIC>, grid, block, 0, s, Nm, n, x, y, z,
-                           rmax_gather, invdz, zmin, Nz, invdr, rmin, Nr, G, row_stride,
-                           Ex, Ey, Ez, Bx, By, Bz);
-    else { set_error("fb_gather", "unknown shape"); return -1; }
-    FB_CHECK_LAUNCH("fb_gather");
+    PushArgs PA = {};
+    return launch_gather(shape, Nm, n, x, y, z, rmax_gather, invdz, zmin, Nz, invdr, rmin, Nr,
+                         grids, row_stride, Ex, Ey, Ez, Bx, By, Bz, PA, (hipStream_t)stream,
+                         "fb_gather");
+}
+
+extern "C" int fb_gather_push(int shape, int Nm, long n, double *x, double *y, double *z,
+        double *ux, double *uy, double *uz, double *inv_gamma,
+        double rmax_gather, double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
+        const void *const *grids, long row_stride,
+        double *Ex, double *Ey, double *Ez, double *Bx, double *By, double *Bz,
+        double q, double m, double c, double dt, double dt_x, void *stream)
+{
+    PushArgs PA;
+    PA.x = x; PA.y = y; PA.z = z;
+    PA.ux = ux; PA.uy = uy; PA.uz = uz; PA.ig = inv_gamma;
+    PA.econst = q * dt / (m * c);
+    PA.bconst = 0.5 * q * dt / m;
+    PA.chdt = c * dt_x;
+    return launch_gather(shape, Nm, n, x, y, z, rmax_gather, invdz, zmin, Nz, invdr, rmin, Nr,
+                         grids, row_stride, Ex, Ey, Ez, Bx, By, Bz, PA, (hipStream_t)stream,
+                         "fb_gather_push");
 }

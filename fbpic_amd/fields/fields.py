@@ -167,6 +167,8 @@ class Fields(object):
     def _group(self, fieldtype):
         """(interp first field, spect first field, n fields, is_vector)."""
         Nm = self.Nm
+        if fieldtype == 'EB':       # E and B are adjacent in both slabs: one batched transform
+            return 0, 0, 6 * Nm, True
         if fieldtype in _VEC:
             f0 = 3 * Nm * _VEC[fieldtype]
             return f0, f0, 3 * Nm, True
@@ -176,9 +178,13 @@ class Fields(object):
             raise NotImplementedError('%s is outside the fbpic_amd scope' % fieldtype)
         raise ValueError('Invalid string for fieldtype: %s' % fieldtype)
 
-    def interp2spect(self, fieldtype):
+    def interp2spect(self, fieldtype, fuse_divide_by_volume=False, fuse_filter=False):
         """FFT(z) then DHT(r) of one field group, all modes at once
-        (reference: fields.py:313-368 + spectral_transformer.py:157-223)."""
+        (reference: fields.py:313-368 + spectral_transformer.py:157-223).
+        `fieldtype` may also be 'EB' (E and B in one batch).  The two optional flags fold
+        the divide-by-volume pass (it commutes with the z-FFT) and the spectral filter pass
+        into the Hankel GEMM (fb_hankel_scaled) instead of two extra sweeps over the grids;
+        with `fuse_divide_by_volume` the interpolation-grid arrays are left un-normalised."""
         self._need_gpu()
         fi, fs, nf, vec = self._group(fieldtype)
         Nz, Nr = self.Nz, self.Nr
@@ -190,12 +196,24 @@ class Fields(object):
         if vec:
             r = pa(scr_f[0::3])
             t = pa(scr_f[1::3])
-            _capi.check(lib.fb_rt_to_pm(self.Nm, r, t, r, t, self.NFx * Nr, Nz, Nr, st),
+            _capi.check(lib.fb_rt_to_pm(nf // 3, r, t, r, t, self.NFx * Nr, Nz, Nr, st),
                         'fb_rt_to_pm')
         out = self._field_views(self.d_spect, fs, nf)
         mats = self._mats['vec_fwd' if vec else 'scal_fwd']
-        _capi.check(lib.fb_hankel(nf, pa(scr_f), self.NFx * Nr, pa(out), self.NFs * Nr,
-                                  pa(mats), 1.0, Nz, Nr, st), 'fb_hankel')
+        if fieldtype == 'EB':
+            mats = mats + mats
+        if fuse_divide_by_volume or fuse_filter:
+            per = 3 if vec else 1
+            mode_of = [(j // per) % self.Nm for j in range(nf)]
+            sk = [self.interp[m].d_invvol if fuse_divide_by_volume else None for m in mode_of]
+            fz = [self.spect[m].d_filter_array_z if fuse_filter else None for m in mode_of]
+            fr = [self.spect[m].d_filter_array_r if fuse_filter else None for m in mode_of]
+            _capi.check(lib.fb_hankel_scaled(nf, pa(scr_f), self.NFx * Nr, pa(out), self.NFs * Nr,
+                                             pa(mats), pa(sk), pa(fz), pa(fr), 1.0, Nz, Nr, st),
+                        'fb_hankel_scaled')
+        else:
+            _capi.check(lib.fb_hankel(nf, pa(scr_f), self.NFx * Nr, pa(out), self.NFs * Nr,
+                                      pa(mats), 1.0, Nz, Nr, st), 'fb_hankel')
 
     def spect2interp(self, fieldtype):
         """inverse DHT(r) then inverse FFT(z) (reference: fields.py:370-429)."""
@@ -206,12 +224,14 @@ class Fields(object):
         inp = self._field_views(self.d_spect, fs, nf)
         scr_f = self._field_views(self.d_scratch, 0, nf)
         mats = self._mats['vec_inv' if vec else 'scal_inv']
+        if fieldtype == 'EB':
+            mats = mats + mats
         _capi.check(lib.fb_hankel(nf, pa(inp), self.NFs * Nr, pa(scr_f), self.NFx * Nr,
                                   pa(mats), 1.0, Nz, Nr, st), 'fb_hankel')
         if vec:
             p = pa(scr_f[0::3])
             mm = pa(scr_f[1::3])
-            _capi.check(lib.fb_pm_to_rt(self.Nm, p, mm, p, mm, self.NFx * Nr, Nz, Nr, st),
+            _capi.check(lib.fb_pm_to_rt(nf // 3, p, mm, p, mm, self.NFx * Nr, Nz, Nr, st),
                         'fb_pm_to_rt')
         fft_exec(self.d_scratch[:, 0, :], self.d_interp[:, fi, :], +1, ncols=nf * Nr)
 
@@ -239,6 +259,24 @@ class Fields(object):
         for m in range(self.Nm):
             self.spect[m].push_eb_with(self.psatd[m], use_true_rho)
             self.spect[m].push_rho()
+
+    def psatd_step(self, correct_currents=True, use_true_rho=False):
+        """correct_currents() + push() for all modes in ONE launch (the three updates are
+        cell-local).  Used by Simulation.step on a single domain, where no guard-cell
+        exchange of J separates the correction from the push (main.py:530-542)."""
+        self._need_gpu()
+        from scipy.constants import c, epsilon_0, mu_0
+        fields, tables = [], []
+        for m in range(self.Nm):
+            sp, tb = self.spect[m], self.psatd[m].device_tables()
+            fields += [getattr(sp, k) for k in SPECT_FIELDS]
+            tables += [tb['rho_prev_coef'], tb['rho_next_coef'], tb['j_coef'], tb['C'], tb['S_w'],
+                       sp.d_kr, sp.d_kz, sp.d_inv_k2]
+        rc = _capi.lib().fb_psatd_step_standard(
+            self.Nm, _capi.ptr_array(fields), self.NFs * self.Nr, _capi.ptr_array(tables),
+            self.dt, int(bool(correct_currents)), int(bool(use_true_rho)), c, epsilon_0, mu_0,
+            self.Nz, self.Nr, _capi.stream())
+        _capi.check(rc, 'fb_psatd_step_standard')
 
     def correct_currents(self, check_exchanges=False):
         self._need_gpu()

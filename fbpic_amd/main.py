@@ -113,6 +113,9 @@ class Simulation(object):
         # already is that charge density up to rounding.  The re-deposit is skipped after
         # the first iteration of a step() call unless this flag is set.
         self.redeposit_rho_prev_every_step = False
+        self._in_step = False
+        # gather + push_p + push_x(dt/2) in one kernel when no hook sits between them
+        self.fuse_gather_push = True
 
     # -------------------------------------------------------------------- PIC cycle
     def step(self, N=1, correct_currents=True, correct_divE=False, use_true_rho=False,
@@ -126,12 +129,21 @@ class Simulation(object):
                              '`correct_currents` in multi-proc mode.')
         was_on_gpu = fld.data_is_on_gpu and all(s.data_is_on_gpu for s in ptcl)
         send_data_to_gpu(self)
+        self._in_step = True
+        try:
+            self._step_loop(N, correct_currents, use_true_rho, move_positions, move_momenta)
+        finally:
+            self._in_step = False
+        if not was_on_gpu:
+            receive_data_from_gpu(self)
+
+    def _step_loop(self, N, correct_currents, use_true_rho, move_positions, move_momenta):
+        ptcl, fld, dt = self.ptcl, self.fld, self.dt
         # E and B go to spectral space once; afterwards only spectral -> interp
         self.comm.exchange_fields(fld.interp, 'E', 'replace')
         self.comm.exchange_fields(fld.interp, 'B', 'replace')
         self.comm.damp_EB_open_boundary(fld.interp)
-        fld.interp2spect('E')
-        fld.interp2spect('B')
+        fld.interp2spect('EB')
         for i_step in range(N):
             if self.iteration % self.comm.exchange_period == 0 or i_step == 0:
                 for species in ptcl:
@@ -143,18 +155,25 @@ class Simulation(object):
                 self.deposit('J', exchange=True)
             for species in ptcl:
                 species.keep_fields_sorted = True
-            for species in ptcl:
-                species.gather(fld.interp, self.comm)
-            for ext_field in self.external_fields:
-                ext_field.apply_expression(ptcl, self.time)
-            for diag in self.diags:
-                diag.write(self.iteration)
-            if move_momenta:
+            if (self.fuse_gather_push and move_momenta and move_positions
+                    and not self.external_fields and not self.diags):
+                # nothing observes the particles between gather and the half position push:
+                # one pass instead of three (gather, push_p, push_x)
                 for species in ptcl:
-                    species.push_p(self.time + 0.5 * dt)
-            if move_positions:
+                    species.gather_push(fld.interp, self.comm, 0.5 * dt)
+            else:
                 for species in ptcl:
-                    species.push_x(0.5 * dt)
+                    species.gather(fld.interp, self.comm)
+                for ext_field in self.external_fields:
+                    ext_field.apply_expression(ptcl, self.time)
+                for diag in self.diags:
+                    diag.write(self.iteration)
+                if move_momenta:
+                    for species in ptcl:
+                        species.push_p(self.time + 0.5 * dt)
+                if move_positions:
+                    for species in ptcl:
+                        species.push_x(0.5 * dt)
             for species in ptcl:
                 species.handle_elementary_processes(self.time + 0.5 * dt)
             for species in ptcl:
@@ -164,14 +183,19 @@ class Simulation(object):
                 for species in ptcl:
                     species.push_x(0.5 * dt)
             self.deposit('rho_next', exchange=(use_true_rho is True))
-            if correct_currents:
-                fld.correct_currents(check_exchanges=(self.comm.size > 1))
-                if self.comm.size > 1:
+            if self.comm.size == 1:
+                # single domain: correction, push and rho shift are cell-local -> one launch
+                fld.psatd_step(correct_currents, use_true_rho)
+                if correct_currents:
+                    fld.exchanged_source['J'] = True
+            else:
+                if correct_currents:
+                    fld.correct_currents(check_exchanges=True)
                     fld.spect2partial_interp('J')
                     self.comm.exchange_fields(fld.interp, 'J', 'add')
                     fld.partial_interp2spect('J')
-                fld.exchanged_source['J'] = True
-            fld.push(use_true_rho, check_exchanges=(self.comm.size > 1))
+                    fld.exchanged_source['J'] = True
+                fld.push(use_true_rho, check_exchanges=True)
             if self.comm.moving_win is not None:
                 self.comm.move_grids(fld, ptcl, dt, self.time)
             self.exchange_and_damp_EB()
@@ -185,8 +209,6 @@ class Simulation(object):
         fld.spect2interp('rho_prev')
         if (not fld.exchanged_source['rho_prev']) and (self.comm.size > 1):
             self.comm.exchange_fields(fld.interp, 'rho', 'add')
-        if not was_on_gpu:
-            receive_data_from_gpu(self)
 
     def deposit(self, fieldtype, exchange=False, update_spectral=True, species_list=None):
         """Deposit rho or J on the interpolation grid, then transform and filter
@@ -204,6 +226,14 @@ class Simulation(object):
         for species in species_list:
             species.deposit(fld, kind)
         fld.sum_reduce_deposition_array(kind)
+        if self._in_step and update_spectral and not (exchange and self.comm.size > 1):
+            # inside step(): divide-by-volume and filter ride along in the Hankel GEMM
+            # (the interpolation-grid J / rho are overwritten from spectral space before
+            # anything reads them, main.py:572-577)
+            fld.interp2spect(fieldtype, fuse_divide_by_volume=True,
+                             fuse_filter=self.filter_currents)
+            fld.exchanged_source[fieldtype] = exchange
+            return
         fld.divide_by_volume(kind)
         if exchange and self.comm.size > 1:
             self.comm.exchange_fields(fld.interp, kind, 'add')
@@ -230,8 +260,7 @@ class Simulation(object):
                 mirror.set_fields_to_zero(fld.interp, self.comm, self.time)
             fld.partial_interp2spect('E')
             fld.partial_interp2spect('B')
-        fld.spect2interp('E')
-        fld.spect2interp('B')
+        fld.spect2interp('EB')
 
     # -------------------------------------------------------------------- species
     def add_new_species(self, q, m, n=None, dens_func=None, p_nz=None, p_nr=None, p_nt=None,

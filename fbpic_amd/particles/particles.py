@@ -61,6 +61,20 @@ class Particles(object):
         # `deposit` sorts again.  0 restores the reference behaviour.
         self.sort_tolerance = 0.75
         self._moved_since_sort = np.inf
+        # Adaptive part of the policy: the J deposition reports how many runs of equal
+        # cells it met (read back asynchronously, one step late).  While the run count stays
+        # below `resort_fragmentation` x the count measured right after a sort, the sort is
+        # skipped even if the displacement bound is exceeded (slow plasmas), up to
+        # `max_deposits_between_sorts` deposits.  resort_fragmentation = 0 (default) always
+        # obeys the displacement bound: on MI355X the radix sort (~0.26 ms at 4.2 M particles)
+        # costs less than the fragmentation it removes from gather + both depositions after
+        # two steps even for a 0.01 c thermal plasma (measured, profiles/README.md).
+        self.resort_fragmentation = 0.
+        self.max_deposits_between_sorts = 16
+        self._runs_after_sort = None
+        self._runs_latest = None
+        self._deposits_since_sort = 0
+        self._stat_pending = None
         # device-only helpers (allocated in send_particles_to_gpu)
         self.cell_idx = None
         self.sorted_idx = None
@@ -86,6 +100,11 @@ class Particles(object):
         self.sorting_buffer = self._alt[0]
         nbytes = int(_capi.lib().fb_sort_workspace_bytes(n, ncell))
         self._sort_ws = t.empty(nbytes, dtype=t.uint8, device=dev)
+        self._nflush = t.zeros(1024, dtype=t.int64, device=dev)
+        self._nflush_host = t.zeros(1024, dtype=t.int64).pin_memory()
+        self._runs_after_sort = None
+        self._runs_latest = None
+        self._stat_pending = None
 
     def send_particles_to_gpu(self):
         if self.data_is_on_gpu:
@@ -168,6 +187,32 @@ class Particles(object):
                                    p(self.Bz), _capi.stream())
         _capi.check(rc, 'fb_gather')
 
+    def gather_push(self, grid, comm, dt_x, store_fields=True):
+        """gather -> push_p -> push_x(dt_x) in one pass (fb_gather_push): the fused form of
+        the three consecutive calls of Simulation.step (main.py:469-490).  Results are
+        identical to calling gather(), push_p(), push_x(dt_x) one after the other."""
+        self._need_gpu()
+        if self.q == 0:
+            self.push_x(dt_x)
+            return
+        Nm = len(grid)
+        g0 = grid[0]
+        views = []
+        for m in range(Nm):
+            views += [grid[m].Er, grid[m].Et, grid[m].Ez, grid[m].Br, grid[m].Bt, grid[m].Bz]
+        p = _capi.ptr
+        eb = [p(getattr(self, k)) if store_fields else None for k in _FIELDS]
+        rc = _capi.lib().fb_gather_push(
+            _SHAPE[self.particle_shape], Nm, self.Ntot, p(self.x), p(self.y), p(self.z),
+            p(self.ux), p(self.uy), p(self.uz), p(self.inv_gamma),
+            comm.get_rmax(with_damp=False), g0.invdz, g0.zmin, g0.Nz, g0.invdr, g0.rmin, g0.Nr,
+            _capi.ptr_array(views), _capi.row_stride(views[0]), *eb,
+            self.q, self.m, c, self.dt, dt_x, _capi.stream())
+        _capi.check(rc, 'fb_gather_push')
+        self.sorted = False
+        dmin = min(self._cell_size) if self._cell_size else 0.
+        self._moved_since_sort += (c * abs(dt_x) / dmin if dmin > 0 else np.inf)
+
     # ---------------------------------------------------------------- sort
     def sort_particles(self, fld):
         """Cell index -> stable radix sort -> per-cell prefix sum -> permutation
@@ -210,6 +255,42 @@ class Particles(object):
             self._alt[i] = src[i]
         self.sorting_buffer = self._alt[0]
 
+    # ---------------------------------------------------------------- sort policy
+    def _poll_stats(self):
+        """Pick up the run count of an earlier J deposition if its copy has landed."""
+        if self._stat_pending is not None:
+            ev, was_fresh = self._stat_pending
+            if ev.query():
+                runs = int(self._nflush_host.sum())
+                if was_fresh:
+                    self._runs_after_sort = runs
+                self._runs_latest = runs
+                self._stat_pending = None
+
+    def _needs_sort(self):
+        if self._moved_since_sort <= self.sort_tolerance:
+            return False
+        if not (self.resort_fragmentation > 0) or self._moved_since_sort == np.inf:
+            return True
+        if self._deposits_since_sort >= self.max_deposits_between_sorts:
+            return True
+        self._poll_stats()
+        if self._runs_after_sort is None or self._runs_latest is None:
+            return True          # no measurement yet: obey the displacement bound
+        return self._runs_latest > self.resort_fragmentation * self._runs_after_sort
+
+    def _post_deposit_stats(self):
+        """Asynchronous read-back of the run counter written by fb_deposit_J."""
+        self._poll_stats()
+        if self._stat_pending is None:
+            t = _capi.torch()
+            self._nflush_host.copy_(self._nflush, non_blocking=True)
+            ev = t.cuda.Event()
+            ev.record()
+            self._stat_pending = (ev, self._deposits_since_sort == 0)
+        self._nflush.zero_()
+        self._deposits_since_sort += 1
+
     # ---------------------------------------------------------------- deposit
     def deposit(self, fld, fieldtype):
         """Deposit rho or J of this species on the interpolation grid (reference :839-1046)."""
@@ -217,10 +298,11 @@ class Particles(object):
             return
         assert fieldtype in ['rho', 'J']
         self._need_gpu()
-        if not self.sorted:
-            if self._moved_since_sort > self.sort_tolerance:
-                self.sort_particles(fld=fld)
-                self.sorted = True
+        if not self.sorted and self._needs_sort():
+            self.sort_particles(fld=fld)
+            self.sorted = True
+            self._deposits_since_sort = 0
+            self._runs_latest = None
         grid = fld.interp
         Nm = len(grid)
         g0 = grid[0]
@@ -230,13 +312,14 @@ class Particles(object):
         ruyh = getattr(grid[1 if Nm > 1 else 0], 'd_ruyten_%s_coef' % suffix)
         lib = _capi.lib()
         p = _capi.ptr
+        adaptive = self.resort_fragmentation > 0
         if fieldtype == 'rho':
             views = [grid[m].rho for m in range(Nm)]
             rc = lib.fb_deposit_rho(_SHAPE[self.particle_shape], Nm, self.Ntot, p(self.x),
                                     p(self.y), p(self.z), p(weight), self.q, g0.invdz, g0.zmin,
                                     g0.Nz, g0.invdr, g0.rmin, g0.Nr, _capi.ptr_array(views),
                                     _capi.row_stride(views[0]), p(self.prefix_sum), p(ruy0),
-                                    p(ruyh), _capi.stream())
+                                    p(ruyh), None, _capi.stream())
             _capi.check(rc, 'fb_deposit_rho')
         else:
             views = []
@@ -247,5 +330,7 @@ class Particles(object):
                                   p(self.inv_gamma), c, g0.invdz, g0.zmin, g0.Nz, g0.invdr,
                                   g0.rmin, g0.Nr, _capi.ptr_array(views),
                                   _capi.row_stride(views[0]), p(self.prefix_sum), p(ruy0), p(ruyh),
-                                  _capi.stream())
+                                  p(self._nflush) if adaptive else None, _capi.stream())
             _capi.check(rc, 'fb_deposit_J')
+            if adaptive:
+                self._post_deposit_stats()

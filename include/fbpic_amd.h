@@ -68,6 +68,20 @@ int fb_gather(int shape, int Nm, long n,
               double *Ex, double *Ey, double *Ez, double *Bx, double *By, double *Bz,
               void *stream);
 
+/* Fusion of three consecutive launch sites of the PIC cycle (main.py:469-490):
+ * gather (above) -> push_p (particles.py:609-613) -> push_x(dt_x) (particles.py:660-663)
+ * in one pass over the particles: E,B stay in registers, the momenta are read and written
+ * once.  Same arithmetic as the three separate entry points (bit-identical momenta and
+ * positions for identical fields).  Ex..Bz may be NULL (fields not stored); dt_x = 0 skips
+ * the position push. */
+int fb_gather_push(int shape, int Nm, long n, double *x, double *y, double *z,
+                   double *ux, double *uy, double *uz, double *inv_gamma,
+                   double rmax_gather, double invdz, double zmin, int Nz,
+                   double invdr, double rmin, int Nr,
+                   const void *const *grids, long row_stride,
+                   double *Ex, double *Ey, double *Ez, double *Bx, double *By, double *Bz,
+                   double q, double m, double c, double dt, double dt_x, void *stream);
+
 /* ---- cell sort ---------------------------------------------------------------- */
 /* particles/particles.py:1075-1081 -> get_cell_idx_per_particle
  * (utilities/cuda_sorting.py:21-88): cell_idx = ir_upper + iz_upper*(Nr+1);
@@ -101,13 +115,16 @@ int fb_permute(long n, const int *sorted_idx, int nattr,
  * does not depend on the order.  prefix_sum is accepted for signature compatibility with
  * the reference launch and is not read (may be NULL).
  * rho: HOST array of Nm device pointers.
- * ruyten_m0 / ruyten_mh: Ruyten coefficients (Nr+1) for mode 0 / modes >= 1. */
+ * ruyten_m0 / ruyten_mh: Ruyten coefficients (Nr+1) for mode 0 / modes >= 1.
+ * nflush (device uint64[1024], may be NULL): the counters are incremented so that their
+ * SUM grows by the number of runs of equal cells met in the particle stream -- n/sum is the
+ * mean run length, the host's measure of how stale the cell sort has become. */
 int fb_deposit_rho(int shape, int Nm, long n,
                    const double *x, const double *y, const double *z, const double *w, double q,
                    double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
                    void *const *rho, long row_stride,
                    const int *prefix_sum, const double *ruyten_m0, const double *ruyten_mh,
-                   void *stream);
+                   unsigned long long *nflush, void *stream);
 
 /* particles/particles.py:937-985 -> deposit_J_gpu_{linear,cubic}[_one_mode]
  * (deposition/cuda_methods.py:201,750).  J: HOST array of 3*Nm device pointers,
@@ -119,7 +136,7 @@ int fb_deposit_J(int shape, int Nm, long n,
                  double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
                  void *const *J, long row_stride,
                  const int *prefix_sum, const double *ruyten_m0, const double *ruyten_mh,
-                 void *stream);
+                 unsigned long long *nflush, void *stream);
 
 /* ---- interpolation-grid kernels ------------------------------------------------ */
 /* fields/interpolation_grid.py:236-250 -> cuda_erase_scalar/vector (fields/cuda_methods.py:18,40).
@@ -148,6 +165,15 @@ int fb_push_eb_standard(void *Ep, void *Em, void *Ez, void *Bp, void *Bm, void *
         const double *C, const double *S_w, const double *kr, const double *kz,
         double dt, int use_true_rho, double c, double epsilon_0, double mu_0,
         int Nz, int Nr, void *stream);
+/* Single-launch fusion of the three cell-local spectral updates for ALL modes:
+ * fields/spectral_grid.py:225-230 (curl-free correction, optional) -> :350-355 (PSATD push)
+ * -> :416-417 (rho shift).  fields: HOST array of 11*Nm device pointers, per mode in
+ * SpectralGrid order Ep,Em,Ez,Bp,Bm,Bz,Jp,Jm,Jz,rho_prev,rho_next; tables: HOST array of
+ * 8*Nm device pointers, per mode rho_prev_coef,rho_next_coef,j_coef,C,S_w,kr,kz,inv_k2
+ * (each real (Nz,Nr) contiguous).  Same results as the three separate entry points. */
+int fb_psatd_step_standard(int Nm, void *const *fields, long row_stride,
+        const double *const *tables, double dt, int correct_currents, int use_true_rho,
+        double c, double epsilon_0, double mu_0, int Nz, int Nr, void *stream);
 /* fields/spectral_grid.py:416-417 -> cuda_push_rho (:443) */
 int fb_push_rho(void *rho_prev, void *rho_next, long row_stride, int Nz, int Nr, void *stream);
 /* fields/spectral_transform/spectral_transformer.py:140-142, 208-210 ->
@@ -183,6 +209,17 @@ int fb_fft_plan_destroy(void *plan);
 int fb_hankel(int njobs, const void *const *in, long in_row_stride,
               void *const *out, long out_row_stride, const double *const *mat,
               double alpha, int Nz, int Nr, void *stream);
+/* Same transform with three optional per-job real scalings fused in (each table is a HOST
+ * array of njobs device pointers, or NULL; individual entries may be NULL):
+ *   in_col_scale[j][k]  : input column k is multiplied first -- the divide-by-volume of
+ *                         fields/interpolation_grid.py:286-296, which commutes with the z-FFT;
+ *   out_row_scale[j][iz], out_col_scale[j][n] : the spectral filter fz[iz]*fr[n] of
+ *                         fields/spectral_grid.py:437-454 applied to the result. */
+int fb_hankel_scaled(int njobs, const void *const *in, long in_row_stride,
+                     void *const *out, long out_row_stride, const double *const *mat,
+                     const double *const *in_col_scale, const double *const *out_row_scale,
+                     const double *const *out_col_scale, double alpha, int Nz, int Nr,
+                     void *stream);
 
 #ifdef __cplusplus
 }

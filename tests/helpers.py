@@ -19,14 +19,14 @@ def set_species_state(species, arr14):
 
 
 def uniform_plasma_sim(Nz, Nr, Nm, ppc, shape, seed=0, dz=0.2e-6, n_e=2e24, u_th=0.01,
-                       n_order=-1):
+                       n_order=-1, n_guard=None):
     """Synthetic uniform-plasma input of SURVEY.md 8d (C2 family) at any size."""
     from scipy.constants import c
     from fbpic_amd.main import Simulation
     zmax, rmax = Nz * dz, Nr * dz
     np.random.seed(seed)
     sim = Simulation(Nz, zmax, Nr, rmax, Nm, dz / c, 0., zmax, 0., rmax, ppc[0], ppc[1], ppc[2],
-                     n_e, particle_shape=shape, n_order=n_order)
+                     n_e, particle_shape=shape, n_order=n_order, n_guard=n_guard)
     rng = np.random.default_rng(seed + 1)
     s = sim.ptcl[0]
     s.ux = rng.normal(0., u_th, s.Ntot)

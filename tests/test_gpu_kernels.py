@@ -189,12 +189,12 @@ def _deposit_gpu(hip, g, shape, Nm, what, b0, bh, slab=False, presort=True):
     if what == 'rho':
         rc = hip.lib().fb_deposit_rho(sh, Nm, g['x'].size, p(d['x']), p(d['y']), p(d['z']), p(d['w']),
                                       float(g['q']), *geom, hip.ptr_array(views),
-                                      hip.row_stride(views[0]), p(dpre), p(db0), p(dbh), hip.stream())
+                                      hip.row_stride(views[0]), p(dpre), p(db0), p(dbh), None, hip.stream())
     else:
         rc = hip.lib().fb_deposit_J(sh, Nm, g['x'].size, p(d['x']), p(d['y']), p(d['z']), p(d['w']),
                                     float(g['q']), p(d['ux']), p(d['uy']), p(d['uz']),
                                     p(d['inv_gamma']), c, *geom, hip.ptr_array(views),
-                                    hip.row_stride(views[0]), p(dpre), p(db0), p(dbh), hip.stream())
+                                    hip.row_stride(views[0]), p(dpre), p(db0), p(dbh), None, hip.stream())
     hip.check(rc, 'fb_deposit')
     return np.array([host(v) for v in views])
 
@@ -363,3 +363,120 @@ def test_transformer_vs_golden(hip):
         tr.spect2interp_vect(r, tt, o1, o2)
         assert rel_err(host(o1), g['s2i_r_m%d' % m]) < 1e-12
         assert rel_err(host(o2), g['s2i_t_m%d' % m]) < 1e-12
+
+
+def test_hankel_scaled_fusions(hip):
+    """divide-by-volume (input column scale) and filter (output row/column scale) fused
+    into the GEMM == the three separate passes."""
+    rng = np.random.default_rng(8)
+    Nz, Nr, njobs = 96, 72, 4
+    t = hip.torch()
+    a = rng.normal(size=(Nz, njobs, Nr)) + 1j * rng.normal(size=(Nz, njobs, Nr))
+    mats = [rng.normal(size=(Nr, Nr)) for _ in range(njobs)]
+    sk = [rng.uniform(0.5, 2., Nr), None, rng.uniform(0.5, 2., Nr), None]
+    fz = [rng.uniform(0., 1., Nz), rng.uniform(0., 1., Nz), None, None]
+    fr = [rng.uniform(0., 1., Nr), rng.uniform(0., 1., Nr), None, None]
+    src = dev(hip, a)
+    dst = t.zeros((Nz, njobs, Nr), dtype=t.complex128, device='cuda')
+    D = lambda L: [dev(hip, v) if v is not None else None for v in L]  # noqa: E731
+    dm, dsk, dfz, dfr = D(mats), D(sk), D(fz), D(fr)
+    pa = hip.ptr_array
+    hip.check(hip.lib().fb_hankel_scaled(njobs, pa([src[:, j, :] for j in range(njobs)]), njobs * Nr,
+                                         pa([dst[:, j, :] for j in range(njobs)]), njobs * Nr,
+                                         pa(dm), pa(dsk), pa(dfz), pa(dfr), 1.0, Nz, Nr,
+                                         hip.stream()), 'hks')
+    for j in range(njobs):
+        x = a[:, j, :] * (sk[j][None, :] if sk[j] is not None else 1.)
+        ref = x @ mats[j]
+        if fz[j] is not None:
+            ref = (fz[j][:, None] * fr[j][None, :]) * ref
+        scale = (np.abs(a[:, j, :]) @ np.abs(mats[j])).max() * 2
+        assert np.abs(host(dst[:, j, :]) - ref).max() < 1e-14 * scale, j
+
+
+def test_psatd_step_fused_equals_separate(hip, oracle):
+    """fb_psatd_step_standard == correct_currents -> push_eb -> push_rho (oracle, per mode)."""
+    g = golden('spectral')
+    gs = golden('grid_setup')
+    Nm, Nz, Nr = int(g['Nm']), int(g['Nz']), int(g['Nr'])
+    dt = float(g['dt'])
+    names = ['Ep', 'Em', 'Ez', 'Bp', 'Bm', 'Bz', 'Jp', 'Jm', 'Jz', 'rho_prev', 'rho_next']
+    t = hip.torch()
+    for correct in (1, 0):
+        for utr in (0, 1):
+            slab = t.zeros((Nz, 11 * Nm, Nr), dtype=t.complex128, device='cuda')
+            fields, tables, expect = [], [], []
+            keep = []
+            for m in range(Nm):
+                tg = 'o-1_m%d' % m
+                kz = np.repeat(gs['kz_' + tg][:, None], Nr, 1).copy()
+                kr = np.repeat(gs['kr_' + tg][None, :], Nz, 0).copy()
+                a = {k: g['sp_in_%s_m%d' % (k, m)].copy() for k in names}
+                for i, k in enumerate(names):
+                    slab[:, 11 * m + i, :] = dev(hip, a[k])
+                    fields.append(slab[:, 11 * m + i, :])
+                tabs = [gs[k + '_' + tg] for k in ('rho_prev_coef', 'rho_next_coef', 'j_coef', 'C', 'S_w')]
+                tabs += [kr, kz, gs['inv_k2_' + tg]]
+                dt_ = [dev(hip, x) for x in tabs]
+                keep.append(dt_)
+                tables += dt_
+                if correct:
+                    oracle.correct_currents_curlfree(a['rho_prev'], a['rho_next'], a['Jp'], a['Jm'],
+                                                     a['Jz'], kz, kr, gs['inv_k2_' + tg], 1. / dt)
+                oracle.push_eb_standard(*[a[k] for k in names], *tabs[:5], kr, kz, dt, utr)
+                a['rho_prev'] = a['rho_next'].copy()
+                a['rho_next'][:] = 0.
+                expect.append(a)
+            hip.check(hip.lib().fb_psatd_step_standard(Nm, hip.ptr_array(fields), 11 * Nm * Nr,
+                                                       hip.ptr_array(tables), dt, correct, utr, c,
+                                                       epsilon_0, mu_0, Nz, Nr, hip.stream()), 'psatd')
+            for m in range(Nm):
+                for i, k in enumerate(names):
+                    assert rel_err(host(slab[:, 11 * m + i, :]), expect[m][k]) < TOL or \
+                        (np.abs(expect[m][k]).max() == 0 and np.all(host(slab[:, 11 * m + i, :]) == 0)), \
+                        (correct, utr, m, k)
+
+
+@pytest.mark.parametrize('shape', ['linear', 'cubic'])
+def test_gather_push_fused_is_bit_identical_to_sequence(hip, shape):
+    """fb_gather_push == fb_gather -> fb_push_p -> fb_push_x (same arithmetic, same bits)."""
+    g = golden('gather')
+    Nz, Nr, nm = int(g['Nz']), int(g['Nr']), 3
+    n = g['x'].size
+    t = hip.torch()
+    rng = np.random.default_rng(21)
+    views = [dev(hip, g['grids'][m, k] * 1e9) for m in range(nm) for k in range(6)]
+    u0 = [rng.normal(size=n) for _ in range(3)]
+    ig0 = 1. / np.sqrt(1 + u0[0]**2 + u0[1]**2 + u0[2]**2)
+    dt = 6.67e-16
+    geom = (float(g['rmax_gather']), 1. / float(g['dz']), float(g['zmin']), Nz, 1. / float(g['dr']), 0., Nr)
+    p = hip.ptr
+    sh = 1 if shape == 'linear' else 3
+
+    def fresh():
+        pos = [dev(hip, g[k]) for k in ('x', 'y', 'z')]
+        mom = [dev(hip, a) for a in u0] + [dev(hip, ig0)]
+        F = [t.zeros(n, dtype=t.float64, device='cuda') for _ in range(6)]
+        return pos, mom, F
+    pos, mom, F = fresh()
+    hip.check(hip.lib().fb_gather(sh, nm, n, *[p(a) for a in pos], *geom, hip.ptr_array(views), Nr,
+                                  *[p(f) for f in F], hip.stream()), 'gather')
+    hip.check(hip.lib().fb_push_p(n, *[p(a) for a in mom], *[p(f) for f in F], -e, m_e, c, dt,
+                                  hip.stream()), 'push_p')
+    hip.check(hip.lib().fb_push_x(n, *[p(a) for a in pos], *[p(a) for a in mom], c, 0.5 * dt,
+                                  1., 1., 1., hip.stream()), 'push_x')
+    pos2, mom2, F2 = fresh()
+    hip.check(hip.lib().fb_gather_push(sh, nm, n, *[p(a) for a in pos2], *[p(a) for a in mom2], *geom,
+                                       hip.ptr_array(views), Nr, *[p(f) for f in F2], -e, m_e, c, dt,
+                                       0.5 * dt, hip.stream()), 'gather_push')
+    for a, b in zip(pos + mom + F, pos2 + mom2 + F2):
+        assert np.array_equal(host(a), host(b))
+    # fields not stored, no position push
+    pos3, mom3, _ = fresh()
+    hip.check(hip.lib().fb_gather_push(sh, nm, n, *[p(a) for a in pos3], *[p(a) for a in mom3], *geom,
+                                       hip.ptr_array(views), Nr, *([None] * 6), -e, m_e, c, dt,
+                                       0., hip.stream()), 'gather_push')
+    for a, b in zip(mom, mom3):
+        assert np.array_equal(host(a), host(b))
+    for k, b in zip(('x', 'y', 'z'), pos3):
+        assert np.array_equal(g[k], host(b))
