@@ -61,6 +61,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=3)
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--resort-fragmentation', type=float, default=None,
+                    help='override Particles.resort_fragmentation (adaptive sort policy)')
     return ap.parse_args()
 
 
@@ -94,6 +96,9 @@ def main():
     # weak scaling: every rank owns args.Nz cells; the Simulation is given the global box
     sim = helpers.uniform_plasma_sim(args.Nz * world, args.Nr, args.Nm, ppc, args.shape, seed=0,
                                      n_order=n_order, n_guard=(None if world == 1 else 64))
+    if args.resort_fragmentation is not None:
+        for sp in sim.ptcl:
+            sp.resort_fragmentation = args.resort_fragmentation
     n_local = sum(s.Ntot for s in sim.ptcl)
     n_total = n_local
     if world > 1:
