@@ -29,6 +29,8 @@ _SIGNATURES = {
     'fb_cell_index': (I, [L, P, P, P, D, D, I, D, D, I, P, P, P]),
     'fb_sort_workspace_bytes': (Z, [L, I]),
     'fb_sort_by_cell': (I, [L, I, P, P, P, P, ctypes.POINTER(I), P, P, Z, P]),
+    'fb_bin_sort_workspace_bytes': (Z, [L, I]),
+    'fb_bin_sort_particles': (I, [L, I, P, P, P, D, D, I, D, D, I, I, _PP, _PP, P, P, P, P, Z, P]),
     'fb_permute': (I, [L, P, I, _PP, _PP, P]),
     'fb_deposit_rho': (I, [I, I, L, P, P, P, P, D, D, D, I, D, D, I, _PP, L, P, P, P, P, P]),
     'fb_deposit_J': (I, [I, I, L, P, P, P, P, D, P, P, P, P, D, D, D, I, D, D, I, _PP, L,
@@ -154,7 +156,7 @@ class _TimedLib(object):
     def __getattr__(self, name):
         f = getattr(self._real, name)
         if not name.startswith('fb_') or name in ('fb_last_error', 'fb_abi_version',
-                                                  'fb_sort_workspace_bytes', 'fb_fft_plan_create',
+                                                  'fb_sort_workspace_bytes', 'fb_bin_sort_workspace_bytes', 'fb_fft_plan_create',
                                                   'fb_fft_plan_destroy', 'fb_sync', 'fb_set_device'):
             return f
         t = torch()

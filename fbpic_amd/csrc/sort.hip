@@ -4,6 +4,7 @@
 #include <cstring>
 #include "fb_common.h"
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 namespace fb {
 
@@ -61,6 +62,88 @@ __global__ __launch_bounds__(256) void k_permute(long n, const int *__restrict__
         int j = sidx[i];
         for (int k = 0; k < nattr; k++) dst.p[k][i] = src.p[k][j];
     }
+}
+
+// ---- counting sort by cell (fast path of Particles.sort_particles) -----------------
+// The radix sort above is general; the PIC cycle re-sorts an ALMOST sorted stream every
+// step, for which a counting sort needs one pass less over the keys and no permutation
+// index:
+//   k_bin_rank : cell index (same arithmetic as k_cell_index) + rank of each particle
+//                inside its cell.  Lanes of a wave that sit in the same cell form runs
+//                (the stream is nearly sorted): one atomicAdd per run on the per-cell
+//                counter, the lanes take consecutive ranks -> ~n/ppc atomics, spread over
+//                distinct addresses.
+//   scan       : inclusive prefix sum of the per-cell counters (rocPRIM) = prefix_sum.
+//   k_scatter  : every attribute is written to prefix_sum[c-1] + rank in ONE launch.
+// The order of particles inside a cell is the arrival order of the runs (not the original
+// order as with the stable radix sort); deposition and gather do not depend on it.
+__global__ __launch_bounds__(256) void k_bin_rank(long n, const double *__restrict__ x,
+        const double *__restrict__ y, const double *__restrict__ z,
+        double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
+        int *__restrict__ cell, int *__restrict__ rank, int *__restrict__ count)
+{
+    const int lane = threadIdx.x & 63;
+    const long nchunks = (n + 63) / 64;
+    const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long chv = wave0; chv < nchunks; chv += nwaves) {
+        const long i = chv * 64 + lane;
+        const bool act = i < n;
+        int c = -1;
+        if (act) {
+            const double xj = x[i], yj = y[i], zj = z[i];
+            const double rj = sqrt(xj * xj + yj * yj);
+            const double r_cell = invdr * (rj - rmin) - 0.5;
+            const double z_cell = invdz * (zj - zmin) - 0.5;
+            int ir_upper = (int)ceil(r_cell);
+            int iz_upper = (int)ceil(z_cell);
+            if (ir_upper > Nr) ir_upper = Nr;
+            if (iz_upper < 0) iz_upper += Nz;
+            else if (iz_upper > Nz - 1) iz_upper -= Nz;
+            c = ir_upper + iz_upper * (Nr + 1);
+        }
+        const int prev = __shfl_up(c, 1);
+        const bool is_start = act && (lane == 0 || c != prev);
+        const unsigned long long starts = __ballot(is_start);
+        const unsigned long long active = __ballot(act);
+        const int cnt = __popcll(active);
+        // my run: starts at the highest start bit at or below my lane
+        const unsigned long long below = starts & ((2ull << lane) - 1ull);
+        const int run0 = 63 - __builtin_clzll(below | 1ull);
+        int base = 0;
+        if (is_start) {
+            const unsigned long long rest = (lane + 1 < 64) ? (starts >> (lane + 1)) : 0ull;
+            int len = rest ? (__builtin_ctzll(rest) + 1) : (cnt - lane);
+            base = atomicAdd(count + c, len);
+        }
+        base = __shfl(base, run0);
+        if (act) {
+            cell[i] = c;
+            rank[i] = base + (lane - run0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scatter(long n, const int *__restrict__ cell,
+        const int *__restrict__ rank, const int *__restrict__ prefix, int nattr, CPtrs16 src,
+        Ptrs16 dst, int *__restrict__ cell_sorted, int *__restrict__ sorted_idx)
+{
+    long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int c = cell[i];
+        const int d = (c > 0 ? prefix[c - 1] : 0) + rank[i];
+        for (int k = 0; k < nattr; k++) dst.p[k][d] = src.p[k][i];
+        cell_sorted[d] = c;
+        sorted_idx[d] = (int)i;
+    }
+}
+
+static size_t scan_temp_bytes(int ncell)
+{
+    size_t bytes = 0;
+    (void)rocprim::inclusive_scan((void *)nullptr, bytes, (int *)nullptr, (int *)nullptr,
+                                  (size_t)ncell, rocprim::plus<int>(), (hipStream_t)0, false);
+    return bytes;
 }
 
 static inline int key_bits(int ncell)
@@ -148,4 +231,53 @@ extern "C" int fb_permute(long n, const int *sorted_idx, int nattr, const double
     hipLaunchKernelGGL(k_permute, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, n,
                        sorted_idx, nattr, a, b);
     FB_CHECK_LAUNCH("fb_permute");
+}
+
+extern "C" size_t fb_bin_sort_workspace_bytes(long n, int ncell)
+{
+    // per-cell counters + per-particle cell and rank + rocPRIM scan scratch
+    return align_up((size_t)ncell * sizeof(int), 256) + 2 * align_up((size_t)(n > 0 ? n : 1) * sizeof(int), 256)
+           + align_up(scan_temp_bytes(ncell), 256) + 256;
+}
+
+extern "C" int fb_bin_sort_particles(long n, int ncell, const double *x, const double *y,
+        const double *z, double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
+        int nattr, const double *const *src, double *const *dst,
+        int *cell_idx_sorted, int *sorted_idx, int *prefix_sum,
+        void *workspace, size_t workspace_bytes, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (nattr < 0 || nattr > 16) { set_error("fb_bin_sort_particles", "nattr > 16"); return -1; }
+    if (ncell != Nz * (Nr + 1)) { set_error("fb_bin_sort_particles", "ncell != Nz*(Nr+1)"); return -1; }
+    if (workspace_bytes < fb_bin_sort_workspace_bytes(n, ncell)) {
+        set_error("fb_bin_sort_particles", "workspace too small");
+        return -1;
+    }
+    char *ws = (char *)workspace;
+    int *count = (int *)ws;
+    ws += align_up((size_t)ncell * sizeof(int), 256);
+    const size_t pb = align_up((size_t)(n > 0 ? n : 1) * sizeof(int), 256);
+    int *cell = (int *)ws; ws += pb;
+    int *rank = (int *)ws; ws += pb;
+    void *temp = ws;
+    size_t temp_bytes = workspace_bytes - (size_t)(ws - (char *)workspace);
+    hipError_t e = hipMemsetAsync(count, 0, (size_t)ncell * sizeof(int), s);
+    if (e != hipSuccess) return check(e, "fb_bin_sort_particles(memset)");
+    if (n > 0) {
+        hipLaunchKernelGGL(k_bin_rank, dim3(stream_grid(n, 256, 256 * 16)), dim3(256), 0, s, n, x, y,
+                           z, invdz, zmin, Nz, invdr, rmin, Nr, cell, rank, count);
+        int r = check(hipGetLastError(), "fb_bin_sort_particles(rank)");
+        if (r) return r;
+    }
+    e = rocprim::inclusive_scan(temp, temp_bytes, count, prefix_sum, (size_t)ncell,
+                                rocprim::plus<int>(), s, false);
+    if (e != hipSuccess) return check(e, "fb_bin_sort_particles(scan)");
+    if (n > 0) {
+        CPtrs16 a;
+        Ptrs16 b;
+        for (int k = 0; k < 16; k++) { a.p[k] = k < nattr ? src[k] : nullptr; b.p[k] = k < nattr ? dst[k] : nullptr; }
+        hipLaunchKernelGGL(k_scatter, dim3(stream_grid(n)), dim3(256), 0, s, n, cell, rank,
+                           prefix_sum, nattr, a, b, cell_idx_sorted, sorted_idx);
+    }
+    FB_CHECK_LAUNCH("fb_bin_sort_particles");
 }

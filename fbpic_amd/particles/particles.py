@@ -70,6 +70,9 @@ class Particles(object):
         # costs less than the fragmentation it removes from gather + both depositions after
         # two steps even for a 0.01 c thermal plasma (measured, profiles/README.md).
         self.resort_fragmentation = 0.
+        # counting sort (fb_bin_sort_particles) instead of cell_index + radix sort + permute;
+        # False restores the reference-like stable three-stage sort
+        self.use_bin_sort = True
         self.max_deposits_between_sorts = 16
         self._runs_after_sort = None
         self._runs_latest = None
@@ -98,7 +101,8 @@ class Particles(object):
         self.prefix_sum = t.zeros(ncell, dtype=t.int32, device=dev)
         self._alt = [t.empty(n, dtype=t.float64, device=dev) for _ in range(14)]
         self.sorting_buffer = self._alt[0]
-        nbytes = int(_capi.lib().fb_sort_workspace_bytes(n, ncell))
+        nbytes = max(int(_capi.lib().fb_sort_workspace_bytes(n, ncell)),
+                     int(_capi.lib().fb_bin_sort_workspace_bytes(n, ncell)))
         self._sort_ws = t.empty(nbytes, dtype=t.uint8, device=dev)
         self._nflush = t.zeros(1024, dtype=t.int64, device=dev)
         self._nflush_host = t.zeros(1024, dtype=t.int64).pin_memory()
@@ -222,6 +226,25 @@ class Particles(object):
         lib = _capi.lib()
         p = _capi.ptr
         st = _capi.stream()
+        if self.use_bin_sort:
+            # counting sort specialised for the almost-sorted stream: 3 launches in all
+            names = list(_STATE) + (list(_FIELDS) if self.keep_fields_sorted else [])
+            src = [getattr(self, k) for k in names]
+            dst = self._alt[:len(names)]
+            rc = lib.fb_bin_sort_particles(
+                self.Ntot, self.prefix_sum.shape[0], p(self.x), p(self.y), p(self.z),
+                g0.invdz, g0.zmin, g0.Nz, g0.invdr, g0.rmin, g0.Nr, len(names),
+                _capi.ptr_array(src), _capi.ptr_array(dst), p(self.cell_idx), p(self.sorted_idx),
+                p(self.prefix_sum), p(self._sort_ws), self._sort_ws.shape[0], st)
+            _capi.check(rc, 'fb_bin_sort_particles')
+            for i, k in enumerate(names):
+                setattr(self, k, dst[i])
+                self._alt[i] = src[i]
+            self.sorting_buffer = self._alt[0]
+            self.prefix_sum_shift = 0
+            self._cell_size = (g0.dz, g0.dr)
+            self._moved_since_sort = 0.
+            return
         rc = lib.fb_cell_index(self.Ntot, p(self.x), p(self.y), p(self.z), g0.invdz, g0.zmin,
                                g0.Nz, g0.invdr, g0.rmin, g0.Nr, p(self.cell_idx),
                                p(self.sorted_idx), st)

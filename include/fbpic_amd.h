@@ -102,6 +102,21 @@ int fb_sort_by_cell(long n, int ncell, int *cell_idx, int *sorted_idx,
                     int *cell_idx_alt, int *sorted_idx_alt, int *result_in_alt,
                     int *prefix_sum, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The whole of Particles.sort_particles (particles/particles.py:1049-1094: cell index,
+ * argsort, prefix sum, rearrange) as a counting sort specialised for the almost-sorted
+ * stream of the PIC cycle: cell index + per-cell rank (one atomic per run of equal cells),
+ * scan of the per-cell counts, one scatter of all nattr attributes (dst[k][new] =
+ * src[k][old]).  Outputs as the reference's sort: cell_idx_sorted[n], sorted_idx[n]
+ * (old index of each sorted particle), prefix_sum[ncell] (inclusive).  Unlike Thrust's
+ * stable argsort the order INSIDE a cell is unspecified (gather and deposition do not
+ * depend on it).  src/dst: HOST arrays of nattr (<= 16) device pointers. */
+size_t fb_bin_sort_workspace_bytes(long n, int ncell);
+int fb_bin_sort_particles(long n, int ncell, const double *x, const double *y, const double *z,
+                          double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
+                          int nattr, const double *const *src, double *const *dst,
+                          int *cell_idx_sorted, int *sorted_idx, int *prefix_sum,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
 /* particles/particles.py:519-538 -> write_sorting_buffer (cuda_sorting.py:192-213),
  * all attributes in one launch: dst[k][i] = src[k][sorted_idx[i]].
  * src, dst: HOST arrays of nattr device pointers (nattr <= 16). */

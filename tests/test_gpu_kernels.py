@@ -480,3 +480,47 @@ def test_gather_push_fused_is_bit_identical_to_sequence(hip, shape):
         assert np.array_equal(host(a), host(b))
     for k, b in zip(('x', 'y', 'z'), pos3):
         assert np.array_equal(g[k], host(b))
+
+
+@pytest.mark.parametrize('presorted', [True, False])
+def test_bin_sort_particles(hip, oracle, presorted):
+    """Counting-sort fast path: cells sorted, a valid permutation, prefix sums and cell
+    indices identical to the reference definition (order inside a cell is free)."""
+    rng = np.random.default_rng(31)
+    n, Nz, Nr = 300001, 96, 40
+    dzc = 0.2e-6
+    r = rng.uniform(0, 1.05 * Nr * dzc, n)
+    th = rng.uniform(0, 2 * np.pi, n)
+    x, y = r * np.cos(th), r * np.sin(th)
+    z = rng.uniform(0, Nz * dzc, n)
+    geom = (1. / dzc, 0., Nz, 1. / dzc, 0., Nr)
+    ref = oracle.cell_index(x, y, z, *geom)
+    if presorted:       # the PIC-cycle situation: almost sorted, long runs
+        o = np.argsort(ref, kind='stable')
+        x, y, z, ref = x[o], y[o], z[o], ref[o]
+        sw = rng.integers(0, n - 40, 2000)
+        for a in sw:     # perturb: a few particles out of place
+            for arr in (x, y, z, ref):
+                arr[a], arr[a + 37] = arr[a + 37], arr[a]
+    w = rng.normal(size=n)
+    t = hip.torch()
+    ncell = Nz * (Nr + 1)
+    src = [dev(hip, a) for a in (x, y, z, w)]
+    dst = [t.empty_like(src[0]) for _ in range(4)]
+    ci = t.empty(n, dtype=t.int32, device='cuda')
+    si = t.empty(n, dtype=t.int32, device='cuda')
+    pre = t.empty(ncell, dtype=t.int32, device='cuda')
+    nb = int(hip.lib().fb_bin_sort_workspace_bytes(n, ncell))
+    ws = t.empty(nb, dtype=t.uint8, device='cuda')
+    p = hip.ptr
+    for _ in range(2):     # twice: the per-cell counters must be reset between calls
+        hip.check(hip.lib().fb_bin_sort_particles(n, ncell, p(src[0]), p(src[1]), p(src[2]), *geom, 4,
+                                                  hip.ptr_array(src), hip.ptr_array(dst), p(ci), p(si),
+                                                  p(pre), p(ws), nb, hip.stream()), 'binsort')
+    cis, sidx, prefix = host(ci), host(si), host(pre)
+    assert np.all(np.diff(cis) >= 0)
+    assert np.array_equal(np.sort(sidx), np.arange(n, dtype=np.int32))
+    assert np.array_equal(cis, ref[sidx])                       # bit-exact cell of every particle
+    assert np.array_equal(prefix, np.cumsum(np.bincount(ref, minlength=ncell)).astype(np.int32))
+    for a, b in zip((x, y, z, w), dst):
+        assert np.array_equal(host(b), a[sidx])
