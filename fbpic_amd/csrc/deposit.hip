@@ -147,18 +147,23 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
         o_sgn[j] = (NCOMP == 1 || k == 2) ? flip : -flip;
     }
 
-    double acc[OPL];
+    double acc[OPL], acc2[OPL];
 #pragma unroll
-    for (int j = 0; j < OPL; j++) acc[j] = 0.;
+    for (int j = 0; j < OPL; j++) { acc[j] = 0.; acc2[j] = 0.; }
     int cur_z = DEP_NOKEY, cur_r = DEP_NOKEY;
     unsigned int my_flushes = 0;      // wave-uniform: runs of equal cells seen by this wave
 
-    auto flush = [&]() {
+    // With the linear shape and one output per lane, two cells that follow each other along
+    // r share one node column: its partial sums slide to the lanes of the lower column
+    // instead of being flushed, halving the atomics of an r-ordered stream.
+    constexpr bool SLIDE = (SHAPE == FB_SHAPE_LINEAR) && (OPL == 1) && (2 * S * NA <= 64);
+    auto flush = [&](bool lower_column_only) {
         if (cur_z == DEP_NOKEY) return;
         my_flushes++;
 #pragma unroll
         for (int j = 0; j < OPL; j++) {
             if (!o_ok[j] || acc[j] == 0.) continue;
+            if (lower_column_only && o_jr[j] != 0) continue;
             int gz = cur_z + o_jz[j], gr = cur_r + o_jr[j];
             fold_node(gz, gr, Nz, Nr);
             double *g = (double *)(G.g[o_km[j] >> 1] + (long)gz * rs + gr) + (o_km[j] & 1);
@@ -255,16 +260,41 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
         int p = 0;
         while (p < cnt) {
             if ((starts >> p) & 1ull) {
-                flush();
+                const int nz_ = __builtin_amdgcn_readlane(my_kz, p);
+                const int nr_ = __builtin_amdgcn_readlane(my_kr, p);
 #pragma unroll
-                for (int j = 0; j < OPL; j++) acc[j] = 0.;
-                cur_z = __builtin_amdgcn_readlane(my_kz, p);
-                cur_r = __builtin_amdgcn_readlane(my_kr, p);
+                for (int j = 0; j < OPL; j++) { acc[j] += acc2[j]; acc2[j] = 0.; }
+                if (SLIDE && nz_ == cur_z && nr_ == cur_r + 1) {
+                    flush(true);                     // column cur_r is complete
+                    const double up = __shfl_down(acc[0], NA);   // column cur_r+1 carries on
+                    acc[0] = (o_jr[0] == 0) ? up : 0.;
+                } else {
+                    flush(false);
+#pragma unroll
+                    for (int j = 0; j < OPL; j++) acc[j] = 0.;
+                }
+                cur_z = nz_;
+                cur_r = nr_;
             }
             const unsigned long long rest = (p + 1 < 64) ? (starts >> (p + 1)) : 0ull;
             int e = rest ? p + 1 + __builtin_ctzll(rest) : cnt;
             if (e > cnt) e = cnt;
             if (cur_r >= 0) {                       // no node of this cell is below the axis
+                // 4 particles per trip, two accumulator chains: all 8 LDS reads are in
+                // flight before the first FMA, and the fp64 FMA latency is overlapped
+                for (; p + 4 <= e; p += 4) {
+#pragma unroll
+                    for (int j = 0; j < OPL; j++) {
+                        const double *wp = Wl + (o_m0[j] ? o_w0[j] : o_wh[j]) + p;
+                        const double *ap = Al + o_a[j] + p;
+                        const double w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
+                        const double a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];
+                        acc[j] = __builtin_fma(w0, a0, acc[j]);
+                        acc2[j] = __builtin_fma(w1, a1, acc2[j]);
+                        acc[j] = __builtin_fma(w2, a2, acc[j]);
+                        acc2[j] = __builtin_fma(w3, a3, acc2[j]);
+                    }
+                }
                 for (; p < e; p++) {
 #pragma unroll
                     for (int j = 0; j < OPL; j++) {
@@ -287,7 +317,9 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    flush();
+#pragma unroll
+    for (int j = 0; j < OPL; j++) acc[j] += acc2[j];
+    flush(false);
     // fragmentation statistic for the host's sort policy: 1024 counters (same-address
     // device atomics serialise at ~10 ns each; one shared counter would cost > 100 us)
     if (nflush && lane == 0)
