@@ -121,13 +121,19 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
     double *Wl = lds + (size_t)wave * L::WAVE_DOUBLES;
     double *Al = Wl + NW * DEP_PAD;
 
+    // When a cell has few output values (rho: 16 for the linear shape, Nm = 2) the wave is
+    // split into NSUB groups of NP2 lanes; group g accumulates particles g, g+NSUB, ... of a
+    // run and the groups are summed with xor-shuffles at the end of the run.
+    constexpr int NP2 = (NOUT <= 16) ? 16 : (NOUT <= 32) ? 32 : 64;
+    constexpr int NSUB = (OPL == 1) ? 64 / NP2 : 1;
+    const int sub = (NSUB > 1) ? lane / NP2 : 0;
     // decode the outputs owned by this lane: o = lane + 64 j -> (jz, jr, comp, mode, re/im)
     int o_w0[OPL], o_wh[OPL], o_a[OPL], o_jr[OPL], o_jz[OPL], o_km[OPL];
     double o_sgn[OPL];
     bool o_ok[OPL], o_m0[OPL];
 #pragma unroll
     for (int j = 0; j < OPL; j++) {
-        int o = lane + 64 * j;
+        int o = (NSUB > 1) ? (lane % NP2) : (lane + 64 * j);
         o_ok[j] = o < NOUT;
         if (!o_ok[j]) o = 0;
         const int ri = o & 1;
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
         my_flushes++;
 #pragma unroll
         for (int j = 0; j < OPL; j++) {
-            if (!o_ok[j] || acc[j] == 0.) continue;
+            if (!o_ok[j] || acc[j] == 0. || sub != 0) continue;
             if (lower_column_only && o_jr[j] != 0) continue;
             int gz = cur_z + o_jz[j], gr = cur_r + o_jr[j];
             fold_node(gz, gr, Nz, Nr);
@@ -264,10 +270,14 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
                 const int nr_ = __builtin_amdgcn_readlane(my_kr, p);
 #pragma unroll
                 for (int j = 0; j < OPL; j++) { acc[j] += acc2[j]; acc2[j] = 0.; }
+                if constexpr (NSUB > 1) {
+#pragma unroll
+                    for (int d = NP2; d < 64; d <<= 1) acc[0] += __shfl_xor(acc[0], d);
+                }
                 if (SLIDE && nz_ == cur_z && nr_ == cur_r + 1) {
                     flush(true);                     // column cur_r is complete
                     const double up = __shfl_down(acc[0], NA);   // column cur_r+1 carries on
-                    acc[0] = (o_jr[0] == 0) ? up : 0.;
+                    acc[0] = (o_jr[0] == 0 && sub == 0) ? up : 0.;
                 } else {
                     flush(false);
 #pragma unroll
@@ -280,6 +290,22 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
             int e = rest ? p + 1 + __builtin_ctzll(rest) : cnt;
             if (e > cnt) e = cnt;
             if (cur_r >= 0) {                       // no node of this cell is below the axis
+                if constexpr (NSUB > 1) {
+                    // group `sub` takes particles p+sub, p+sub+NSUB, ...; two chains
+                    int q = p + sub;
+                    for (; q + NSUB < e; q += 2 * NSUB) {
+                        const double *wp = Wl + (o_m0[0] ? o_w0[0] : o_wh[0]) + q;
+                        const double *ap = Al + o_a[0] + q;
+                        const double w0 = wp[0], w1 = wp[NSUB], a0 = ap[0], a1 = ap[NSUB];
+                        acc[0] = __builtin_fma(w0, a0, acc[0]);
+                        acc2[0] = __builtin_fma(w1, a1, acc2[0]);
+                    }
+                    if (q < e) {
+                        const double wv = o_m0[0] ? Wl[o_w0[0] + q] : Wl[o_wh[0] + q];
+                        acc[0] = __builtin_fma(wv, Al[o_a[0] + q], acc[0]);
+                    }
+                    p = e;
+                } else {
                 // 4 particles per trip, two accumulator chains: all 8 LDS reads are in
                 // flight before the first FMA, and the fp64 FMA latency is overlapped
                 for (; p + 4 <= e; p += 4) {
@@ -302,6 +328,7 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
                         acc[j] = __builtin_fma(wv, Al[o_a[j] + p], acc[j]);
                     }
                 }
+                }
             } else {
                 for (; p < e; p++) {
                     const int nb = __builtin_amdgcn_readlane(my_nb, p);
@@ -309,7 +336,7 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
                     for (int j = 0; j < OPL; j++) {
                         double wv = o_m0[j] ? Wl[o_w0[j] + p] : Wl[o_wh[j] + p];
                         if (o_jr[j] < nb) wv *= o_sgn[j];
-                        acc[j] = __builtin_fma(wv, Al[o_a[j] + p], acc[j]);
+                        if (sub == 0) acc[j] = __builtin_fma(wv, Al[o_a[j] + p], acc[j]);
                     }
                 }
             }
@@ -319,6 +346,10 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
     }
 #pragma unroll
     for (int j = 0; j < OPL; j++) acc[j] += acc2[j];
+    if constexpr (NSUB > 1) {
+#pragma unroll
+        for (int d = NP2; d < 64; d <<= 1) acc[0] += __shfl_xor(acc[0], d);
+    }
     flush(false);
     // fragmentation statistic for the host's sort policy: 1024 counters (same-address
     // device atomics serialise at ~10 ns each; one shared counter would cost > 100 us)
