@@ -43,6 +43,7 @@ _SIGNATURES = {
     'fb_push_rho': (I, [P, P, L, I, I, P]),
     'fb_rt_to_pm': (I, [I, _PP, _PP, _PP, _PP, L, I, I, P]),
     'fb_pm_to_rt': (I, [I, _PP, _PP, _PP, _PP, L, I, I, P]),
+    'fb_shift_spect': (I, [I, _PP, L, P, I, I, I, P]),
     'fb_scale': (I, [I, _PP, L, D, I, I, P]),
     'fb_fft_plan_create': (I, [I, L, L, L, I, _PP]),
     'fb_fft_exec': (I, [P, I, P, P, P]),

@@ -164,6 +164,10 @@ class BoundaryCommunicator(object):
     def shift_global_domain_positions(self, z_shift):
         self._zmin_global_domain += z_shift
 
+    def move_grids(self, fld, ptcl, dt, time):
+        """Advance the moving window (boundary_communicator.py:533-553)."""
+        self.moving_win.move_grids(fld, ptcl, self, time)
+
     # ---------------------------------------------------------------- damping (open z)
     def generate_damp_array(self, n_guard, nz_damp, n_inject):
         """Damping profile of the open-z boundary: zero over the outer n_guard + n_inject
@@ -248,6 +252,8 @@ class BoundaryCommunicator(object):
         """Nearest-neighbour exchange (boundary_communicator.py:674-707) as one batch of
         point-to-point operations.  Complex tensors travel as their real view.  With
         `skip_empty`, zero-length messages are not posted (both sides know the lengths)."""
+        if self.left_proc is None and self.right_proc is None:
+            return
         dist = _dist()
         t = _capi.torch()
         # RCCL moves device buffers directly over xGMI.  Under the gloo backend (CPU tests,

@@ -44,6 +44,13 @@ def exchange_particles_between_ranks(comm, species, fld, time):
     recv_l = t.empty((len(_STATE), n_rl), dtype=t.float64, device=dev)
     recv_r = t.empty((len(_STATE), n_rr), dtype=t.float64, device=dev)
     comm.exchange_domains(send_l, send_r, recv_l, recv_r, skip_empty=True)
+    # plasma uncovered by the moving window enters through the right edge of the last rank
+    # (boundary_communicator.py:803-808)
+    if (comm.moving_win is not None) and (comm.rank == comm.size - 1) \
+            and species.continuous_injection:
+        new = species.generate_continuously_injected_particles(time)
+        recv_r = t.from_numpy(new).to(dev)
+        n_rr = recv_r.shape[1]
     # periodic wrap of the hand-over across the ends of the global box
     Ltot = comm._Nz_global_domain * comm.dz
     if comm.right_proc == 0 and n_rr:

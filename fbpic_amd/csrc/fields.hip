@@ -222,6 +222,25 @@ __global__ __launch_bounds__(256) void k_psatd_step(PsatdModes M, long rs, doubl
     }
 }
 
+// boundaries/moving_window.py:204-239 (shift_spect_array_cpu): F[iz,:] *= shift[iz]^n_move,
+// the power by repeated multiplication, conjugated for n_move < 0
+__global__ __launch_bounds__(256) void k_shift_spect(int nf, Ptrs48 P, long rs,
+        const cplx *__restrict__ shift, int n_move, int Nz, int Nr)
+{
+    FB_GRID_LOOP(idx, iz, ir) {
+        const cplx sh = ld(shift + iz);
+        cplx pw = {1., 0.};
+        const int na = n_move < 0 ? -n_move : n_move;
+        for (int i = 0; i < na; i++) pw = {pw.re * sh.re - pw.im * sh.im, pw.re * sh.im + pw.im * sh.re};
+        if (n_move < 0) pw.im = -pw.im;
+        for (int f = 0; f < nf; f++) {
+            cplx *p = (cplx *)P.p[f] + (long)iz * rs + ir;
+            const cplx a = ld(p);
+            st(p, {a.re * pw.re - a.im * pw.im, a.re * pw.im + a.im * pw.re});
+        }
+    }
+}
+
 // fields/spectral_grid.py:407-421
 __global__ __launch_bounds__(256) void k_push_rho(cplx *__restrict__ rho_prev,
                                                   cplx *__restrict__ rho_next, long rs, int Nz, int Nr)
@@ -360,4 +379,15 @@ extern "C" int fb_psatd_step_standard(int Nm, void *const *fields, long rs,
     hipLaunchKernelGGL(k_psatd_step, grid, dim3(256), 0, (hipStream_t)stream, M, rs, dt, 1. / dt,
                        correct_currents, use_true_rho, c * c, epsilon_0, mu_0, Nz, Nr);
     FB_CHECK_LAUNCH("fb_psatd_step_standard");
+}
+
+extern "C" int fb_shift_spect(int nf, void *const *ptrs, long rs, const void *shift, int n_move,
+                              int Nz, int Nr, void *stream)
+{
+    Ptrs48 P;
+    if (!fill48(P, ptrs, nf, "fb_shift_spect")) return -1;
+    if (nf == 0 || n_move == 0) return 0;
+    hipLaunchKernelGGL(k_shift_spect, dim3(grid_for(Nz, Nr)), dim3(256), 0, (hipStream_t)stream, nf, P,
+                       rs, (const cplx *)shift, n_move, Nz, Nr);
+    FB_CHECK_LAUNCH("fb_shift_spect");
 }

@@ -9,6 +9,7 @@ from . import _capi
 from .particles.particles import Particles
 from .fields import Fields
 from .boundaries.boundary_communicator import BoundaryCommunicator
+from .boundaries.moving_window import MovingWindow
 
 
 def send_data_to_gpu(simulation):
@@ -127,6 +128,11 @@ class Simulation(object):
         if self.comm.size > 1 and use_true_rho and correct_currents:
             raise ValueError('`use_true_rho` cannot be used together with '
                              '`correct_currents` in multi-proc mode.')
+        if self.comm.moving_win is not None:
+            for species in ptcl:
+                if species.continuous_injection:
+                    species.injector.initialize_injection_positions(
+                        self.comm, self.comm.moving_win.v, species.z, self.dt)
         was_on_gpu = fld.data_is_on_gpu and all(s.data_is_on_gpu for s in ptcl)
         send_data_to_gpu(self)
         self._in_step = True
@@ -251,16 +257,18 @@ class Simulation(object):
         fld = self.fld
         needs_partial = (self.comm.size > 1) or (self.comm.nz_damp != 0) or len(self.mirrors) > 0
         if needs_partial:
-            fld.spect2partial_interp('E')
-            fld.spect2partial_interp('B')
+            fld.spect2partial_interp('EB')
             self.comm.exchange_fields(fld.interp, 'E', 'replace')
             self.comm.exchange_fields(fld.interp, 'B', 'replace')
             self.comm.damp_EB_open_boundary(fld.interp)
             for mirror in self.mirrors:
                 mirror.set_fields_to_zero(fld.interp, self.comm, self.time)
-            fld.partial_interp2spect('E')
-            fld.partial_interp2spect('B')
+            fld.partial_interp2spect('EB')
         fld.spect2interp('EB')
+
+    def set_moving_window(self, v=c, **deprecated):
+        """Attach a window moving at velocity v to the simulation (main.py:1004-1032)."""
+        self.comm.moving_win = MovingWindow(self.comm, self.dt, v, self.time)
 
     # -------------------------------------------------------------------- species
     def add_new_species(self, q, m, n=None, dens_func=None, p_nz=None, p_nr=None, p_nt=None,

@@ -10,7 +10,7 @@ import ctypes
 import numpy as np
 from scipy.constants import c
 from .. import _capi
-from .injection import generate_evenly_spaced
+from .injection import generate_evenly_spaced, ContinuousInjector
 
 _SHAPE = {'linear': 1, 'cubic': 3}
 _STATE = ('x', 'y', 'z', 'ux', 'uy', 'uz', 'w', 'inv_gamma')
@@ -38,9 +38,14 @@ class Particles(object):
         self.inv_gamma, self.w = inv_gamma, w
         for k in _FIELDS:
             setattr(self, k, np.zeros(Ntot))
-        # continuous injection (moving window) is a "next" row: keep the flag only
+        # continuous injection behind a moving window (reference :194-203)
         self.continuous_injection = continuous_injection
-        self.injector = None
+        if continuous_injection:
+            self.injector = ContinuousInjector(Npz, zmin, zmax, dz_particles, Npr, rmin, rmax,
+                                               Nptheta, n, dens_func, ux_m, uy_m, uz_m,
+                                               ux_th, uy_th, uz_th)
+        else:
+            self.injector = None
         self.tracker = None
         self.ionizer = None
         self.compton_scatterer = None
@@ -127,6 +132,16 @@ class Particles(object):
         for k in _STATE + _FIELDS:
             setattr(self, k, _capi.to_host(getattr(self, k)))
         self.data_is_on_gpu = False
+
+    def generate_continuously_injected_particles(self, time):
+        """(8, N) float buffer of the plasma uncovered by the moving window since the last
+        particle exchange (reference :335-374), in the buffer order x,y,z,ux,uy,uz,inv_gamma,w."""
+        assert self.continuous_injection is True
+        Ntot, x, y, z, ux, uy, uz, inv_gamma, w = self.injector.generate_particles(time)
+        buf = np.empty((self.n_float_quantities, Ntot), dtype=np.float64)
+        for i, a in enumerate((x, y, z, ux, uy, uz, inv_gamma, w)):
+            buf[i, :] = a
+        return buf
 
     def on_particle_number_changed(self):
         """Re-size the device helpers after particles were added / removed."""

@@ -202,6 +202,11 @@ int fb_pm_to_rt(int npairs, const void *const *p, const void *const *m,
 int fb_scale(int nfields, void *const *ptrs, long row_stride, double factor,
              int Nz, int Nr, void *stream);
 
+/* boundaries/moving_window.py:243-278 -> shift_spect_array_gpu: translate spectral fields
+ * by n_move cells, F[iz, :] *= shift[iz]^n_move with shift = exp(i kz_true dz) (complex128[Nz]). */
+int fb_shift_spect(int nfields, void *const *ptrs, long row_stride, const void *shift,
+                   int n_move, int Nz, int Nr, void *stream);
+
 /* ---- FFT along z (rocFFT) --------------------------------------------------------- */
 /* fields/spectral_transform/fourier.py:78 (cufft Plan1d) and :116-160.
  * One plan transforms `ncols` columns at once: element (iz, col) lives at

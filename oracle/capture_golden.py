@@ -397,13 +397,51 @@ def cap_bunch():
         save('bunch_' + shape, **res)
 
 
+def cap_lwfa():
+    """"Next" rows: open z boundary + damping, moving window, continuous
+    injection, Gaussian laser initialised on the grid -- a miniature of
+    docs/source/example_input/lwfa_script.py."""
+    from fbpic.main import Simulation
+    from fbpic.lpa_utils.laser import add_laser_pulse, GaussianLaser
+    for shape in ('linear', 'cubic'):
+        Nz, Nr, Nm = 96, 24, 2
+        zmax, zmin, rmax = 12.e-6, -12.e-6, 12.e-6
+        dt = (zmax - zmin) / Nz / c
+        np.random.seed(11)
+        sim = Simulation(Nz, zmax, Nr, rmax, Nm, dt, zmin=zmin,
+                         p_zmin=2.e-6, p_zmax=1., p_rmin=0., p_rmax=10.e-6, p_nz=1, p_nr=2, p_nt=4,
+                         n_e=4.e24, n_order=-1, particle_shape=shape, verbose_level=0,
+                         boundaries={'z': 'open', 'r': 'reflective'}, n_guard=16,
+                         n_damp={'z': 16, 'r': 8}, exchange_period=4)
+        prof = GaussianLaser(a0=1.5, waist=4.e-6, tau=8.e-15, z0=0.e-6, zf=4.e-6,
+                             lambda0=0.8e-6, theta_pol=0.3, cep_phase=0.4)
+        add_laser_pulse(sim, prof)
+        sim.set_moving_window(v=c)
+        res = dict(Nz=Nz, Nr=Nr, Nm=Nm, zmin=zmin, zmax=zmax, rmax=rmax, dt=dt, shape=shape,
+                   Nz_local=sim.fld.Nz, n_guard=sim.comm.n_guard, n_inject=sim.comm.n_inject,
+                   nz_damp=sim.comm.nz_damp)
+        def snap(tag, ptcl=True):
+            res[tag + '_interp'] = np.array([[getattr(sim.fld.interp[m], k) for k in INTERP]
+                                             for m in range(Nm)])
+            res[tag + '_zmin'] = sim.fld.interp[0].zmin
+            if ptcl:
+                res[tag + '_ptcl0'] = np.array([getattr(sim.ptcl[0], k) for k in PTCL[:8]])
+        snap('s0')
+        done = 0
+        for upto in (6, 14):
+            sim.step(upto - done, show_progress=False)
+            done = upto
+            snap('s%d' % upto)
+        save('lwfa_' + shape, **res)
+
+
 def cap_uniform_rho():
     """Counterpart of tests/test_uniform_rho_deposition.py: only the assertion values."""
     # The assertions are analytic (rho = -n e inside the plasma); no fixture needed.
 
 
 ALL = dict(push=cap_push, gather=cap_gather, deposit=cap_deposit, grid_setup=cap_grid_setup,
-           spectral=cap_spectral, cycle=cap_cycle, bunch=cap_bunch)
+           spectral=cap_spectral, cycle=cap_cycle, bunch=cap_bunch, lwfa=cap_lwfa)
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(ALL)

@@ -1,0 +1,74 @@
+""""Next" rows of the scope table: open z boundary with damping, moving
+window, continuous plasma injection and a Gaussian laser initialised on the grid -- a
+miniature of docs/source/example_input/lwfa_script.py, against a trajectory captured from
+the real reference (tests/golden/lwfa_*.npz, oracle/capture_golden.py:cap_lwfa)."""
+import numpy as np
+import pytest
+from scipy.constants import c
+from conftest import golden
+from helpers import INTERP, PTCL
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(shape):
+    from fbpic_amd.main import Simulation
+    from fbpic_amd.lpa_utils.laser import add_laser_pulse, GaussianLaser
+    Nz, Nr, Nm = 96, 24, 2
+    zmax, zmin, rmax = 12.e-6, -12.e-6, 12.e-6
+    dt = (zmax - zmin) / Nz / c
+    np.random.seed(11)
+    sim = Simulation(Nz, zmax, Nr, rmax, Nm, dt, zmin=zmin,
+                     p_zmin=2.e-6, p_zmax=1., p_rmin=0., p_rmax=10.e-6, p_nz=1, p_nr=2, p_nt=4,
+                     n_e=4.e24, n_order=-1, particle_shape=shape,
+                     boundaries={'z': 'open', 'r': 'reflective'}, n_guard=16,
+                     n_damp={'z': 16, 'r': 8}, exchange_period=4)
+    prof = GaussianLaser(a0=1.5, waist=4.e-6, tau=8.e-15, z0=0.e-6, zf=4.e-6,
+                         lambda0=0.8e-6, theta_pol=0.3, cep_phase=0.4)
+    add_laser_pulse(sim, prof)
+    sim.set_moving_window(v=c)
+    return sim
+
+
+def _compare_fields(sim, g, tag, tol, groups=('E', 'B', 'J', 'r')):
+    ref = g[tag + '_interp']
+    for m in range(sim.fld.Nm):
+        for i, k in enumerate(INTERP):
+            if k[0] not in groups:
+                continue
+            grp = [j for j, kk in enumerate(INTERP) if kk[0] == k[0]]
+            scale = np.abs(ref[:, grp]).max()
+            if scale == 0:
+                continue
+            err = np.abs(getattr(sim.fld.interp[m], k) - ref[m, i]).max() / scale
+            assert err < tol, (tag, m, k, err)
+
+
+@pytest.mark.parametrize('shape', ['linear', 'cubic'])
+def test_lwfa_moving_window_vs_reference(shape):
+    g = golden('lwfa_' + shape)
+    sim = _build(shape)
+    assert sim.fld.Nz == int(g['Nz_local']) and sim.comm.n_inject == int(g['n_inject'])
+    assert sim.ptcl[0].Ntot == g['s0_ptcl0'].shape[1]
+    # initial particles are bit-identical (same lattice, same np.random sequence)
+    for j, k in enumerate(PTCL[:8]):
+        assert np.array_equal(getattr(sim.ptcl[0], k), g['s0_ptcl0'][j]), k
+    # laser fields on the grid (device FFT + Hankel, host algebra in spectral space)
+    _compare_fields(sim, g, 's0', 1e-11, groups=('E', 'B'))
+    done = 0
+    for upto, tol in ((6, 1e-9), (14, 1e-8)):
+        sim.step(upto - done)
+        done = upto
+        tag = 's%d' % upto
+        assert sim.fld.interp[0].zmin == float(g[tag + '_zmin'])        # same window motion
+        ref = g[tag + '_ptcl0']
+        s = sim.ptcl[0]
+        assert s.Ntot == ref.shape[1]                                    # same injection/removal
+        _compare_fields(sim, g, tag, tol)
+        got = np.array([getattr(s, k) for k in PTCL[:8]])
+        o1 = np.lexsort((ref[2], ref[1], ref[0], ref[7]))
+        o2 = np.lexsort((got[2], got[1], got[0], got[7]))
+        for j, k in enumerate(PTCL[:8]):
+            sc = np.abs(ref[j]).max()
+            if sc > 0:
+                assert np.abs(got[j][o2] - ref[j][o1]).max() / sc < tol, (tag, k)

@@ -1,0 +1,61 @@
+"""CPU-only checks of the host-side pieces of the "next" rows: Gaussian laser
+profile against its closed form at focus, continuous-injection book-keeping, damping profile.
+(The full open-boundary / moving-window cycle is checked on the GPU against the reference
+trajectory in tests/test_gpu_lwfa.py.)"""
+import numpy as np
+from scipy.constants import c, m_e, e
+
+
+def test_gaussian_laser_closed_form_at_focus():
+    from fbpic_amd.lpa_utils.laser import GaussianLaser
+    a0, w0, tau, z0, lam, cep = 2., 5e-6, 20e-15, 3e-6, 0.8e-6, 0.3
+    prof = GaussianLaser(a0, w0, tau, z0, lambda0=lam, cep_phase=cep, theta_pol=0.)
+    rng = np.random.default_rng(0)
+    x, y = rng.normal(size=50) * 3e-6, rng.normal(size=50) * 3e-6
+    t = 7e-15
+    z = np.full(50, z0)                       # focal plane (zf = z0): no diffraction terms
+    Ex, Ey = prof.E_field(x, y, z, t)
+    k0 = 2 * np.pi / lam
+    E0 = a0 * m_e * c**2 * k0 / e
+    ref = E0 * np.exp(-(x**2 + y**2) / w0**2 - (z - z0 - c * t)**2 / (c * tau)**2) \
+        * np.cos(k0 * (z - z0 - c * t) - cep)
+    assert np.allclose(Ex, ref, rtol=1e-12, atol=1e-6 * E0)
+    assert np.all(Ey == 0.)
+    # polarisation angle splits the same profile between x and y
+    Ex2, Ey2 = GaussianLaser(a0, w0, tau, z0, lambda0=lam, cep_phase=cep, theta_pol=0.7).E_field(x, y, z, t)
+    assert np.allclose(Ex2, np.cos(0.7) * ref, rtol=1e-12, atol=1e-6 * E0)
+    assert np.allclose(Ey2, np.sin(0.7) * ref, rtol=1e-12, atol=1e-6 * E0)
+
+
+def test_continuous_injector_bookkeeping():
+    from fbpic_amd.particles.injection import ContinuousInjector
+    np.random.seed(3)
+    inj = ContinuousInjector(Npz=10, zmin=0., zmax=10e-6, dz_particles=None, Npr=4, rmin=0.,
+                             rmax=4e-6, Nptheta=4, n=1e24, dens_func=None,
+                             ux_m=0., uy_m=0., uz_m=0., ux_th=0., uy_th=0., uz_th=0.)
+    assert abs(inj.dz_particles - 1e-6) < 1e-20 and inj.v_end_plasma == 0.
+    inj.z_inject, inj.z_end_plasma, inj.nz_inject = 10e-6, 10e-6, 0
+    total = 0
+    for _ in range(7):
+        inj.increment_injection_positions(c, 0.8e-6 / c)      # the window advances 0.8 um
+        n, x, y, z, ux, uy, uz, ig, w = inj.generate_particles(0.)
+        total += n
+        assert n % (4 * 4) == 0 and inj.nz_inject == 0
+        if n:
+            assert z.max() < inj.z_end_plasma and z.min() > inj.z_end_plasma - (n // 16 + 1) * 1e-6
+    # 7 * 0.8 um = 5.6 um uncovered -> 5 lattice planes of 16 particles
+    assert total == 5 * 16
+    assert abs(inj.z_end_plasma - 15e-6) < 1e-15
+
+
+def test_damp_profile_matches_reference_formula():
+    from fbpic_amd.boundaries.boundary_communicator import BoundaryCommunicator
+    comm = BoundaryCommunicator(64, 0., 64e-6, 8, 8e-6, 2, 1e-6 / c, None, False,
+                                {'z': 'open', 'r': 'reflective'}, -1, 16, {'z': 16, 'r': 8},
+                                1., None, 4, False)
+    d = comm.left_damp
+    assert d.shape == (16 + 16 + 8,)
+    i = np.arange(40)
+    ref = np.where(i < 24 + 8, np.sin((i - 24) * np.pi / 16.)**2, 1.)
+    ref = np.where(i < 24, 0., ref)
+    assert np.array_equal(d, ref)
