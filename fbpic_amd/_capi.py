@@ -31,6 +31,8 @@ _SIGNATURES = {
     'fb_sort_by_cell': (I, [L, I, P, P, P, P, ctypes.POINTER(I), P, P, Z, P]),
     'fb_bin_sort_workspace_bytes': (Z, [L, I]),
     'fb_bin_sort_particles': (I, [L, I, P, P, P, D, D, I, D, D, I, I, _PP, _PP, P, P, P, P, Z, P]),
+    'fb_push_x_bin_sort_particles': (I, [L, I, P, P, P, P, P, P, P, D, D, D, D, D, D, D, I, D, D, I, I, _PP,
+                                         _PP, P, P, P, P, Z, P]),
     'fb_permute': (I, [L, P, I, _PP, _PP, P]),
     'fb_deposit_rho': (I, [I, I, L, P, P, P, P, D, D, D, I, D, D, I, _PP, L, P, P, P, P, P]),
     'fb_deposit_J': (I, [I, I, L, P, P, P, P, D, P, P, P, P, D, D, D, I, D, D, I, _PP, L,

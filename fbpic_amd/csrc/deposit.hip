@@ -90,19 +90,52 @@ __device__ __forceinline__ void fold_node(int &iz, int &ir, int Nz, int Nr)
 constexpr int DEP_PAD = 65;          // panel row stride in doubles (64 particles + 1)
 constexpr int DEP_NOKEY = -0x40000000;
 
-template <int SHAPE, int NCOMP, int NM>
+// Phase 2 is a small matrix product per cell: out[node][amplitude] = sum over the particles
+// of the cell of W[node][p] * A[amplitude][p].  It runs on the matrix cores with
+// v_mfma_f64_4x4x4_4b_f64: 4 independent blocks of (4 nodes x 4 particles).(4 particles x 4
+// amplitudes), i.e. 16 particles per instruction and 16 cycles per issue, operands taken
+// straight from the staged LDS panels.  Lane layout (measured on gfx950 with
+// tools/mfma4_probe.hip):  A operand lane l = A[i = l&3][k = l>>4] of block (l>>2)&3,
+// B operand lane l = B[k = l>>4][j = l&3] of block (l>>2)&3, D lane l = D[i = l>>4][j = l&3]
+// of block (l>>2)&3.
+//
+// Amplitude rows of the panel: the first mode of the launch, then the others.  When the
+// first mode is m = 0 (Z0) its imaginary parts are identically zero and are not staged.
+// Column tiles of 4 amplitudes never mix mode 0 with modes >= 1 because the two use
+// different radial weights (Ruyten coefficients).
+template <int SHAPE, int NCOMP, int NM, bool Z0>
 struct DepLayout {
     static constexpr int S = ShapeTraits<SHAPE>::S;
-    static constexpr int NW = 2 * S * S;              // weights: [mode0 | modes>=1][jz][jr]
-    static constexpr int NA = NCOMP * NM * 2;         // amplitudes: [comp][mode][re|im]
-    static constexpr int NOUT = S * S * NA;           // outputs of one cell
-    static constexpr int OPL = (NOUT + 63) / 64;      // outputs per lane
+    static constexpr int NPT = S * S;                 // nodes of one cell
+    static constexpr int RG = NPT / 4;                // row groups of 4 nodes
+    static constexpr int NW = 2 * NPT;                // weights: [mode0 | modes>=1][jz][jr]
+    static constexpr int R1 = Z0 ? NCOMP : 2 * NCOMP; // amplitude rows of the first mode
+    static constexpr int T1 = (R1 + 3) / 4;
+    static constexpr int RH = (NM - 1) * NCOMP * 2;   // rows of the other modes
+    static constexpr int TH = (RH + 3) / 4;
+    static constexpr int NT = T1 + TH;                // column tiles
+    static constexpr int NA = 4 * NT;                 // amplitude rows incl. padding
     static constexpr int WAVE_DOUBLES = (NW + NA) * DEP_PAD + 1;
     static constexpr size_t wave_bytes() { return (size_t)WAVE_DOUBLES * 8; }
+    // panel row of amplitude (component k, launch-local mode mm, re/im)
+    __host__ __device__ static constexpr int row(int k, int mm, int ri)
+    {
+        return (mm == 0) ? (Z0 ? k : 2 * k + ri) : 4 * T1 + ((mm - 1) * NCOMP + k) * 2 + ri;
+    }
 };
 
-// NCOMP = 1 (rho) or 3 (Jr,Jt,Jz); this launch handles modes m0 .. m0+NM-1
-template <int SHAPE, int NCOMP, int NM>
+// rotate within rows of 16 lanes (DPP row_ror:N), used to add up the 4 MFMA blocks
+template <int N>
+__device__ __forceinline__ double row_ror(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x120 + N, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x120 + N, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// NCOMP = 1 (rho) or 3 (Jr,Jt,Jz); this launch handles modes m0 .. m0+NM-1; Z0 <=> m0 == 0
+template <int SHAPE, int NCOMP, int NM, bool Z0>
 __global__ __launch_bounds__(256) void k_deposit(long n,
         const double *__restrict__ x, const double *__restrict__ y,
         const double *__restrict__ z, const double *__restrict__ w, double q,
@@ -113,67 +146,94 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
         const double *__restrict__ beta0, const double *__restrict__ betah,
         int chunks_per_wave, unsigned long long *__restrict__ nflush)
 {
-    using L = DepLayout<SHAPE, NCOMP, NM>;
+    using L = DepLayout<SHAPE, NCOMP, NM, Z0>;
     constexpr int S = L::S, H = ShapeTraits<SHAPE>::H;
-    constexpr int NW = L::NW, NA = L::NA, NOUT = L::NOUT, OPL = L::OPL;
+    constexpr int NPT = L::NPT, RG = L::RG, NW = L::NW, NT = L::NT, T1 = L::T1;
+    constexpr bool NEED_W0 = Z0, NEED_WH = (!Z0) || (NM > 1);
     extern __shared__ double lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    // wave index as a scalar: every loop bound below is then wave-uniform for the compiler
+    const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double *Wl = lds + (size_t)wave * L::WAVE_DOUBLES;
     double *Al = Wl + NW * DEP_PAD;
 
-    // When a cell has few output values (rho: 16 for the linear shape, Nm = 2) the wave is
-    // split into NSUB groups of NP2 lanes; group g accumulates particles g, g+NSUB, ... of a
-    // run and the groups are summed with xor-shuffles at the end of the run.
-    constexpr int NP2 = (NOUT <= 16) ? 16 : (NOUT <= 32) ? 32 : 64;
-    constexpr int NSUB = (OPL == 1) ? 64 / NP2 : 1;
-    const int sub = (NSUB > 1) ? lane / NP2 : 0;
-    // decode the outputs owned by this lane: o = lane + 64 j -> (jz, jr, comp, mode, re/im)
-    int o_w0[OPL], o_wh[OPL], o_a[OPL], o_jr[OPL], o_jz[OPL], o_km[OPL];
-    double o_sgn[OPL];
-    bool o_ok[OPL], o_m0[OPL];
+    const int jl = lane & 3, bl = (lane >> 2) & 3, kl = lane >> 4;
+    const int poff = 4 * bl + kl;          // particle (within a group of 16) fed by this lane
+    // Accumulator tile u = rg * NT + t holds, in lane l, node rg*4 + kl x amplitude row 4t + jl
+    // of block bl.  At a flush the 4 blocks are added (row rotations) and the lanes of block b
+    // write tile 4 q + b in round q: one atomic instruction per 4 tiles.
+    constexpr int NTILE = RG * NT, NQ = (NTILE + 3) / 4;
+    double *f_ptr[NQ];          // grid base of this lane's amplitude (re or im part)
+    double f_sgn[NQ];
+    int f_jz[NQ], f_jr[NQ];
+    bool f_ok[NQ];
 #pragma unroll
-    for (int j = 0; j < OPL; j++) {
-        int o = (NSUB > 1) ? (lane % NP2) : (lane + 64 * j);
-        o_ok[j] = o < NOUT;
-        if (!o_ok[j]) o = 0;
-        const int ri = o & 1;
-        int t = o >> 1;
-        const int mm = t % NM; t /= NM;
-        const int k = t % NCOMP; t /= NCOMP;
-        const int jr = t % S, jz = t / S;
+    for (int qq = 0; qq < NQ; qq++) {
+        const int u = 4 * qq + bl;
+        const int rg = u / NT, t = u % NT;
+        int k, mm, ri;
+        bool ok = u < NTILE;
+        if (t < T1) {
+            const int idx = 4 * t + jl;
+            ok = ok && idx < L::R1;
+            mm = 0;
+            if (Z0) { k = idx; ri = 0; } else { k = idx >> 1; ri = idx & 1; }
+        } else {
+            const int idx = 4 * (t - T1) + jl;
+            ok = ok && idx < L::RH;
+            ri = idx & 1;
+            k = (idx >> 1) % NCOMP;
+            mm = 1 + (idx >> 1) / NCOMP;
+        }
+        if (!ok) { k = 0; mm = 0; ri = 0; }
         const int m = m0 + mm;
-        o_m0[j] = (m == 0);
-        o_w0[j] = (jz * S + jr) * DEP_PAD;
-        o_wh[j] = ((S + jz) * S + jr) * DEP_PAD;
-        o_a[j] = ((k * NM + mm) * 2 + ri) * DEP_PAD;
-        o_jr[j] = jr; o_jz[j] = jz;
-        o_km[j] = (k + NCOMP * m) * 2 + ri;
+        f_ok[qq] = ok;
+        f_ptr[qq] = (double *)G.g[k + NCOMP * m] + ri;
         // rho, Jz: (-1)^m ; Jr, Jt: -(-1)^m (threading_methods.py:143-146, 289-302)
         const double flip = m1pow(m);
-        o_sgn[j] = (NCOMP == 1 || k == 2) ? flip : -flip;
+        f_sgn[qq] = (NCOMP == 1 || k == 2) ? flip : -flip;
+        const int pt = (rg % RG) * 4 + kl;
+        f_jz[qq] = pt / S; f_jr[qq] = pt % S;
     }
 
-    double acc[OPL], acc2[OPL];
+    double acc[RG][NT];
 #pragma unroll
-    for (int j = 0; j < OPL; j++) { acc[j] = 0.; acc2[j] = 0.; }
-    int cur_z = DEP_NOKEY, cur_r = DEP_NOKEY;
+    for (int rg = 0; rg < RG; rg++)
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[rg][t] = 0.;
+    int cur_z = DEP_NOKEY, cur_r = DEP_NOKEY, cur_nb = 0;
     unsigned int my_flushes = 0;      // wave-uniform: runs of equal cells seen by this wave
 
-    // With the linear shape and one output per lane, two cells that follow each other along
-    // r share one node column: its partial sums slide to the lanes of the lower column
-    // instead of being flushed, halving the atomics of an r-ordered stream.
-    constexpr bool SLIDE = (SHAPE == FB_SHAPE_LINEAR) && (OPL == 1) && (2 * S * NA <= 64);
-    auto flush = [&](bool lower_column_only) {
+    // With the linear shape, two cells that follow each other along r share one node column.
+    // Its partial sums are not flushed: the accumulator lanes of that column simply become
+    // the lower column of the new cell (`par` swaps which radial weight feeds which lane),
+    // halving the atomics of an r-ordered stream.
+    constexpr bool SLIDE = (SHAPE == FB_SHAPE_LINEAR);
+    int par = 0;                      // linear shape: logical jr of a lane = (kl & 1) ^ par
+    // flush the finished cell; keep_upper: only its lower node column (the upper one carries on)
+    auto flush = [&](bool keep_upper) {
         if (cur_z == DEP_NOKEY) return;
         my_flushes++;
 #pragma unroll
-        for (int j = 0; j < OPL; j++) {
-            if (!o_ok[j] || acc[j] == 0. || sub != 0) continue;
-            if (lower_column_only && o_jr[j] != 0) continue;
-            int gz = cur_z + o_jz[j], gr = cur_r + o_jr[j];
+        for (int qq = 0; qq < NQ; qq++) {
+            // add the 4 blocks of each tile, then keep the tile this lane writes in this round
+            double v = 0.;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int u = 4 * qq + b;
+                if (u < NTILE) {
+                    double a = acc[u / NT][u % NT];
+                    a += row_ror<4>(a);
+                    a += row_ror<8>(a);
+                    v = (bl == b) ? a : v;
+                }
+            }
+            const int jr = SLIDE ? (f_jr[qq] ^ par) : f_jr[qq];
+            if (!f_ok[qq] || v == 0. || (keep_upper && jr != 0)) continue;
+            int gz = cur_z + f_jz[qq], gr = cur_r + jr;
             fold_node(gz, gr, Nz, Nr);
-            double *g = (double *)(G.g[o_km[j] >> 1] + (long)gz * rs + gr) + (o_km[j] & 1);
-            atomicAdd(g, acc[j]);
+            if (jr < cur_nb) v *= f_sgn[qq];            // node below the axis: signed fold
+            atomicAdd(f_ptr[qq] + 2 * ((long)gz * rs + gr), v);
         }
     };
 
@@ -215,19 +275,21 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
                 are[2] = wj * c_light * ig * pc[6]; aim[2] = 0.;
             }
             // mode recurrence (cos + i sin)^m, threading_methods.py:119-121, 264-267
-            for (int m = 0; m < m0; m++) {
+            if constexpr (!Z0) {
+                for (int m = 0; m < m0; m++) {
 #pragma unroll
-                for (int k = 0; k < NCOMP; k++) {
-                    double re = cs * are[k] - sn * aim[k], im = cs * aim[k] + sn * are[k];
-                    are[k] = re; aim[k] = im;
+                    for (int k = 0; k < NCOMP; k++) {
+                        double re = cs * are[k] - sn * aim[k], im = cs * aim[k] + sn * are[k];
+                        are[k] = re; aim[k] = im;
+                    }
                 }
             }
 #pragma unroll
             for (int mm = 0; mm < NM; mm++) {
 #pragma unroll
                 for (int k = 0; k < NCOMP; k++) {
-                    Al[((k * NM + mm) * 2 + 0) * DEP_PAD + lane] = are[k];
-                    Al[((k * NM + mm) * 2 + 1) * DEP_PAD + lane] = aim[k];
+                    Al[L::row(k, mm, 0) * DEP_PAD + lane] = are[k];
+                    if (!(Z0 && mm == 0)) Al[L::row(k, mm, 1) * DEP_PAD + lane] = aim[k];
                     double re = cs * are[k] - sn * aim[k], im = cs * aim[k] + sn * are[k];
                     are[k] = re; aim[k] = im;
                 }
@@ -241,23 +303,27 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
             const int ir_ruy = min(icr, Nr);
             double Sz[S], Sr0[S], Srh[S];
             shape_z<SHAPE>(z_cell, Sz);
-            shape_r<SHAPE>(r_cell, beta0[ir_ruy], Sr0);
-            shape_r<SHAPE>(r_cell, betah[ir_ruy], Srh);
+            if constexpr (NEED_W0) shape_r<SHAPE>(r_cell, beta0[ir_ruy], Sr0);
+            if constexpr (NEED_WH) shape_r<SHAPE>(r_cell, betah[ir_ruy], Srh);
 #pragma unroll
             for (int jz = 0; jz < S; jz++)
 #pragma unroll
                 for (int jr = 0; jr < S; jr++) {
-                    Wl[(jz * S + jr) * DEP_PAD + lane] = Sz[jz] * Sr0[jr];
-                    Wl[((S + jz) * S + jr) * DEP_PAD + lane] = Sz[jz] * Srh[jr];
+                    if constexpr (NEED_W0) Wl[(jz * S + jr) * DEP_PAD + lane] = Sz[jz] * Sr0[jr];
+                    if constexpr (NEED_WH) Wl[(NPT + jz * S + jr) * DEP_PAD + lane] = Sz[jz] * Srh[jr];
                 }
             // number of stencil columns below the axis: index + (icr - H) < 0
             my_nb = H - icr;
+        } else {
+            // tail of the stream: finite amplitudes for the (masked) matrix operands
+#pragma unroll
+            for (int a = 0; a < L::NA; a++) Al[a * DEP_PAD + lane] = 0.;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // ---- phase 2: lane = output value.  Segment boundaries (first particle of a new
-        // cell) are found with one ballot; each segment is a branch-free register
-        // accumulation over its staged particles.
+        // ---- phase 2: runs of equal cells (boundaries found with one ballot) are reduced on
+        // the matrix cores, 16 staged particles per instruction; particles of a group that
+        // belong to another run are masked out of the weight operand.
         const int cnt = (int)min((long)64, n - base);
         const int prev_kz = __shfl_up(my_kz, 1), prev_kr = __shfl_up(my_kr, 1);
         bool is_start = (lane == 0) ? (my_kz != cur_z || my_kr != cur_r)
@@ -268,87 +334,56 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
             if ((starts >> p) & 1ull) {
                 const int nz_ = __builtin_amdgcn_readlane(my_kz, p);
                 const int nr_ = __builtin_amdgcn_readlane(my_kr, p);
-#pragma unroll
-                for (int j = 0; j < OPL; j++) { acc[j] += acc2[j]; acc2[j] = 0.; }
-                if constexpr (NSUB > 1) {
-#pragma unroll
-                    for (int d = NP2; d < 64; d <<= 1) acc[0] += __shfl_xor(acc[0], d);
-                }
                 if (SLIDE && nz_ == cur_z && nr_ == cur_r + 1) {
                     flush(true);                     // column cur_r is complete
-                    const double up = __shfl_down(acc[0], NA);   // column cur_r+1 carries on
-                    acc[0] = (o_jr[0] == 0 && sub == 0) ? up : 0.;
+                    const bool upper = ((kl & 1) ^ par) != 0;   // carries on as the lower column
+#pragma unroll
+                    for (int t = 0; t < NT; t++) acc[0][t] = upper ? acc[0][t] : 0.;
+                    par ^= 1;
                 } else {
                     flush(false);
 #pragma unroll
-                    for (int j = 0; j < OPL; j++) acc[j] = 0.;
+                    for (int rg = 0; rg < RG; rg++)
+#pragma unroll
+                        for (int t = 0; t < NT; t++) acc[rg][t] = 0.;
+                    par = 0;
                 }
                 cur_z = nz_;
                 cur_r = nr_;
+                cur_nb = __builtin_amdgcn_readlane(my_nb, p);
             }
             const unsigned long long rest = (p + 1 < 64) ? (starts >> (p + 1)) : 0ull;
             int e = rest ? p + 1 + __builtin_ctzll(rest) : cnt;
             if (e > cnt) e = cnt;
-            if (cur_r >= 0) {                       // no node of this cell is below the axis
-                if constexpr (NSUB > 1) {
-                    // group `sub` takes particles p+sub, p+sub+NSUB, ...; two chains
-                    int q = p + sub;
-                    for (; q + NSUB < e; q += 2 * NSUB) {
-                        const double *wp = Wl + (o_m0[0] ? o_w0[0] : o_wh[0]) + q;
-                        const double *ap = Al + o_a[0] + q;
-                        const double w0 = wp[0], w1 = wp[NSUB], a0 = ap[0], a1 = ap[NSUB];
-                        acc[0] = __builtin_fma(w0, a0, acc[0]);
-                        acc2[0] = __builtin_fma(w1, a1, acc2[0]);
-                    }
-                    if (q < e) {
-                        const double wv = o_m0[0] ? Wl[o_w0[0] + q] : Wl[o_wh[0] + q];
-                        acc[0] = __builtin_fma(wv, Al[o_a[0] + q], acc[0]);
-                    }
-                    p = e;
-                } else {
-                // 4 particles per trip, two accumulator chains: all 8 LDS reads are in
-                // flight before the first FMA, and the fp64 FMA latency is overlapped
-                for (; p + 4 <= e; p += 4) {
+            const int g1 = (e - 1) >> 4;
+            // weight rows fed by this lane: node rg*4 + jl (linear: its column follows `par`)
+            const int wrow = SLIDE ? (jl ^ par) : jl;
+            for (int g = p >> 4; g <= g1; g++) {
+                const int pi = 16 * g + poff;
+                const bool in = (pi >= p) && (pi < e);
+                double w0[RG], wh[RG];
 #pragma unroll
-                    for (int j = 0; j < OPL; j++) {
-                        const double *wp = Wl + (o_m0[j] ? o_w0[j] : o_wh[j]) + p;
-                        const double *ap = Al + o_a[j] + p;
-                        const double w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
-                        const double a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];
-                        acc[j] = __builtin_fma(w0, a0, acc[j]);
-                        acc2[j] = __builtin_fma(w1, a1, acc2[j]);
-                        acc[j] = __builtin_fma(w2, a2, acc[j]);
-                        acc2[j] = __builtin_fma(w3, a3, acc2[j]);
-                    }
+                for (int rg = 0; rg < RG; rg++) {
+                    if constexpr (NEED_W0) { const double v = Wl[(rg * 4 + wrow) * DEP_PAD + pi]; w0[rg] = in ? v : 0.; }
+                    if constexpr (NEED_WH) { const double v = Wl[(NPT + rg * 4 + wrow) * DEP_PAD + pi]; wh[rg] = in ? v : 0.; }
                 }
-                for (; p < e; p++) {
 #pragma unroll
-                    for (int j = 0; j < OPL; j++) {
-                        const double wv = o_m0[j] ? Wl[o_w0[j] + p] : Wl[o_wh[j] + p];
-                        acc[j] = __builtin_fma(wv, Al[o_a[j] + p], acc[j]);
-                    }
-                }
-                }
-            } else {
-                for (; p < e; p++) {
-                    const int nb = __builtin_amdgcn_readlane(my_nb, p);
+                for (int t = 0; t < NT; t++) {
+                    const double av = Al[(4 * t + jl) * DEP_PAD + pi];
 #pragma unroll
-                    for (int j = 0; j < OPL; j++) {
-                        double wv = o_m0[j] ? Wl[o_w0[j] + p] : Wl[o_wh[j] + p];
-                        if (o_jr[j] < nb) wv *= o_sgn[j];
-                        if (sub == 0) acc[j] = __builtin_fma(wv, Al[o_a[j] + p], acc[j]);
+                    for (int rg = 0; rg < RG; rg++) {
+                        double wv;
+                        if constexpr (!NEED_WH) wv = w0[rg];
+                        else if constexpr (!NEED_W0) wv = wh[rg];
+                        else wv = (t < T1) ? w0[rg] : wh[rg];
+                        acc[rg][t] = __builtin_amdgcn_mfma_f64_4x4x4f64(wv, av, acc[rg][t], 0, 0, 0);
                     }
                 }
             }
+            p = e;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-    }
-#pragma unroll
-    for (int j = 0; j < OPL; j++) acc[j] += acc2[j];
-    if constexpr (NSUB > 1) {
-#pragma unroll
-        for (int d = NP2; d < 64; d <<= 1) acc[0] += __shfl_xor(acc[0], d);
     }
     flush(false);
     // fragmentation statistic for the host's sort policy: 1024 counters (same-address
@@ -357,14 +392,14 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
         atomicAdd(nflush + ((blockIdx.x * nwaves + wave) & 1023), (unsigned long long)my_flushes);
 }
 
-template <int SHAPE, int NCOMP, int NM>
-static int launch_one(long n, const double *x, const double *y, const double *z, const double *w,
+template <int SHAPE, int NCOMP, int NM, bool Z0>
+static int launch_z(long n, const double *x, const double *y, const double *z, const double *w,
         double q, const double *ux, const double *uy, const double *uz, const double *ig,
         double c, double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
         const DepGrids &G, long rs, int m0, const double *b0, const double *bh,
         unsigned long long *nflush, hipStream_t s)
 {
-    using L = DepLayout<SHAPE, NCOMP, NM>;
+    using L = DepLayout<SHAPE, NCOMP, NM, Z0>;
     // waves per workgroup: keep the LDS panel <= 64 KiB
     int nwaves = 4;
     while (nwaves > 1 && L::wave_bytes() * nwaves > 64 * 1024) nwaves >>= 1;
@@ -377,11 +412,25 @@ static int launch_one(long n, const double *x, const double *y, const double *z,
     if (cpw > 64) cpw = 64;
     const long total_waves = (nchunks + cpw - 1) / cpw;
     const long nblocks = (total_waves + nwaves - 1) / nwaves;
-    auto kern = k_deposit<SHAPE, NCOMP, NM>;
+    auto kern = k_deposit<SHAPE, NCOMP, NM, Z0>;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(64 * nwaves),
                        L::wave_bytes() * nwaves, s, n, x, y, z, w, q, ux, uy, uz, ig, c,
                        invdz, zmin, Nz, invdr, rmin, Nr, G, rs, m0, b0, bh, cpw, (m0 == 0) ? nflush : nullptr);
     return check(hipGetLastError(), "fb_deposit");
+}
+
+template <int SHAPE, int NCOMP, int NM>
+static int launch_one(long n, const double *x, const double *y, const double *z, const double *w,
+        double q, const double *ux, const double *uy, const double *uz, const double *ig,
+        double c, double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
+        const DepGrids &G, long rs, int m0, const double *b0, const double *bh,
+        unsigned long long *nflush, hipStream_t s)
+{
+    if (m0 == 0)
+        return launch_z<SHAPE, NCOMP, NM, true>(n, x, y, z, w, q, ux, uy, uz, ig, c, invdz, zmin,
+                Nz, invdr, rmin, Nr, G, rs, m0, b0, bh, nflush, s);
+    return launch_z<SHAPE, NCOMP, NM, false>(n, x, y, z, w, q, ux, uy, uz, ig, c, invdz, zmin,
+            Nz, invdr, rmin, Nr, G, rs, m0, b0, bh, nflush, s);
 }
 
 template <int SHAPE, int NCOMP>

@@ -77,8 +77,18 @@ __global__ __launch_bounds__(256) void k_permute(long n, const int *__restrict__
 //   k_scatter  : every attribute is written to prefix_sum[c-1] + rank in ONE launch.
 // The order of particles inside a cell is the arrival order of the runs (not the original
 // order as with the stable radix sort); deposition and gather do not depend on it.
+// Optional position push folded into the sort (fb_push_x_bin_sort_particles): the rank pass
+// evaluates the pushed position in registers, the scatter pass evaluates it again (same
+// expression as k_push_x, particles.hip) and writes it at the sorted slot, so the stand-alone
+// push_x sweep (56 B read + 24 B written per particle) disappears.
+struct PushX {
+    const double *ux, *uy, *uz, *ig;
+    double chdt, px, py, pz;
+};
+
+template <bool PUSH>
 __global__ __launch_bounds__(256) void k_bin_rank(long n, const double *__restrict__ x,
-        const double *__restrict__ y, const double *__restrict__ z,
+        const double *__restrict__ y, const double *__restrict__ z, PushX P,
         double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
         int *__restrict__ cell, int *__restrict__ rank, int *__restrict__ count)
 {
@@ -91,7 +101,13 @@ __global__ __launch_bounds__(256) void k_bin_rank(long n, const double *__restri
         const bool act = i < n;
         int c = -1;
         if (act) {
-            const double xj = x[i], yj = y[i], zj = z[i];
+            double xj = x[i], yj = y[i], zj = z[i];
+            if constexpr (PUSH) {
+                const double g = P.ig[i];
+                xj += P.chdt * g * P.px * P.ux[i];
+                yj += P.chdt * g * P.py * P.uy[i];
+                zj += P.chdt * g * P.pz * P.uz[i];
+            }
             const double rj = sqrt(xj * xj + yj * yj);
             const double r_cell = invdr * (rj - rmin) - 0.5;
             const double z_cell = invdz * (zj - zmin) - 0.5;
@@ -124,15 +140,22 @@ __global__ __launch_bounds__(256) void k_bin_rank(long n, const double *__restri
     }
 }
 
+template <bool PUSH>
 __global__ __launch_bounds__(256) void k_scatter(long n, const int *__restrict__ cell,
         const int *__restrict__ rank, const int *__restrict__ prefix, int nattr, CPtrs16 src,
-        Ptrs16 dst, int *__restrict__ cell_sorted, int *__restrict__ sorted_idx)
+        Ptrs16 dst, PushX P, int *__restrict__ cell_sorted, int *__restrict__ sorted_idx)
 {
     long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const int c = cell[i];
         const int d = (c > 0 ? prefix[c - 1] : 0) + rank[i];
-        for (int k = 0; k < nattr; k++) dst.p[k][d] = src.p[k][i];
+        if constexpr (PUSH) {      // attributes 0..2 are x, y, z
+            const double g = P.ig[i];
+            dst.p[0][d] = src.p[0][i] + P.chdt * g * P.px * P.ux[i];
+            dst.p[1][d] = src.p[1][i] + P.chdt * g * P.py * P.uy[i];
+            dst.p[2][d] = src.p[2][i] + P.chdt * g * P.pz * P.uz[i];
+        }
+        for (int k = PUSH ? 3 : 0; k < nattr; k++) dst.p[k][d] = src.p[k][i];
         cell_sorted[d] = c;
         sorted_idx[d] = (int)i;
     }
@@ -240,17 +263,20 @@ extern "C" size_t fb_bin_sort_workspace_bytes(long n, int ncell)
            + align_up(scan_temp_bytes(ncell), 256) + 256;
 }
 
-extern "C" int fb_bin_sort_particles(long n, int ncell, const double *x, const double *y,
-        const double *z, double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
-        int nattr, const double *const *src, double *const *dst,
-        int *cell_idx_sorted, int *sorted_idx, int *prefix_sum,
-        void *workspace, size_t workspace_bytes, void *stream)
+static int bin_sort_impl(const char *who, bool push, const PushX &P, long n, int ncell,
+        const double *x, const double *y, const double *z, double invdz, double zmin, int Nz,
+        double invdr, double rmin, int Nr, int nattr, const double *const *src,
+        double *const *dst, int *cell_idx_sorted, int *sorted_idx, int *prefix_sum,
+        void *workspace, size_t workspace_bytes, hipStream_t s)
 {
-    hipStream_t s = (hipStream_t)stream;
-    if (nattr < 0 || nattr > 16) { set_error("fb_bin_sort_particles", "nattr > 16"); return -1; }
-    if (ncell != Nz * (Nr + 1)) { set_error("fb_bin_sort_particles", "ncell != Nz*(Nr+1)"); return -1; }
+    if (nattr < 0 || nattr > 16) { set_error(who, "nattr > 16"); return -1; }
+    if (ncell != Nz * (Nr + 1)) { set_error(who, "ncell != Nz*(Nr+1)"); return -1; }
     if (workspace_bytes < fb_bin_sort_workspace_bytes(n, ncell)) {
-        set_error("fb_bin_sort_particles", "workspace too small");
+        set_error(who, "workspace too small");
+        return -1;
+    }
+    if (push && n > 0 && (nattr < 3 || src[0] != x || src[1] != y || src[2] != z)) {
+        set_error(who, "src[0..2] must be x, y, z");
         return -1;
     }
     char *ws = (char *)workspace;
@@ -262,22 +288,58 @@ extern "C" int fb_bin_sort_particles(long n, int ncell, const double *x, const d
     void *temp = ws;
     size_t temp_bytes = workspace_bytes - (size_t)(ws - (char *)workspace);
     hipError_t e = hipMemsetAsync(count, 0, (size_t)ncell * sizeof(int), s);
-    if (e != hipSuccess) return check(e, "fb_bin_sort_particles(memset)");
+    if (e != hipSuccess) return check(e, who);
     if (n > 0) {
-        hipLaunchKernelGGL(k_bin_rank, dim3(stream_grid(n, 256, 256 * 16)), dim3(256), 0, s, n, x, y,
-                           z, invdz, zmin, Nz, invdr, rmin, Nr, cell, rank, count);
-        int r = check(hipGetLastError(), "fb_bin_sort_particles(rank)");
+        const dim3 grid(stream_grid(n, 256, 256 * 16));
+        if (push)
+            hipLaunchKernelGGL(k_bin_rank<true>, grid, dim3(256), 0, s, n, x, y, z, P, invdz, zmin,
+                               Nz, invdr, rmin, Nr, cell, rank, count);
+        else
+            hipLaunchKernelGGL(k_bin_rank<false>, grid, dim3(256), 0, s, n, x, y, z, P, invdz, zmin,
+                               Nz, invdr, rmin, Nr, cell, rank, count);
+        int r = check(hipGetLastError(), who);
         if (r) return r;
     }
     e = rocprim::inclusive_scan(temp, temp_bytes, count, prefix_sum, (size_t)ncell,
                                 rocprim::plus<int>(), s, false);
-    if (e != hipSuccess) return check(e, "fb_bin_sort_particles(scan)");
+    if (e != hipSuccess) return check(e, who);
     if (n > 0) {
         CPtrs16 a;
         Ptrs16 b;
         for (int k = 0; k < 16; k++) { a.p[k] = k < nattr ? src[k] : nullptr; b.p[k] = k < nattr ? dst[k] : nullptr; }
-        hipLaunchKernelGGL(k_scatter, dim3(stream_grid(n)), dim3(256), 0, s, n, cell, rank,
-                           prefix_sum, nattr, a, b, cell_idx_sorted, sorted_idx);
+        if (push)
+            hipLaunchKernelGGL(k_scatter<true>, dim3(stream_grid(n)), dim3(256), 0, s, n, cell, rank,
+                               prefix_sum, nattr, a, b, P, cell_idx_sorted, sorted_idx);
+        else
+            hipLaunchKernelGGL(k_scatter<false>, dim3(stream_grid(n)), dim3(256), 0, s, n, cell, rank,
+                               prefix_sum, nattr, a, b, P, cell_idx_sorted, sorted_idx);
     }
-    FB_CHECK_LAUNCH("fb_bin_sort_particles");
+    FB_CHECK_LAUNCH(who);
+}
+
+extern "C" int fb_bin_sort_particles(long n, int ncell, const double *x, const double *y,
+        const double *z, double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
+        int nattr, const double *const *src, double *const *dst,
+        int *cell_idx_sorted, int *sorted_idx, int *prefix_sum,
+        void *workspace, size_t workspace_bytes, void *stream)
+{
+    PushX P = {nullptr, nullptr, nullptr, nullptr, 0., 0., 0., 0.};
+    return bin_sort_impl("fb_bin_sort_particles", false, P, n, ncell, x, y, z, invdz, zmin, Nz,
+                         invdr, rmin, Nr, nattr, src, dst, cell_idx_sorted, sorted_idx, prefix_sum,
+                         workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int fb_push_x_bin_sort_particles(long n, int ncell, const double *x, const double *y,
+        const double *z, const double *ux, const double *uy, const double *uz,
+        const double *inv_gamma, double c, double dt, double x_push, double y_push,
+        double z_push, double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
+        int nattr, const double *const *src, double *const *dst,
+        int *cell_idx_sorted, int *sorted_idx, int *prefix_sum,
+        void *workspace, size_t workspace_bytes, void *stream)
+{
+    // fbpic/particles/push/numba_methods.py:24-30: chdt = c * dt
+    PushX P = {ux, uy, uz, inv_gamma, c * dt, x_push, y_push, z_push};
+    return bin_sort_impl("fb_push_x_bin_sort_particles", true, P, n, ncell, x, y, z, invdz, zmin,
+                         Nz, invdr, rmin, Nr, nattr, src, dst, cell_idx_sorted, sorted_idx,
+                         prefix_sum, workspace, workspace_bytes, (hipStream_t)stream);
 }

@@ -186,9 +186,12 @@ class Simulation(object):
                 species.keep_fields_sorted = False
             self.deposit('J', exchange=(correct_currents is False))
             if move_positions:
+                # deferred: the push is folded into the sort that deposit('rho_next') triggers
                 for species in ptcl:
-                    species.push_x(0.5 * dt)
+                    species.push_x(0.5 * dt, defer=True)
             self.deposit('rho_next', exchange=(use_true_rho is True))
+            for species in ptcl:
+                species.flush_pending_push()      # species that did not deposit
             if self.comm.size == 1:
                 # single domain: correction, push and rho shift are cell-local -> one launch
                 fld.psatd_step(correct_currents, use_true_rho)

@@ -58,6 +58,7 @@ class Particles(object):
         self.grid_shape = grid_shape
         self.prefix_sum_shift = 0
         self.sorted = False
+        self._pending_push = None     # deferred push_x (dt, x_push, y_push, z_push)
         # Sort policy.  The reference re-sorts before every deposit that follows a push_x.
         # The HIP deposition does not need an exact sort (it accumulates runs of equal
         # cells), so a re-sort is only worth its cost once the particles have moved far
@@ -172,18 +173,39 @@ class Particles(object):
                                    p(self.Bz), self.q, self.m, c, self.dt, _capi.stream())
         _capi.check(rc, 'fb_push_p')
 
-    def push_x(self, dt, x_push=1., y_push=1., z_push=1.):
-        """x += c dt inv_gamma push u (reference :639-671); invalidates the cell sort."""
+    def push_x(self, dt, x_push=1., y_push=1., z_push=1., defer=False):
+        """x += c dt inv_gamma push u (reference :639-671); invalidates the cell sort.
+        With `defer` the push is not launched: it is folded into the sort of the next
+        `deposit` (fb_push_x_bin_sort_particles), or launched by `flush_pending_push`,
+        whichever comes first.  Simulation.step uses it for the half push that precedes
+        deposit('rho_next'), main.py:519-528."""
         self._need_gpu()
+        self.flush_pending_push()
+        if defer and self.use_bin_sort:
+            self._pending_push = (dt, x_push, y_push, z_push)
+            self._note_push(dt, max(abs(x_push), abs(y_push), abs(z_push)))
+            return
+        self._launch_push_x(dt, x_push, y_push, z_push)
+        self._note_push(dt, max(abs(x_push), abs(y_push), abs(z_push)))
+
+    def flush_pending_push(self):
+        """Launch a deferred push_x now (no-op if none is pending)."""
+        pend = self._pending_push
+        if pend is not None:
+            self._pending_push = None
+            self._launch_push_x(*pend)
+
+    def _note_push(self, dt, push):
+        self.sorted = False
+        dmin = min(self._cell_size) if self._cell_size else 0.
+        self._moved_since_sort += (c * abs(dt) * push / dmin if dmin > 0 else np.inf)
+
+    def _launch_push_x(self, dt, x_push, y_push, z_push):
         p = _capi.ptr
         rc = _capi.lib().fb_push_x(self.Ntot, p(self.x), p(self.y), p(self.z), p(self.ux),
                                    p(self.uy), p(self.uz), p(self.inv_gamma), c, dt,
                                    x_push, y_push, z_push, _capi.stream())
         _capi.check(rc, 'fb_push_x')
-        self.sorted = False
-        dmin = min(self._cell_size) if self._cell_size else 0.
-        self._moved_since_sort += (c * abs(dt) * max(abs(x_push), abs(y_push), abs(z_push)) / dmin
-                                   if dmin > 0 else np.inf)
 
     # ---------------------------------------------------------------- gather
     def gather(self, grid, comm):
@@ -191,6 +213,7 @@ class Particles(object):
         if self.q == 0:
             return
         self._need_gpu()
+        self.flush_pending_push()
         Nm = len(grid)
         rmax_gather = comm.get_rmax(with_damp=False)
         g0 = grid[0]
@@ -211,6 +234,7 @@ class Particles(object):
         the three consecutive calls of Simulation.step (main.py:469-490).  Results are
         identical to calling gather(), push_p(), push_x(dt_x) one after the other."""
         self._need_gpu()
+        self.flush_pending_push()
         if self.q == 0:
             self.push_x(dt_x)
             return
@@ -246,12 +270,25 @@ class Particles(object):
             names = list(_STATE) + (list(_FIELDS) if self.keep_fields_sorted else [])
             src = [getattr(self, k) for k in names]
             dst = self._alt[:len(names)]
-            rc = lib.fb_bin_sort_particles(
-                self.Ntot, self.prefix_sum.shape[0], p(self.x), p(self.y), p(self.z),
-                g0.invdz, g0.zmin, g0.Nz, g0.invdr, g0.rmin, g0.Nr, len(names),
-                _capi.ptr_array(src), _capi.ptr_array(dst), p(self.cell_idx), p(self.sorted_idx),
-                p(self.prefix_sum), p(self._sort_ws), self._sort_ws.shape[0], st)
-            _capi.check(rc, 'fb_bin_sort_particles')
+            pend, self._pending_push = self._pending_push, None
+            if pend is not None:
+                # the deferred push_x rides along: positions are written once, sorted
+                rc = lib.fb_push_x_bin_sort_particles(
+                    self.Ntot, self.prefix_sum.shape[0], p(self.x), p(self.y), p(self.z),
+                    p(self.ux), p(self.uy), p(self.uz), p(self.inv_gamma), c, pend[0], pend[1],
+                    pend[2], pend[3], g0.invdz, g0.zmin, g0.Nz, g0.invdr, g0.rmin, g0.Nr,
+                    len(names), _capi.ptr_array(src), _capi.ptr_array(dst), p(self.cell_idx),
+                    p(self.sorted_idx), p(self.prefix_sum), p(self._sort_ws),
+                    self._sort_ws.shape[0], st)
+                _capi.check(rc, 'fb_push_x_bin_sort_particles')
+            else:
+                rc = lib.fb_bin_sort_particles(
+                    self.Ntot, self.prefix_sum.shape[0], p(self.x), p(self.y), p(self.z),
+                    g0.invdz, g0.zmin, g0.Nz, g0.invdr, g0.rmin, g0.Nr, len(names),
+                    _capi.ptr_array(src), _capi.ptr_array(dst), p(self.cell_idx),
+                    p(self.sorted_idx), p(self.prefix_sum), p(self._sort_ws),
+                    self._sort_ws.shape[0], st)
+                _capi.check(rc, 'fb_bin_sort_particles')
             for i, k in enumerate(names):
                 setattr(self, k, dst[i])
                 self._alt[i] = src[i]
@@ -260,6 +297,7 @@ class Particles(object):
             self._cell_size = (g0.dz, g0.dr)
             self._moved_since_sort = 0.
             return
+        self.flush_pending_push()
         rc = lib.fb_cell_index(self.Ntot, p(self.x), p(self.y), p(self.z), g0.invdz, g0.zmin,
                                g0.Nz, g0.invdr, g0.rmin, g0.Nr, p(self.cell_idx),
                                p(self.sorted_idx), st)
@@ -341,6 +379,7 @@ class Particles(object):
             self.sorted = True
             self._deposits_since_sort = 0
             self._runs_latest = None
+        self.flush_pending_push()
         grid = fld.interp
         Nm = len(grid)
         g0 = grid[0]

@@ -117,6 +117,20 @@ int fb_bin_sort_particles(long n, int ncell, const double *x, const double *y, c
                           int *cell_idx_sorted, int *sorted_idx, int *prefix_sum,
                           void *workspace, size_t workspace_bytes, void *stream);
 
+/* push_x (particles/particles.py:639-671, push/numba_methods.py:16-32) folded into the sort
+ * that follows it in Simulation.step (main.py:519-528: push_x, then deposit('rho_next')
+ * re-sorts): identical result to fb_push_x(n, x, y, z, ..., c, dt, x_push, y_push, z_push)
+ * followed by fb_bin_sort_particles, but the pushed positions are only written once, at
+ * their sorted slot.  src[0..2] must be x, y, z. */
+int fb_push_x_bin_sort_particles(long n, int ncell, const double *x, const double *y,
+                                 const double *z, const double *ux, const double *uy,
+                                 const double *uz, const double *inv_gamma, double c, double dt,
+                                 double x_push, double y_push, double z_push,
+                                 double invdz, double zmin, int Nz, double invdr, double rmin,
+                                 int Nr, int nattr, const double *const *src, double *const *dst,
+                                 int *cell_idx_sorted, int *sorted_idx, int *prefix_sum,
+                                 void *workspace, size_t workspace_bytes, void *stream);
+
 /* particles/particles.py:519-538 -> write_sorting_buffer (cuda_sorting.py:192-213),
  * all attributes in one launch: dst[k][i] = src[k][sorted_idx[i]].
  * src, dst: HOST arrays of nattr device pointers (nattr <= 16). */

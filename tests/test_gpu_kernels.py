@@ -524,3 +524,48 @@ def test_bin_sort_particles(hip, oracle, presorted):
     assert np.array_equal(prefix, np.cumsum(np.bincount(ref, minlength=ncell)).astype(np.int32))
     for a, b in zip((x, y, z, w), dst):
         assert np.array_equal(host(b), a[sidx])
+
+
+def test_push_x_folded_into_sort(hip, oracle):
+    """fb_push_x_bin_sort_particles == fb_push_x followed by the counting sort: pushed
+    positions bit-identical to the oracle push, cells from the pushed positions."""
+    from scipy.constants import c
+    rng = np.random.default_rng(32)
+    n, Nz, Nr = 200003, 64, 32
+    dzc = 0.2e-6
+    r = rng.uniform(0, 1.02 * Nr * dzc, n)
+    th = rng.uniform(0, 2 * np.pi, n)
+    x, y = r * np.cos(th), r * np.sin(th)
+    z = rng.uniform(0, Nz * dzc, n)
+    ux, uy, uz = (rng.normal(size=n) for _ in range(3))
+    ig = 1. / np.sqrt(1. + ux**2 + uy**2 + uz**2)
+    w = rng.normal(size=n)
+    dt = 0.5 * dzc / c
+    geom = (1. / dzc, 0., Nz, 1. / dzc, 0., Nr)
+    xr, yr, zr = x.copy(), y.copy(), z.copy()
+    oracle.push_x(xr, yr, zr, ux, uy, uz, ig, dt, 1., 1., 1.)
+    ref = oracle.cell_index(xr, yr, zr, *geom)
+    t = hip.torch()
+    ncell = Nz * (Nr + 1)
+    src = [dev(hip, a) for a in (x, y, z, ux, uy, uz, w, ig)]
+    dst = [t.empty_like(src[0]) for _ in range(8)]
+    ci = t.empty(n, dtype=t.int32, device='cuda')
+    si = t.empty(n, dtype=t.int32, device='cuda')
+    pre = t.empty(ncell, dtype=t.int32, device='cuda')
+    nb = int(hip.lib().fb_bin_sort_workspace_bytes(n, ncell))
+    ws = t.empty(nb, dtype=t.uint8, device='cuda')
+    p = hip.ptr
+    hip.check(hip.lib().fb_push_x_bin_sort_particles(
+        n, ncell, p(src[0]), p(src[1]), p(src[2]), p(src[3]), p(src[4]), p(src[5]), p(src[7]),
+        c, dt, 1., 1., 1., *geom, 8, hip.ptr_array(src), hip.ptr_array(dst), p(ci), p(si), p(pre),
+        p(ws), nb, hip.stream()), 'push_x_bin_sort')
+    cis, sidx, prefix = host(ci), host(si), host(pre)
+    assert np.all(np.diff(cis) >= 0)
+    assert np.array_equal(np.sort(sidx), np.arange(n, dtype=np.int32))
+    assert np.array_equal(cis, ref[sidx])
+    assert np.array_equal(prefix, np.cumsum(np.bincount(ref, minlength=ncell)).astype(np.int32))
+    for a, b in zip((xr, yr, zr, ux, uy, uz, w, ig), dst):
+        assert np.array_equal(host(b), a[sidx])
+    # the inputs are untouched
+    for a, b in zip((x, y, z), src[:3]):
+        assert np.array_equal(host(b), a)
