@@ -40,6 +40,12 @@ WORK = {
     'fb_gather_push': ('hbm', lambda a: 160.0 * a[2]),
     'fb_deposit_rho': ('hbm', lambda a: 32.0 * a[2]),
     'fb_deposit_J': ('hbm', lambda a: 64.0 * a[2]),
+    # J deposition + cell/rank of the pushed position for the next sort: 64 B read + 8 B written
+    'fb_deposit_J_rank_next': ('hbm', lambda a: 72.0 * a[2]),
+    # push_x folded into the counting sort (pre-ranked): 8 arrays + cell + rank read, 8 arrays +
+    # sorted cell + permutation written (sort = implementation overhead)
+    'fb_push_x_bin_sort_particles': ('hbm', lambda a: 144.0 * a[0]),
+    'fb_zfft': ('hbm', lambda a: 32.0 * a[0] * a[1]),
     'fb_cell_index': ('hbm', lambda a: 32.0 * a[0]),
     'fb_sort_by_cell': ('hbm', lambda a: 16.0 * a[0]),          # one read+write of (key, value)
     'fb_permute': ('hbm', lambda a: (16.0 * a[2] + 4.0) * a[0]),

@@ -32,7 +32,9 @@ _SIGNATURES = {
     'fb_bin_sort_workspace_bytes': (Z, [L, I]),
     'fb_bin_sort_particles': (I, [L, I, P, P, P, D, D, I, D, D, I, I, _PP, _PP, P, P, P, P, Z, P]),
     'fb_push_x_bin_sort_particles': (I, [L, I, P, P, P, P, P, P, P, D, D, D, D, D, D, D, I, D, D, I, I, _PP,
-                                         _PP, P, P, P, P, Z, P]),
+                                         _PP, P, P, P, P, Z, I, P]),
+    'fb_deposit_J_rank_next': (I, [I, I, L, P, P, P, P, D, P, P, P, P, D, D, D, I, D, D, I, _PP, L, P, P, P,
+                                   D, D, D, D, I, P, Z, P]),
     'fb_permute': (I, [L, P, I, _PP, _PP, P]),
     'fb_deposit_rho': (I, [I, I, L, P, P, P, P, D, D, D, I, D, D, I, _PP, L, P, P, P, P, P]),
     'fb_deposit_J': (I, [I, I, L, P, P, P, P, D, P, P, P, P, D, D, D, I, D, D, I, _PP, L,
@@ -50,6 +52,8 @@ _SIGNATURES = {
     'fb_fft_plan_create': (I, [I, L, L, L, I, _PP]),
     'fb_fft_exec': (I, [P, I, P, P, P]),
     'fb_fft_plan_destroy': (I, [P]),
+    'fb_zfft_supported': (I, [I]),
+    'fb_zfft': (I, [I, L, P, L, P, L, I, P]),
     'fb_hankel': (I, [I, _PP, L, _PP, L, _PP, D, I, I, P]),
     'fb_hankel_scaled': (I, [I, _PP, L, _PP, L, _PP, _PP, _PP, _PP, D, I, I, P]),
     'fb_psatd_step_standard': (I, [I, _PP, L, _PP, D, I, I, D, D, D, I, I, P]),
@@ -160,7 +164,7 @@ class _TimedLib(object):
         f = getattr(self._real, name)
         if not name.startswith('fb_') or name in ('fb_last_error', 'fb_abi_version',
                                                   'fb_sort_workspace_bytes', 'fb_bin_sort_workspace_bytes', 'fb_fft_plan_create',
-                                                  'fb_fft_plan_destroy', 'fb_sync', 'fb_set_device'):
+                                                  'fb_fft_plan_destroy', 'fb_sync', 'fb_set_device', 'fb_zfft_supported'):
             return f
         t = torch()
         recs = self._records.setdefault(name, [])

@@ -301,6 +301,8 @@ class BoundaryCommunicator(object):
         """Single periodic domain: wrap z into [zmin, zmax) (particle_buffer_handling.py:
         514-556).  Decomposed domain: hand the particles that left the local physical
         range to the neighbours (boundary_communicator.py:750-826)."""
+        species.flush_pending_push()
+        species._prerank = None
         if self.n_guard == 0:
             rc = _capi.lib().fb_shift_periodic(species.Ntot, _capi.ptr(species.z),
                                                fld.interp[0].zmin, fld.interp[0].zmax,

@@ -134,8 +134,20 @@ __device__ __forceinline__ double row_ror(double v)
     return __hiloint2double(hi, lo);
 }
 
+// Optional by-product of the J deposition (fb_deposit_J_rank_next): Simulation.step pushes
+// the positions by another half step right after depositing J and then re-sorts them
+// (main.py:519-528).  The deposition already holds x, y, z, u, inv_gamma in registers, so it
+// also evaluates the pushed position (same expression as k_push_x), its cell and the rank of
+// the particle inside that cell (one atomic per run of equal cells, as k_bin_rank in
+// sort.hip): the counting sort then needs neither its own pass over the particles nor the
+// 56 B / particle that pass reads.
+struct RankNext {
+    double chdt, px, py, pz;
+    int *cell, *rank, *count;
+};
+
 // NCOMP = 1 (rho) or 3 (Jr,Jt,Jz); this launch handles modes m0 .. m0+NM-1; Z0 <=> m0 == 0
-template <int SHAPE, int NCOMP, int NM, bool Z0>
+template <int SHAPE, int NCOMP, int NM, bool Z0, bool RANK>
 __global__ __launch_bounds__(256) void k_deposit(long n,
         const double *__restrict__ x, const double *__restrict__ y,
         const double *__restrict__ z, const double *__restrict__ w, double q,
@@ -144,8 +156,9 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
         double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
         DepGrids G, long rs, int m0,
         const double *__restrict__ beta0, const double *__restrict__ betah,
-        int chunks_per_wave, unsigned long long *__restrict__ nflush)
+        int chunks_per_wave, unsigned long long *__restrict__ nflush, RankNext RK)
 {
+    static_assert(!RANK || NCOMP == 3, "ranking needs the momenta");
     using L = DepLayout<SHAPE, NCOMP, NM, Z0>;
     constexpr int S = L::S, H = ShapeTraits<SHAPE>::H;
     constexpr int NPT = L::NPT, RG = L::RG, NW = L::NW, NT = L::NT, T1 = L::T1;
@@ -254,6 +267,7 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
         const long ip = base + lane;
         // ---- phase 1: lane = particle; stage weights / amplitudes, keep the cell key
         int my_kz = DEP_NOKEY, my_kr = DEP_NOKEY, my_nb = 0;
+        int rk_c = -1, rk_run0 = 0, rk_base = 0;
         double pc[NCOMP == 1 ? 4 : 8];
 #pragma unroll
         for (int k = 0; k < (NCOMP == 1 ? 4 : 8); k++) pc[k] = pn[k];
@@ -314,10 +328,40 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
                 }
             // number of stencil columns below the axis: index + (icr - H) < 0
             my_nb = H - icr;
+            if constexpr (RANK) {
+                // position after the coming push_x, cell as in k_cell_index / k_bin_rank
+                const double g = pc[7];
+                const double xq = xj + RK.chdt * g * RK.px * pc[4];
+                const double yq = yj + RK.chdt * g * RK.py * pc[5];
+                const double zq = zj + RK.chdt * g * RK.pz * pc[6];
+                const double rq = sqrt(xq * xq + yq * yq);
+                int ir_upper = (int)ceil(invdr * (rq - rmin) - 0.5);
+                int iz_upper = (int)ceil(invdz * (zq - zmin) - 0.5);
+                if (ir_upper > Nr) ir_upper = Nr;
+                if (iz_upper < 0) iz_upper += Nz;
+                else if (iz_upper > Nz - 1) iz_upper -= Nz;
+                rk_c = ir_upper + iz_upper * (Nr + 1);
+            }
         } else {
             // tail of the stream: finite amplitudes for the (masked) matrix operands
 #pragma unroll
             for (int a = 0; a < L::NA; a++) Al[a * DEP_PAD + lane] = 0.;
+        }
+        if constexpr (RANK) {
+            // one atomic per run of equal destination cells; its result is only needed at
+            // the end of the chunk, so the round trip hides behind phase 2
+            const bool act = ip < n;
+            const int prev = __shfl_up(rk_c, 1);
+            const bool rk_start = act && (lane == 0 || rk_c != prev);
+            const unsigned long long rstarts = __ballot(rk_start);
+            const int nact = __popcll(__ballot(act));
+            const unsigned long long below = rstarts & ((2ull << lane) - 1ull);
+            rk_run0 = 63 - __builtin_clzll(below | 1ull);
+            if (rk_start) {
+                const unsigned long long rest = (lane + 1 < 64) ? (rstarts >> (lane + 1)) : 0ull;
+                const int len = rest ? (__builtin_ctzll(rest) + 1) : (nact - lane);
+                rk_base = atomicAdd(RK.count + rk_c, len);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -382,6 +426,13 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
             }
             p = e;
         }
+        if constexpr (RANK) {
+            const int base_r = __shfl(rk_base, rk_run0);
+            if (ip < n) {
+                RK.cell[ip] = rk_c;
+                RK.rank[ip] = base_r + (lane - rk_run0);
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
@@ -392,12 +443,12 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
         atomicAdd(nflush + ((blockIdx.x * nwaves + wave) & 1023), (unsigned long long)my_flushes);
 }
 
-template <int SHAPE, int NCOMP, int NM, bool Z0>
+template <int SHAPE, int NCOMP, int NM, bool Z0, bool RANK>
 static int launch_z(long n, const double *x, const double *y, const double *z, const double *w,
         double q, const double *ux, const double *uy, const double *uz, const double *ig,
         double c, double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
         const DepGrids &G, long rs, int m0, const double *b0, const double *bh,
-        unsigned long long *nflush, hipStream_t s)
+        unsigned long long *nflush, const RankNext &RK, hipStream_t s)
 {
     using L = DepLayout<SHAPE, NCOMP, NM, Z0>;
     // waves per workgroup: keep the LDS panel <= 64 KiB
@@ -412,10 +463,11 @@ static int launch_z(long n, const double *x, const double *y, const double *z, c
     if (cpw > 64) cpw = 64;
     const long total_waves = (nchunks + cpw - 1) / cpw;
     const long nblocks = (total_waves + nwaves - 1) / nwaves;
-    auto kern = k_deposit<SHAPE, NCOMP, NM, Z0>;
+    auto kern = k_deposit<SHAPE, NCOMP, NM, Z0, RANK>;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(64 * nwaves),
                        L::wave_bytes() * nwaves, s, n, x, y, z, w, q, ux, uy, uz, ig, c,
-                       invdz, zmin, Nz, invdr, rmin, Nr, G, rs, m0, b0, bh, cpw, (m0 == 0) ? nflush : nullptr);
+                       invdz, zmin, Nz, invdr, rmin, Nr, G, rs, m0, b0, bh, cpw,
+                       (m0 == 0) ? nflush : nullptr, RK);
     return check(hipGetLastError(), "fb_deposit");
 }
 
@@ -424,13 +476,18 @@ static int launch_one(long n, const double *x, const double *y, const double *z,
         double q, const double *ux, const double *uy, const double *uz, const double *ig,
         double c, double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
         const DepGrids &G, long rs, int m0, const double *b0, const double *bh,
-        unsigned long long *nflush, hipStream_t s)
+        unsigned long long *nflush, const RankNext *RK, hipStream_t s)
 {
-    if (m0 == 0)
-        return launch_z<SHAPE, NCOMP, NM, true>(n, x, y, z, w, q, ux, uy, uz, ig, c, invdz, zmin,
-                Nz, invdr, rmin, Nr, G, rs, m0, b0, bh, nflush, s);
-    return launch_z<SHAPE, NCOMP, NM, false>(n, x, y, z, w, q, ux, uy, uz, ig, c, invdz, zmin,
-            Nz, invdr, rmin, Nr, G, rs, m0, b0, bh, nflush, s);
+    const RankNext none = {0., 0., 0., 0., nullptr, nullptr, nullptr};
+#define ZARGS n, x, y, z, w, q, ux, uy, uz, ig, c, invdz, zmin, Nz, invdr, rmin, Nr, G, rs, m0, b0, bh, nflush
+    if (m0 == 0) {
+        if constexpr (NCOMP == 3) {
+            if (RK) return launch_z<SHAPE, NCOMP, NM, true, true>(ZARGS, *RK, s);
+        }
+        return launch_z<SHAPE, NCOMP, NM, true, false>(ZARGS, none, s);
+    }
+    return launch_z<SHAPE, NCOMP, NM, false, false>(ZARGS, none, s);
+#undef ZARGS
 }
 
 template <int SHAPE, int NCOMP>
@@ -438,12 +495,12 @@ static int launch_modes(int Nm, long n, const double *x, const double *y, const 
         const double *w, double q, const double *ux, const double *uy, const double *uz,
         const double *ig, double c, double invdz, double zmin, int Nz, double invdr, double rmin,
         int Nr, const DepGrids &G, long rs, const double *b0, const double *bh,
-        unsigned long long *nflush, hipStream_t s)
+        unsigned long long *nflush, const RankNext *RK, hipStream_t s)
 {
     int m0 = 0;
     while (m0 < Nm) {
         int left = Nm - m0, r;
-#define ARGS n, x, y, z, w, q, ux, uy, uz, ig, c, invdz, zmin, Nz, invdr, rmin, Nr, G, rs, m0, b0, bh, nflush, s
+#define ARGS n, x, y, z, w, q, ux, uy, uz, ig, c, invdz, zmin, Nz, invdr, rmin, Nr, G, rs, m0, b0, bh, nflush, RK, s
         if (left >= 4) { r = launch_one<SHAPE, NCOMP, 4>(ARGS); m0 += 4; }
         else if (left == 3) { r = launch_one<SHAPE, NCOMP, 3>(ARGS); m0 += 3; }
         else if (left == 2) { r = launch_one<SHAPE, NCOMP, 2>(ARGS); m0 += 2; }
@@ -473,12 +530,32 @@ extern "C" int fb_deposit_rho(int shape, int Nm, long n, const double *x, const 
     if (shape == FB_SHAPE_LINEAR)
         return launch_modes<FB_SHAPE_LINEAR, 1>(Nm, n, x, y, z, w, q, nullptr, nullptr, nullptr,
                 nullptr, 0., invdz, zmin, Nz, invdr, rmin, Nr, G, row_stride, ruyten_m0,
-                ruyten_mh, nflush, s);
+                ruyten_mh, nflush, nullptr, s);
     if (shape == FB_SHAPE_CUBIC)
         return launch_modes<FB_SHAPE_CUBIC, 1>(Nm, n, x, y, z, w, q, nullptr, nullptr, nullptr,
                 nullptr, 0., invdz, zmin, Nz, invdr, rmin, Nr, G, row_stride, ruyten_m0,
-                ruyten_mh, nflush, s);
+                ruyten_mh, nflush, nullptr, s);
     set_error("fb_deposit_rho", "unknown shape");
+    return -1;
+}
+
+static int deposit_J_impl(const char *who, int shape, int Nm, long n, const double *x,
+        const double *y, const double *z, const double *w, double q, const double *ux,
+        const double *uy, const double *uz, const double *inv_gamma, double c, double invdz,
+        double zmin, int Nz, double invdr, double rmin, int Nr, void *const *J, long row_stride,
+        const double *ruyten_m0, const double *ruyten_mh, unsigned long long *nflush,
+        const RankNext *RK, hipStream_t s)
+{
+    if (Nm < 1 || Nm > FB_MAX_MODES) { set_error(who, "Nm out of range"); return -1; }
+    DepGrids G;
+    for (int i = 0; i < 3 * FB_MAX_MODES; i++) G.g[i] = i < 3 * Nm ? (cplx *)J[i] : nullptr;
+    if (shape == FB_SHAPE_LINEAR)
+        return launch_modes<FB_SHAPE_LINEAR, 3>(Nm, n, x, y, z, w, q, ux, uy, uz, inv_gamma, c,
+                invdz, zmin, Nz, invdr, rmin, Nr, G, row_stride, ruyten_m0, ruyten_mh, nflush, RK, s);
+    if (shape == FB_SHAPE_CUBIC)
+        return launch_modes<FB_SHAPE_CUBIC, 3>(Nm, n, x, y, z, w, q, ux, uy, uz, inv_gamma, c,
+                invdz, zmin, Nz, invdr, rmin, Nr, G, row_stride, ruyten_m0, ruyten_mh, nflush, RK, s);
+    set_error(who, "unknown shape");
     return -1;
 }
 
@@ -491,16 +568,32 @@ extern "C" int fb_deposit_J(int shape, int Nm, long n, const double *x, const do
 {
     (void)prefix_sum;
     if (n <= 0) return 0;
-    if (Nm < 1 || Nm > FB_MAX_MODES) { set_error("fb_deposit_J", "Nm out of range"); return -1; }
-    DepGrids G;
-    for (int i = 0; i < 3 * FB_MAX_MODES; i++) G.g[i] = i < 3 * Nm ? (cplx *)J[i] : nullptr;
+    return deposit_J_impl("fb_deposit_J", shape, Nm, n, x, y, z, w, q, ux, uy, uz, inv_gamma, c,
+                          invdz, zmin, Nz, invdr, rmin, Nr, J, row_stride, ruyten_m0, ruyten_mh,
+                          nflush, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int fb_deposit_J_rank_next(int shape, int Nm, long n, const double *x, const double *y,
+        const double *z, const double *w, double q, const double *ux, const double *uy,
+        const double *uz, const double *inv_gamma, double c, double invdz, double zmin, int Nz,
+        double invdr, double rmin, int Nr, void *const *J, long row_stride,
+        const double *ruyten_m0, const double *ruyten_mh, unsigned long long *nflush,
+        double dt_push, double x_push, double y_push, double z_push, int ncell,
+        void *sort_workspace, size_t workspace_bytes, void *stream)
+{
     hipStream_t s = (hipStream_t)stream;
-    if (shape == FB_SHAPE_LINEAR)
-        return launch_modes<FB_SHAPE_LINEAR, 3>(Nm, n, x, y, z, w, q, ux, uy, uz, inv_gamma, c,
-                invdz, zmin, Nz, invdr, rmin, Nr, G, row_stride, ruyten_m0, ruyten_mh, nflush, s);
-    if (shape == FB_SHAPE_CUBIC)
-        return launch_modes<FB_SHAPE_CUBIC, 3>(Nm, n, x, y, z, w, q, ux, uy, uz, inv_gamma, c,
-                invdz, zmin, Nz, invdr, rmin, Nr, G, row_stride, ruyten_m0, ruyten_mh, nflush, s);
-    set_error("fb_deposit_J", "unknown shape");
-    return -1;
+    if (ncell != Nz * (Nr + 1)) { set_error("fb_deposit_J_rank_next", "ncell != Nz*(Nr+1)"); return -1; }
+    if (workspace_bytes < fb_bin_sort_workspace_bytes(n, ncell)) {
+        set_error("fb_deposit_J_rank_next", "workspace too small");
+        return -1;
+    }
+    const BinSortWs W = carve_bin_sort_ws(sort_workspace, workspace_bytes, n, ncell);
+    hipError_t e = hipMemsetAsync(W.count, 0, (size_t)ncell * sizeof(int), s);
+    if (e != hipSuccess) return check(e, "fb_deposit_J_rank_next(memset)");
+    if (n <= 0) return 0;
+    // fbpic/particles/push/numba_methods.py:24-30: chdt = c * dt
+    const RankNext RK = {c * dt_push, x_push, y_push, z_push, W.cell, W.rank, W.count};
+    return deposit_J_impl("fb_deposit_J_rank_next", shape, Nm, n, x, y, z, w, q, ux, uy, uz,
+                          inv_gamma, c, invdz, zmin, Nz, invdr, rmin, Nr, J, row_stride,
+                          ruyten_m0, ruyten_mh, nflush, &RK, s);
 }

@@ -31,6 +31,36 @@ inline int stream_grid(long n, int block = 256, int max_blocks = 256 * 8)
 
 __device__ __forceinline__ double m1pow(int m) { return (m & 1) ? -1. : 1.; }
 
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Layout of the counting-sort workspace (fb_bin_sort_workspace_bytes): per-cell counters,
+// per-particle cell and rank, then the rocPRIM scan scratch.  Shared by sort.hip and by the
+// deposition kernel that pre-computes cell + rank for the sort that follows it.
+struct BinSortWs {
+    int *count, *cell, *rank;
+    void *temp;
+    size_t temp_bytes;
+};
+inline BinSortWs carve_bin_sort_ws(void *workspace, size_t workspace_bytes, long n, int ncell)
+{
+    BinSortWs w;
+    char *ws = (char *)workspace;
+    w.count = (int *)ws;
+    ws += align_up((size_t)ncell * sizeof(int), 256);
+    const size_t pb = align_up((size_t)(n > 0 ? n : 1) * sizeof(int), 256);
+    w.cell = (int *)ws; ws += pb;
+    w.rank = (int *)ws; ws += pb;
+    w.temp = ws;
+    w.temp_bytes = workspace_bytes - (size_t)(ws - (char *)workspace);
+    return w;
+}
+
+// Position push evaluated inside another kernel (same expression as k_push_x, particles.hip)
+struct PushX {
+    const double *ux, *uy, *uz, *ig;
+    double chdt, px, py, pz;
+};
+
 }  // namespace fb
 
 #define FB_CHECK_LAUNCH(where) return fb::check(hipGetLastError(), where)

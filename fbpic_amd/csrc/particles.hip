@@ -142,8 +142,10 @@ template <> struct GShape<FB_SHAPE_CUBIC> { static constexpr int S = 4, OFF = 1;
 
 constexpr int G_NOKEY = -0x40000000;
 
-template <int SHAPE>
-__global__ __launch_bounds__(256) void k_gather(int Nm, long n,
+// NMT > 0: number of modes known at compile time (mode loop unrolled, exptheta_0 = 1 folded
+// away); NMT = 0: run-time Nm.
+template <int SHAPE, int NMT>
+__global__ __launch_bounds__(256) void k_gather(int Nm_arg, long n,
         const double *__restrict__ x, const double *__restrict__ y,
         const double *__restrict__ z, double rmax_gather,
         double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
@@ -153,8 +155,10 @@ __global__ __launch_bounds__(256) void k_gather(int Nm, long n,
         int maxseg, int chunks_per_wave, PushArgs PA)
 {
     constexpr int S = GShape<SHAPE>::S, OFF = GShape<SHAPE>::OFF;
+    const int Nm = NMT ? NMT : Nm_arg;
     extern __shared__ double lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar loop bounds
     const int NV = S * S * 6 * Nm;                 // complex node values of one segment
     const int PSTR = 2 * NV + 2;                   // panel stride in doubles (16-B pad)
     double *panel = lds + (size_t)wave * ((size_t)maxseg * PSTR + 2 * 8);
@@ -247,6 +251,7 @@ __global__ __launch_bounds__(256) void k_gather(int Nm, long n,
             if (inside && myseg >= s0 && myseg < s0 + ns) {
                 const double *P = panel + (size_t)(myseg - s0) * PSTR;
                 double er = 1., ei = 0.;            // exptheta_m = (cos - i sin)^m
+#pragma unroll
                 for (int m = 0; m < Nm; m++) {
                     const double factor = (m == 0) ? 1. : 2.;
 #pragma unroll
@@ -388,14 +393,24 @@ static int launch_gather(int shape, int Nm, long n, const double *x, const doubl
     if (cpw > 64) cpw = 64;
     const long total_waves = (nchunks + cpw - 1) / cpw;
     dim3 grid((unsigned)((total_waves + nwaves - 1) / nwaves)), block(64 * nwaves);
-    if (shape == FB_SHAPE_LINEAR)
-        hipLaunchKernelGGL(k_gather<FB_SHAPE_LINEAR>, grid, block, wave_bytes * nwaves, s, Nm, n,
-                           x, y, z, rmax_gather, invdz, zmin, Nz, invdr, rmin, Nr, G, row_stride,
-                           Ex, Ey, Ez, Bx, By, Bz, maxseg, cpw, PA);
-    else
-        hipLaunchKernelGGL(k_gather<FB_SHAPE_CUBIC>, grid, block, wave_bytes * nwaves, s, Nm, n,
-                           x, y, z, rmax_gather, invdz, zmin, Nz, invdr, rmin, Nr, G, row_stride,
-                           Ex, Ey, Ez, Bx, By, Bz, maxseg, cpw, PA);
+#define FB_LAUNCH_GATHER(SH, NMT) \
+    hipLaunchKernelGGL((k_gather<SH, NMT>), grid, block, wave_bytes * nwaves, s, Nm, n, x, y, z, \
+                       rmax_gather, invdz, zmin, Nz, invdr, rmin, Nr, G, row_stride, Ex, Ey, Ez, \
+                       Bx, By, Bz, maxseg, cpw, PA)
+    if (shape == FB_SHAPE_LINEAR) {
+        if (Nm == 1) FB_LAUNCH_GATHER(FB_SHAPE_LINEAR, 1);
+        else if (Nm == 2) FB_LAUNCH_GATHER(FB_SHAPE_LINEAR, 2);
+        else if (Nm == 3) FB_LAUNCH_GATHER(FB_SHAPE_LINEAR, 3);
+        else if (Nm == 4) FB_LAUNCH_GATHER(FB_SHAPE_LINEAR, 4);
+        else FB_LAUNCH_GATHER(FB_SHAPE_LINEAR, 0);
+    } else {
+        if (Nm == 1) FB_LAUNCH_GATHER(FB_SHAPE_CUBIC, 1);
+        else if (Nm == 2) FB_LAUNCH_GATHER(FB_SHAPE_CUBIC, 2);
+        else if (Nm == 3) FB_LAUNCH_GATHER(FB_SHAPE_CUBIC, 3);
+        else if (Nm == 4) FB_LAUNCH_GATHER(FB_SHAPE_CUBIC, 4);
+        else FB_LAUNCH_GATHER(FB_SHAPE_CUBIC, 0);
+    }
+#undef FB_LAUNCH_GATHER
     return check(hipGetLastError(), where);
 }
 

@@ -81,11 +81,6 @@ __global__ __launch_bounds__(256) void k_permute(long n, const int *__restrict__
 // evaluates the pushed position in registers, the scatter pass evaluates it again (same
 // expression as k_push_x, particles.hip) and writes it at the sorted slot, so the stand-alone
 // push_x sweep (56 B read + 24 B written per particle) disappears.
-struct PushX {
-    const double *ux, *uy, *uz, *ig;
-    double chdt, px, py, pz;
-};
-
 template <bool PUSH>
 __global__ __launch_bounds__(256) void k_bin_rank(long n, const double *__restrict__ x,
         const double *__restrict__ y, const double *__restrict__ z, PushX P,
@@ -149,13 +144,18 @@ __global__ __launch_bounds__(256) void k_scatter(long n, const int *__restrict__
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const int c = cell[i];
         const int d = (c > 0 ? prefix[c - 1] : 0) + rank[i];
-        if constexpr (PUSH) {      // attributes 0..2 are x, y, z
-            const double g = P.ig[i];
-            dst.p[0][d] = src.p[0][i] + P.chdt * g * P.px * P.ux[i];
-            dst.p[1][d] = src.p[1][i] + P.chdt * g * P.py * P.uy[i];
-            dst.p[2][d] = src.p[2][i] + P.chdt * g * P.pz * P.uz[i];
+        if constexpr (PUSH) {
+            // attributes 0..7 are x, y, z, ux, uy, uz, w, inv_gamma (checked by the host):
+            // every array is read once, the pushed position is written at its sorted slot
+            const double ux = src.p[3][i], uy = src.p[4][i], uz = src.p[5][i];
+            const double wt = src.p[6][i], g = src.p[7][i];
+            dst.p[0][d] = src.p[0][i] + P.chdt * g * P.px * ux;
+            dst.p[1][d] = src.p[1][i] + P.chdt * g * P.py * uy;
+            dst.p[2][d] = src.p[2][i] + P.chdt * g * P.pz * uz;
+            dst.p[3][d] = ux; dst.p[4][d] = uy; dst.p[5][d] = uz;
+            dst.p[6][d] = wt; dst.p[7][d] = g;
         }
-        for (int k = PUSH ? 3 : 0; k < nattr; k++) dst.p[k][d] = src.p[k][i];
+        for (int k = PUSH ? 8 : 0; k < nattr; k++) dst.p[k][d] = src.p[k][i];
         cell_sorted[d] = c;
         sorted_idx[d] = (int)i;
     }
@@ -176,7 +176,6 @@ static inline int key_bits(int ncell)
     return b;
 }
 
-static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 static size_t rocprim_temp_bytes(long n, int ncell)
 {
@@ -263,7 +262,7 @@ extern "C" size_t fb_bin_sort_workspace_bytes(long n, int ncell)
            + align_up(scan_temp_bytes(ncell), 256) + 256;
 }
 
-static int bin_sort_impl(const char *who, bool push, const PushX &P, long n, int ncell,
+static int bin_sort_impl(const char *who, bool push, bool preranked, const PushX &P, long n, int ncell,
         const double *x, const double *y, const double *z, double invdz, double zmin, int Nz,
         double invdr, double rmin, int Nr, int nattr, const double *const *src,
         double *const *dst, int *cell_idx_sorted, int *sorted_idx, int *prefix_sum,
@@ -275,21 +274,22 @@ static int bin_sort_impl(const char *who, bool push, const PushX &P, long n, int
         set_error(who, "workspace too small");
         return -1;
     }
-    if (push && n > 0 && (nattr < 3 || src[0] != x || src[1] != y || src[2] != z)) {
-        set_error(who, "src[0..2] must be x, y, z");
+    if (push && n > 0 && (nattr < 8 || src[0] != x || src[1] != y || src[2] != z || src[3] != P.ux ||
+                          src[4] != P.uy || src[5] != P.uz || src[7] != P.ig)) {
+        set_error(who, "src[0..7] must be x, y, z, ux, uy, uz, w, inv_gamma");
         return -1;
     }
-    char *ws = (char *)workspace;
-    int *count = (int *)ws;
-    ws += align_up((size_t)ncell * sizeof(int), 256);
-    const size_t pb = align_up((size_t)(n > 0 ? n : 1) * sizeof(int), 256);
-    int *cell = (int *)ws; ws += pb;
-    int *rank = (int *)ws; ws += pb;
-    void *temp = ws;
-    size_t temp_bytes = workspace_bytes - (size_t)(ws - (char *)workspace);
-    hipError_t e = hipMemsetAsync(count, 0, (size_t)ncell * sizeof(int), s);
-    if (e != hipSuccess) return check(e, who);
-    if (n > 0) {
+    const BinSortWs W = carve_bin_sort_ws(workspace, workspace_bytes, n, ncell);
+    int *count = W.count, *cell = W.cell, *rank = W.rank;
+    void *temp = W.temp;
+    size_t temp_bytes = W.temp_bytes;
+    hipError_t e = hipSuccess;
+    if (!preranked) {
+        // (when `preranked`, fb_deposit_J_rank_next has already filled count, cell and rank)
+        e = hipMemsetAsync(count, 0, (size_t)ncell * sizeof(int), s);
+        if (e != hipSuccess) return check(e, who);
+    }
+    if (n > 0 && !preranked) {
         const dim3 grid(stream_grid(n, 256, 256 * 16));
         if (push)
             hipLaunchKernelGGL(k_bin_rank<true>, grid, dim3(256), 0, s, n, x, y, z, P, invdz, zmin,
@@ -324,7 +324,7 @@ extern "C" int fb_bin_sort_particles(long n, int ncell, const double *x, const d
         void *workspace, size_t workspace_bytes, void *stream)
 {
     PushX P = {nullptr, nullptr, nullptr, nullptr, 0., 0., 0., 0.};
-    return bin_sort_impl("fb_bin_sort_particles", false, P, n, ncell, x, y, z, invdz, zmin, Nz,
+    return bin_sort_impl("fb_bin_sort_particles", false, false, P, n, ncell, x, y, z, invdz, zmin, Nz,
                          invdr, rmin, Nr, nattr, src, dst, cell_idx_sorted, sorted_idx, prefix_sum,
                          workspace, workspace_bytes, (hipStream_t)stream);
 }
@@ -335,11 +335,11 @@ extern "C" int fb_push_x_bin_sort_particles(long n, int ncell, const double *x, 
         double z_push, double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
         int nattr, const double *const *src, double *const *dst,
         int *cell_idx_sorted, int *sorted_idx, int *prefix_sum,
-        void *workspace, size_t workspace_bytes, void *stream)
+        void *workspace, size_t workspace_bytes, int preranked, void *stream)
 {
     // fbpic/particles/push/numba_methods.py:24-30: chdt = c * dt
     PushX P = {ux, uy, uz, inv_gamma, c * dt, x_push, y_push, z_push};
-    return bin_sort_impl("fb_push_x_bin_sort_particles", true, P, n, ncell, x, y, z, invdz, zmin,
+    return bin_sort_impl("fb_push_x_bin_sort_particles", true, preranked != 0, P, n, ncell, x, y, z, invdz, zmin,
                          Nz, invdr, rmin, Nr, nattr, src, dst, cell_idx_sorted, sorted_idx,
                          prefix_sum, workspace, workspace_bytes, (hipStream_t)stream);
 }

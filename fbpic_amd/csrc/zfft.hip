@@ -1,0 +1,266 @@
+// Hand-written batched complex128 FFT along z for power-of-two lengths (64 .. 4096), on the
+// strided (Nz, ncols) view of the z-major field slabs: element (iz, col) at base + iz*stride
+// + col.  rocFFT's strided-batch kernel reaches ~1.0-1.1 TB/s on this layout (measured,
+// tools/fft_stride_probe.py); the grids of the PIC cycle are cache-resident, so a transform is
+// really bound by LDS traffic and fp64 VALU work.  Here:
+//
+//   * one workgroup (256 lanes) transforms a tile of C = 4096/Nz adjacent columns, i.e. 4096
+//     points = 16 per lane, whatever Nz: 64 B (Nz = 1024) .. 1 KiB contiguous per z row, so
+//     the first pass reads the grid and the last pass writes it directly, coalesced, and
+//     in-place transforms are safe (a tile is read completely before it is written);
+//   * Stockham autosort passes of radix 8 / 4 / 2 (compile-time plan per Nz): every lane
+//     keeps its 16 points in registers, does its butterflies, and exchanges through a 66 KiB
+//     LDS tile between passes (row index padded by row/8: conflict-free 16-B accesses for
+//     both the strided writes of a pass and the contiguous reads of the next);
+//   * twiddles exp(-2 pi i m / Nz) come from a table built on the host in extended
+//     precision (one per Nz, cached for the life of the process); the backward transform
+//     uses the conjugates and folds the 1/Nz of the reference (fourier.py:150-160) into its
+//     last pass.
+// Same conventions as np.fft.fft / ifft along axis 0 (fbpic/fields/spectral_transform/
+// fourier.py:104-168).
+#include "fb_common.h"
+#include <cmath>
+#include <map>
+#include <vector>
+
+namespace fb {
+
+typedef double2 cx;
+
+__device__ __forceinline__ cx cadd(cx a, cx b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cx csub(cx a, cx b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cx cmul(cx a, cx b)
+{
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+// multiply by -i (FWD) or +i (backward)
+template <bool FWD> __device__ __forceinline__ cx mul_mi(cx a)
+{
+    return FWD ? make_double2(a.y, -a.x) : make_double2(-a.y, a.x);
+}
+
+template <int R, bool FWD> struct Dft;
+template <bool FWD> struct Dft<2, FWD> {
+    __device__ __forceinline__ static void run(cx *v)
+    {
+        const cx a = v[0], b = v[1];
+        v[0] = cadd(a, b); v[1] = csub(a, b);
+    }
+};
+template <bool FWD> struct Dft<4, FWD> {
+    __device__ __forceinline__ static void run(cx *v)
+    {
+        const cx t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
+        const cx t2 = cadd(v[1], v[3]), t3 = mul_mi<FWD>(csub(v[1], v[3]));
+        v[0] = cadd(t0, t2); v[2] = csub(t0, t2);
+        v[1] = cadd(t1, t3); v[3] = csub(t1, t3);
+    }
+};
+template <bool FWD> struct Dft<8, FWD> {
+    __device__ __forceinline__ static void run(cx *v)
+    {
+        cx e[4] = {v[0], v[2], v[4], v[6]}, o[4] = {v[1], v[3], v[5], v[7]};
+        Dft<4, FWD>::run(e);
+        Dft<4, FWD>::run(o);
+        constexpr double h = 0.70710678118654752440;
+        // o[k] *= W8^k, W8 = exp(-+ 2 pi i / 8)
+        const cx o1 = FWD ? make_double2(h * (o[1].x + o[1].y), h * (o[1].y - o[1].x))
+                          : make_double2(h * (o[1].x - o[1].y), h * (o[1].y + o[1].x));
+        const cx o2 = mul_mi<FWD>(o[2]);
+        const cx o3 = FWD ? make_double2(h * (o[3].y - o[3].x), -h * (o[3].x + o[3].y))
+                          : make_double2(-h * (o[3].x + o[3].y), h * (o[3].x - o[3].y));
+        v[0] = cadd(e[0], o[0]); v[4] = csub(e[0], o[0]);
+        v[1] = cadd(e[1], o1);   v[5] = csub(e[1], o1);
+        v[2] = cadd(e[2], o2);   v[6] = csub(e[2], o2);
+        v[3] = cadd(e[3], o3);   v[7] = csub(e[3], o3);
+    }
+};
+
+// compile-time pass plan: radices of passes 0..3 for N = 2^LOG2N (1 = no pass)
+template <int LOG2N> struct Plan;
+template <> struct Plan<6> { static constexpr int r[4] = {8, 8, 1, 1}; };
+template <> struct Plan<7> { static constexpr int r[4] = {8, 4, 4, 1}; };
+template <> struct Plan<8> { static constexpr int r[4] = {8, 8, 4, 1}; };
+template <> struct Plan<9> { static constexpr int r[4] = {8, 8, 8, 1}; };
+template <> struct Plan<10> { static constexpr int r[4] = {8, 8, 4, 4}; };
+template <> struct Plan<11> { static constexpr int r[4] = {8, 8, 8, 4}; };
+template <> struct Plan<12> { static constexpr int r[4] = {8, 8, 8, 8}; };
+
+constexpr int ZF_POINTS = 4096;                       // points per workgroup tile
+constexpr int ZF_LDS_CX = ZF_POINTS + ZF_POINTS / 8;  // complex slots incl. padding
+
+// One Stockham pass of radix R over the tile (NS = product of the previous radices):
+//   butterfly jj in [0, N/R): inputs rows jj + t N/R, twiddled by W_{NS R}^{t (jj mod NS)},
+//   R-point DFT, outputs to rows (jj - jj mod NS) R + jj mod NS + t NS.
+// The first pass reads the grid, the last one writes it; the others exchange in place
+// through LDS: every lane reads all of its 16 points, barrier, then writes them.
+template <int LOG2N, int R, int NS, bool FWD, bool FIRST, bool LAST>
+__device__ __forceinline__ void zf_pass(cx *lds, const cx *__restrict__ tw,
+        const cx *gin, long in_stride, cx *gout, long out_stride,
+        int c, int jj0, bool col_ok, double scale)
+{
+    constexpr int N = 1 << LOG2N, C = ZF_POINTS / N, NB = 16 / R, JSTEP = 256 / C;
+    constexpr int NR = N / R;
+    cx v[NB][R];
+    if (!FIRST) __syncthreads();                       // the previous pass has written
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        const int jj = jj0 + b * JSTEP;
+#pragma unroll
+        for (int t = 0; t < R; t++) {
+            const int row = jj + t * NR;
+            if (FIRST) v[b][t] = col_ok ? gin[(long)row * in_stride] : make_double2(0., 0.);
+            else v[b][t] = lds[row * C + c + (row >> 3)];
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        const int jj = jj0 + b * JSTEP;
+        if (!FIRST) {
+            const int k = jj & (NS - 1);
+            constexpr int TSTEP = N / (NS * R);
+#pragma unroll
+            for (int t = 1; t < R; t++) {
+                cx w = tw[t * k * TSTEP];
+                if (!FWD) w.y = -w.y;
+                v[b][t] = cmul(v[b][t], w);
+            }
+        }
+        Dft<R, FWD>::run(v[b]);
+    }
+    if (!FIRST && !LAST) __syncthreads();              // every lane has read its inputs
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        const int jj = jj0 + b * JSTEP;
+        const int k = jj & (NS - 1);
+        const int j0 = (jj - k) * R + k;
+#pragma unroll
+        for (int t = 0; t < R; t++) {
+            const int row = j0 + t * NS;
+            if (LAST) {
+                if (col_ok)
+                    gout[(long)row * out_stride] = make_double2(v[b][t].x * scale, v[b][t].y * scale);
+            } else {
+                lds[row * C + c + (row >> 3)] = v[b][t];
+            }
+        }
+    }
+}
+
+template <int LOG2N, bool FWD>
+__global__ __launch_bounds__(256) void k_zfft(long ncols, const cx *in, long in_stride,
+        cx *out, long out_stride, const cx *__restrict__ tw, double scale, int ntiles)
+{
+    constexpr int N = 1 << LOG2N, C = ZF_POINTS / N;
+    using P = Plan<LOG2N>;
+    extern __shared__ double2 zf_lds[];
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs; give each XCD a
+    // contiguous range of tiles so that neighbouring column tiles share its L2
+    const int nb = gridDim.x;
+    int tile = blockIdx.x;
+    if ((nb & 7) == 0) tile = (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3);
+    if (tile >= ntiles) return;
+    const int c = threadIdx.x % C, jj0 = threadIdx.x / C;
+    const long col = (long)tile * C + c;
+    const bool col_ok = col < ncols;
+    const cx *gin = in + col;
+    cx *gout = out + col;
+    constexpr int R0 = P::r[0], R1 = P::r[1], R2 = P::r[2], R3 = P::r[3];
+    constexpr int NPASS = (R1 == 1) ? 1 : (R2 == 1) ? 2 : (R3 == 1) ? 3 : 4;
+    static_assert(R0 * R1 * R2 * R3 == N, "pass plan");
+    zf_pass<LOG2N, R0, 1, FWD, true, NPASS == 1>(zf_lds, tw, gin, in_stride, gout, out_stride,
+                                                 c, jj0, col_ok, scale);
+    if constexpr (NPASS >= 2)
+        zf_pass<LOG2N, R1, R0, FWD, false, NPASS == 2>(zf_lds, tw, gin, in_stride, gout,
+                                                       out_stride, c, jj0, col_ok, scale);
+    if constexpr (NPASS >= 3)
+        zf_pass<LOG2N, R2, R0 * R1, FWD, false, NPASS == 3>(zf_lds, tw, gin, in_stride, gout,
+                                                            out_stride, c, jj0, col_ok, scale);
+    if constexpr (NPASS >= 4)
+        zf_pass<LOG2N, R3, R0 * R1 * R2, FWD, false, true>(zf_lds, tw, gin, in_stride, gout,
+                                                           out_stride, c, jj0, col_ok, scale);
+}
+
+// ---- twiddle tables, one per length, built once
+static std::map<int, cx *> g_twiddles;
+
+static int get_twiddles(int N, const cx **out)
+{
+    auto it = g_twiddles.find(N);
+    if (it != g_twiddles.end()) { *out = it->second; return 0; }
+    std::vector<double> h(2 * (size_t)N);
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    for (int m = 0; m < N; m++) {
+        // exact octant symmetries keep cos/sin of the eighth-turns exact
+        const long double a = two_pi * (long double)m / (long double)N;
+        h[2 * m] = (double)cosl(a);
+        h[2 * m + 1] = (double)(-sinl(a));
+    }
+    cx *d = nullptr;
+    hipError_t e = hipMalloc((void **)&d, 2 * sizeof(double) * (size_t)N);
+    if (e != hipSuccess) return check(e, "fb_zfft(twiddles)");
+    e = hipMemcpy(d, h.data(), 2 * sizeof(double) * (size_t)N, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d); return check(e, "fb_zfft(twiddles)"); }
+    g_twiddles[N] = d;
+    *out = d;
+    return 0;
+}
+
+template <int LOG2N>
+static int zfft_launch(long ncols, const cx *in, long is, cx *out, long os, int direction,
+                       const cx *tw, hipStream_t s)
+{
+    constexpr int N = 1 << LOG2N, C = ZF_POINTS / N;
+    const int ntiles = (int)((ncols + C - 1) / C);
+    const size_t lds_bytes = (size_t)ZF_LDS_CX * sizeof(cx);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_zfft<LOG2N, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)k_zfft<LOG2N, false>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return check(e, "fb_zfft(attr)");
+        attr_set = true;
+    }
+    const int nblocks = (ntiles + 7) & ~7;             // multiple of 8 for the XCD mapping
+    if (direction < 0)
+        hipLaunchKernelGGL((k_zfft<LOG2N, true>), dim3(nblocks), dim3(256), lds_bytes, s, ncols, in,
+                           is, out, os, tw, 1.0, ntiles);
+    else
+        hipLaunchKernelGGL((k_zfft<LOG2N, false>), dim3(nblocks), dim3(256), lds_bytes, s, ncols, in,
+                           is, out, os, tw, 1.0 / (double)N, ntiles);
+    return check(hipGetLastError(), "fb_zfft");
+}
+
+}  // namespace fb
+
+using namespace fb;
+
+extern "C" int fb_zfft_supported(int Nz)
+{
+    return Nz >= 64 && Nz <= 4096 && (Nz & (Nz - 1)) == 0;
+}
+
+extern "C" int fb_zfft(int Nz, long ncols, const void *in, long in_stride, void *out,
+                       long out_stride, int direction, void *stream)
+{
+    if (!fb_zfft_supported(Nz)) { set_error("fb_zfft", "Nz must be a power of two in [64, 4096]"); return -1; }
+    if (ncols <= 0) return 0;
+    if (in == out && in_stride != out_stride) { set_error("fb_zfft", "in-place needs equal strides"); return -1; }
+    const cx *tw = nullptr;
+    int r = get_twiddles(Nz, &tw);
+    if (r) return r;
+    hipStream_t s = (hipStream_t)stream;
+    const cx *a = (const cx *)in;
+    cx *b = (cx *)out;
+    switch (Nz) {
+    case 64: return zfft_launch<6>(ncols, a, in_stride, b, out_stride, direction, tw, s);
+    case 128: return zfft_launch<7>(ncols, a, in_stride, b, out_stride, direction, tw, s);
+    case 256: return zfft_launch<8>(ncols, a, in_stride, b, out_stride, direction, tw, s);
+    case 512: return zfft_launch<9>(ncols, a, in_stride, b, out_stride, direction, tw, s);
+    case 1024: return zfft_launch<10>(ncols, a, in_stride, b, out_stride, direction, tw, s);
+    case 2048: return zfft_launch<11>(ncols, a, in_stride, b, out_stride, direction, tw, s);
+    default: return zfft_launch<12>(ncols, a, in_stride, b, out_stride, direction, tw, s);
+    }
+}

@@ -1,10 +1,14 @@
-"""Batched FFT along z through rocFFT (csrc/fft.hip).  Replaces the cuFFT path of
+"""Batched FFT along z.  Replaces the cuFFT path of
 fbpic/fields/spectral_transform/fourier.py:27-168: no transpose copies, the 1/Nz of the
-backward transform is part of the rocFFT plan."""
+backward transform is part of the kernel / plan.  Power-of-two Nz in [64, 4096] run the
+hand-written LDS Stockham kernel (csrc/zfft.hip); every other length goes through rocFFT
+(csrc/fft.hip)."""
 from ... import _capi
 import ctypes
 
 _PLANS = {}
+# set to False to force the rocFFT path (A/B measurements: tools/kbench.py --rocfft)
+USE_ZFFT = True
 
 
 def get_plan(Nz, ncols, in_stride, out_stride, inplace=False):
@@ -26,6 +30,11 @@ def fft_exec(src, dst, direction, ncols=None):
     if ncols is None:
         ncols = src.shape[1]
     inplace = src.data_ptr() == dst.data_ptr()
+    if USE_ZFFT and _capi.lib().fb_zfft_supported(Nz):
+        rc = _capi.lib().fb_zfft(Nz, ncols, src.data_ptr(), src.stride(0), dst.data_ptr(),
+                                 dst.stride(0), direction, _capi.stream())
+        _capi.check(rc, 'fb_zfft')
+        return
     plan = get_plan(Nz, ncols, src.stride(0), dst.stride(0), inplace)
     rc = _capi.lib().fb_fft_exec(plan, direction, src.data_ptr(), dst.data_ptr(), _capi.stream())
     _capi.check(rc, 'fb_fft_exec')

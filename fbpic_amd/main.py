@@ -184,7 +184,13 @@ class Simulation(object):
                 species.handle_elementary_processes(self.time + 0.5 * dt)
             for species in ptcl:
                 species.keep_fields_sorted = False
+            if move_positions:
+                # the J deposition also ranks the particles for the sort after the push below
+                for species in ptcl:
+                    species.push_after_deposit_J = (0.5 * dt, 1., 1., 1.)
             self.deposit('J', exchange=(correct_currents is False))
+            for species in ptcl:
+                species.push_after_deposit_J = None
             if move_positions:
                 # deferred: the push is folded into the sort that deposit('rho_next') triggers
                 for species in ptcl:

@@ -59,6 +59,12 @@ class Particles(object):
         self.prefix_sum_shift = 0
         self.sorted = False
         self._pending_push = None     # deferred push_x (dt, x_push, y_push, z_push)
+        # Set by Simulation.step before deposit('J'): the push_x that will follow it.  The J
+        # deposition then also ranks the particles for the sort after that push
+        # (fb_deposit_J_rank_next); `_prerank` remembers for which push the ranks are valid
+        # and is dropped by anything that touches the particle arrays in between.
+        self.push_after_deposit_J = None
+        self._prerank = None
         # Sort policy.  The reference re-sorts before every deposit that follows a push_x.
         # The HIP deposition does not need an exact sort (it accumulates runs of equal
         # cells), so a re-sort is only worth its cost once the particles have moved far
@@ -125,11 +131,15 @@ class Particles(object):
             self._alloc_device_helpers()
         self.sorted = False
         self._moved_since_sort = np.inf
+        self._pending_push = None
+        self._prerank = None
         self.data_is_on_gpu = True
 
     def receive_particles_from_gpu(self):
         if not self.data_is_on_gpu:
             return
+        self.flush_pending_push()
+        self._prerank = None
         for k in _STATE + _FIELDS:
             setattr(self, k, _capi.to_host(getattr(self, k)))
         self.data_is_on_gpu = False
@@ -148,6 +158,7 @@ class Particles(object):
         """Re-size the device helpers after particles were added / removed."""
         self.sorted = False
         self._moved_since_sort = np.inf
+        self._prerank = None
         if self.data_is_on_gpu and self.x.is_cuda:
             self._alloc_device_helpers()
 
@@ -168,6 +179,7 @@ class Particles(object):
             return
         self._need_gpu()
         p = _capi.ptr
+        self._prerank = None
         rc = _capi.lib().fb_push_p(self.Ntot, p(self.ux), p(self.uy), p(self.uz), p(self.inv_gamma),
                                    p(self.Ex), p(self.Ey), p(self.Ez), p(self.Bx), p(self.By),
                                    p(self.Bz), self.q, self.m, c, self.dt, _capi.stream())
@@ -183,6 +195,8 @@ class Particles(object):
         self.flush_pending_push()
         if defer and self.use_bin_sort:
             self._pending_push = (dt, x_push, y_push, z_push)
+            if self._prerank != self._pending_push:
+                self._prerank = None
             self._note_push(dt, max(abs(x_push), abs(y_push), abs(z_push)))
             return
         self._launch_push_x(dt, x_push, y_push, z_push)
@@ -202,6 +216,7 @@ class Particles(object):
 
     def _launch_push_x(self, dt, x_push, y_push, z_push):
         p = _capi.ptr
+        self._prerank = None
         rc = _capi.lib().fb_push_x(self.Ntot, p(self.x), p(self.y), p(self.z), p(self.ux),
                                    p(self.uy), p(self.uz), p(self.inv_gamma), c, dt,
                                    x_push, y_push, z_push, _capi.stream())
@@ -252,6 +267,7 @@ class Particles(object):
             _capi.ptr_array(views), _capi.row_stride(views[0]), *eb,
             self.q, self.m, c, self.dt, dt_x, _capi.stream())
         _capi.check(rc, 'fb_gather_push')
+        self._prerank = None
         self.sorted = False
         dmin = min(self._cell_size) if self._cell_size else 0.
         self._moved_since_sort += (c * abs(dt_x) / dmin if dmin > 0 else np.inf)
@@ -271,6 +287,8 @@ class Particles(object):
             src = [getattr(self, k) for k in names]
             dst = self._alt[:len(names)]
             pend, self._pending_push = self._pending_push, None
+            preranked = int(pend is not None and self._prerank == pend)
+            self._prerank = None
             if pend is not None:
                 # the deferred push_x rides along: positions are written once, sorted
                 rc = lib.fb_push_x_bin_sort_particles(
@@ -279,7 +297,7 @@ class Particles(object):
                     pend[2], pend[3], g0.invdz, g0.zmin, g0.Nz, g0.invdr, g0.rmin, g0.Nr,
                     len(names), _capi.ptr_array(src), _capi.ptr_array(dst), p(self.cell_idx),
                     p(self.sorted_idx), p(self.prefix_sum), p(self._sort_ws),
-                    self._sort_ws.shape[0], st)
+                    self._sort_ws.shape[0], preranked, st)
                 _capi.check(rc, 'fb_push_x_bin_sort_particles')
             else:
                 rc = lib.fb_bin_sort_particles(
@@ -298,6 +316,7 @@ class Particles(object):
             self._moved_since_sort = 0.
             return
         self.flush_pending_push()
+        self._prerank = None
         rc = lib.fb_cell_index(self.Ntot, p(self.x), p(self.y), p(self.z), g0.invdz, g0.zmin,
                                g0.Nz, g0.invdr, g0.rmin, g0.Nr, p(self.cell_idx),
                                p(self.sorted_idx), st)
@@ -402,12 +421,27 @@ class Particles(object):
             views = []
             for m in range(Nm):
                 views += [grid[m].Jr, grid[m].Jt, grid[m].Jz]
-            rc = lib.fb_deposit_J(_SHAPE[self.particle_shape], Nm, self.Ntot, p(self.x), p(self.y),
-                                  p(self.z), p(weight), self.q, p(self.ux), p(self.uy), p(self.uz),
-                                  p(self.inv_gamma), c, g0.invdz, g0.zmin, g0.Nz, g0.invdr,
-                                  g0.rmin, g0.Nr, _capi.ptr_array(views),
-                                  _capi.row_stride(views[0]), p(self.prefix_sum), p(ruy0), p(ruyh),
-                                  p(self._nflush) if adaptive else None, _capi.stream())
-            _capi.check(rc, 'fb_deposit_J')
+            hint, self.push_after_deposit_J = self.push_after_deposit_J, None
+            if hint is not None and self.use_bin_sort and self.Ntot > 0:
+                # the deposition also ranks the particles for the sort that follows `hint`
+                rc = lib.fb_deposit_J_rank_next(
+                    _SHAPE[self.particle_shape], Nm, self.Ntot, p(self.x), p(self.y), p(self.z),
+                    p(weight), self.q, p(self.ux), p(self.uy), p(self.uz), p(self.inv_gamma), c,
+                    g0.invdz, g0.zmin, g0.Nz, g0.invdr, g0.rmin, g0.Nr, _capi.ptr_array(views),
+                    _capi.row_stride(views[0]), p(ruy0), p(ruyh),
+                    p(self._nflush) if adaptive else None, hint[0], hint[1], hint[2], hint[3],
+                    self.prefix_sum.shape[0], p(self._sort_ws), self._sort_ws.shape[0],
+                    _capi.stream())
+                _capi.check(rc, 'fb_deposit_J_rank_next')
+                self._prerank = tuple(hint)
+            else:
+                rc = lib.fb_deposit_J(_SHAPE[self.particle_shape], Nm, self.Ntot, p(self.x),
+                                      p(self.y), p(self.z), p(weight), self.q, p(self.ux),
+                                      p(self.uy), p(self.uz), p(self.inv_gamma), c, g0.invdz,
+                                      g0.zmin, g0.Nz, g0.invdr, g0.rmin, g0.Nr,
+                                      _capi.ptr_array(views), _capi.row_stride(views[0]),
+                                      p(self.prefix_sum), p(ruy0), p(ruyh),
+                                      p(self._nflush) if adaptive else None, _capi.stream())
+                _capi.check(rc, 'fb_deposit_J')
             if adaptive:
                 self._post_deposit_stats()

@@ -121,7 +121,11 @@ int fb_bin_sort_particles(long n, int ncell, const double *x, const double *y, c
  * that follows it in Simulation.step (main.py:519-528: push_x, then deposit('rho_next')
  * re-sorts): identical result to fb_push_x(n, x, y, z, ..., c, dt, x_push, y_push, z_push)
  * followed by fb_bin_sort_particles, but the pushed positions are only written once, at
- * their sorted slot.  src[0..2] must be x, y, z. */
+ * their sorted slot.  src[0..7] must be x, y, z, ux, uy, uz, w, inv_gamma (the order of
+ * the reference's particle buffers, particle_buffer_handling.py:150-160).
+ * preranked != 0: the cell / rank / per-cell counts in `workspace` were already produced by
+ * fb_deposit_J_rank_next for exactly this push (same dt and push factors, particle arrays
+ * untouched since); the sort then only scans the counts and scatters. */
 int fb_push_x_bin_sort_particles(long n, int ncell, const double *x, const double *y,
                                  const double *z, const double *ux, const double *uy,
                                  const double *uz, const double *inv_gamma, double c, double dt,
@@ -129,7 +133,8 @@ int fb_push_x_bin_sort_particles(long n, int ncell, const double *x, const doubl
                                  double invdz, double zmin, int Nz, double invdr, double rmin,
                                  int Nr, int nattr, const double *const *src, double *const *dst,
                                  int *cell_idx_sorted, int *sorted_idx, int *prefix_sum,
-                                 void *workspace, size_t workspace_bytes, void *stream);
+                                 void *workspace, size_t workspace_bytes, int preranked,
+                                 void *stream);
 
 /* particles/particles.py:519-538 -> write_sorting_buffer (cuda_sorting.py:192-213),
  * all attributes in one launch: dst[k][i] = src[k][sorted_idx[i]].
@@ -166,6 +171,22 @@ int fb_deposit_J(int shape, int Nm, long n,
                  void *const *J, long row_stride,
                  const int *prefix_sum, const double *ruyten_m0, const double *ruyten_mh,
                  unsigned long long *nflush, void *stream);
+
+/* fb_deposit_J that also prepares the counting sort which Simulation.step runs after the
+ * next push_x (main.py:515-528: deposit J, push_x(dt/2), re-sort for deposit rho_next): for
+ * every particle, the cell of the position pushed by (dt_push, x_push, y_push, z_push) and
+ * its rank in that cell go to `sort_workspace` (layout of fb_bin_sort_workspace_bytes).
+ * Follow with fb_push_x_bin_sort_particles(..., preranked = 1).  J itself is deposited
+ * exactly as by fb_deposit_J. */
+int fb_deposit_J_rank_next(int shape, int Nm, long n, const double *x, const double *y,
+                           const double *z, const double *w, double q, const double *ux,
+                           const double *uy, const double *uz, const double *inv_gamma, double c,
+                           double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
+                           void *const *J, long row_stride, const double *ruyten_m0,
+                           const double *ruyten_mh, unsigned long long *nflush,
+                           double dt_push, double x_push, double y_push, double z_push,
+                           int ncell, void *sort_workspace, size_t workspace_bytes,
+                           void *stream);
 
 /* ---- interpolation-grid kernels ------------------------------------------------ */
 /* fields/interpolation_grid.py:236-250 -> cuda_erase_scalar/vector (fields/cuda_methods.py:18,40).
@@ -232,6 +253,15 @@ int fb_fft_plan_create(int Nz, long ncols, long in_stride, long out_stride, int 
                        void **plan_fwd_bwd);
 int fb_fft_exec(void *plan, int direction, const void *in, void *out, void *stream);
 int fb_fft_plan_destroy(void *plan);
+
+/* Hand-written z-FFT for power-of-two Nz in [64, 4096] (csrc/zfft.hip): same transform and
+ * conventions as fb_fft_exec (fourier.py:104-168; forward unnormalised, backward x 1/Nz) on
+ * the strided (Nz, ncols) view, without a plan object; in == out allowed when the strides
+ * are equal.  fb_zfft_supported(Nz) tells the host which path to take; other lengths go
+ * through the rocFFT plans above. */
+int fb_zfft_supported(int Nz);
+int fb_zfft(int Nz, long ncols, const void *in, long in_stride, void *out, long out_stride,
+            int direction, void *stream);
 
 /* ---- Hankel transform along r (fp64 MFMA GEMM) ------------------------------------ */
 /* fields/spectral_transform/hankel.py:196-205, 227-236 (copy_2dC_to_2dR + cublas dgemm

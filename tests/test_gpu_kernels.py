@@ -305,8 +305,12 @@ def test_spectral_kernels(hip, oracle):
 
 
 # ------------------------------------------------------------------ FFT / Hankel
-@pytest.mark.parametrize('Nz,Nr,nf', [(32, 16, 1), (200, 64, 3), (254, 50, 2), (1024, 128, 6)])
+@pytest.mark.parametrize('Nz,Nr,nf', [(32, 16, 1), (200, 64, 3), (254, 50, 2), (1024, 128, 6),
+                                      (64, 24, 2), (128, 33, 3), (256, 64, 2), (512, 20, 1),
+                                      (2048, 16, 3), (4096, 9, 2)])
 def test_fft_matches_numpy(hip, Nz, Nr, nf):
+    """Both z-FFT paths (hand-written kernel for power-of-two Nz in [64, 4096], rocFFT for the
+    rest) against numpy, on a strided sub-view of a slab; ragged column counts included."""
     from fbpic_amd.fields.spectral_transform.fourier import fft_exec
     rng = np.random.default_rng(3)
     t = hip.torch()
@@ -319,6 +323,19 @@ def test_fft_matches_numpy(hip, Nz, Nr, nf):
     assert np.all(host(dst[:, :2, :]) == 0)           # neighbours untouched
     fft_exec(src[:, 1, :], dst[:, 2, :], +1, ncols=nf * Nr)
     assert rel_err(host(dst[:, 2:, :]), np.fft.ifft(a[:, 1:, :], axis=0)) < TOL
+    # in place, and the two paths against each other where both exist
+    fft_exec(src[:, 1, :], src[:, 1, :], -1, ncols=nf * Nr)
+    assert rel_err(host(src[:, 1:, :]), ref) < TOL
+    assert np.array_equal(host(src[:, 0, :]), a[:, 0, :])
+    if hip.lib().fb_zfft_supported(Nz):
+        from fbpic_amd.fields.spectral_transform import fourier
+        src2 = dev(hip, a)
+        fourier.USE_ZFFT = False
+        try:
+            fft_exec(src2[:, 1, :], dst[:, 2, :], -1, ncols=nf * Nr)
+        finally:
+            fourier.USE_ZFFT = True
+        assert rel_err(host(dst[:, 2:, :]), ref) < TOL
 
 
 @pytest.mark.parametrize('Nz,Nr', [(32, 16), (100, 50), (200, 64), (1024, 128), (70, 130)])
@@ -526,9 +543,12 @@ def test_bin_sort_particles(hip, oracle, presorted):
         assert np.array_equal(host(b), a[sidx])
 
 
-def test_push_x_folded_into_sort(hip, oracle):
+@pytest.mark.parametrize('preranked', [0, 1])
+def test_push_x_folded_into_sort(hip, oracle, preranked):
     """fb_push_x_bin_sort_particles == fb_push_x followed by the counting sort: pushed
-    positions bit-identical to the oracle push, cells from the pushed positions."""
+    positions bit-identical to the oracle push, cells from the pushed positions.  With
+    `preranked` the cell / rank pass is the by-product of fb_deposit_J_rank_next, whose J must
+    equal fb_deposit_J's."""
     from scipy.constants import c
     rng = np.random.default_rng(32)
     n, Nz, Nr = 200003, 64, 32
@@ -555,10 +575,29 @@ def test_push_x_folded_into_sort(hip, oracle):
     nb = int(hip.lib().fb_bin_sort_workspace_bytes(n, ncell))
     ws = t.empty(nb, dtype=t.uint8, device='cuda')
     p = hip.ptr
+    if preranked:
+        Nm = 2
+        J = t.zeros((Nz, 3 * Nm, Nr), dtype=t.complex128, device='cuda')
+        J2 = t.zeros_like(J)
+        ruy = dev(hip, rng.uniform(-0.05, 0.05, Nr + 1))
+        views = [J[:, k, :] for k in range(3 * Nm)]
+        views2 = [J2[:, k, :] for k in range(3 * Nm)]
+        q = -1.6e-19
+        for shape in (1, 3):
+            J.zero_(); J2.zero_()
+            hip.check(hip.lib().fb_deposit_J_rank_next(
+                shape, Nm, n, p(src[0]), p(src[1]), p(src[2]), p(src[6]), q, p(src[3]), p(src[4]),
+                p(src[5]), p(src[7]), c, *geom, hip.ptr_array(views), 3 * Nm * Nr, p(ruy), p(ruy),
+                None, dt, 1., 1., 1., ncell, p(ws), nb, hip.stream()), 'deposit_J_rank_next')
+            hip.check(hip.lib().fb_deposit_J(
+                shape, Nm, n, p(src[0]), p(src[1]), p(src[2]), p(src[6]), q, p(src[3]), p(src[4]),
+                p(src[5]), p(src[7]), c, *geom, hip.ptr_array(views2), 3 * Nm * Nr, None, p(ruy),
+                p(ruy), None, hip.stream()), 'deposit_J')
+            assert rel_err(host(J), host(J2)) < 1e-13
     hip.check(hip.lib().fb_push_x_bin_sort_particles(
         n, ncell, p(src[0]), p(src[1]), p(src[2]), p(src[3]), p(src[4]), p(src[5]), p(src[7]),
         c, dt, 1., 1., 1., *geom, 8, hip.ptr_array(src), hip.ptr_array(dst), p(ci), p(si), p(pre),
-        p(ws), nb, hip.stream()), 'push_x_bin_sort')
+        p(ws), nb, preranked, hip.stream()), 'push_x_bin_sort')
     cis, sidx, prefix = host(ci), host(si), host(pre)
     assert np.all(np.diff(cis) >= 0)
     assert np.array_equal(np.sort(sidx), np.arange(n, dtype=np.int32))

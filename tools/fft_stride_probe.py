@@ -23,9 +23,14 @@ def run(Nz, Nr, nf, NFsrc, NFdst, pad_src, pad_dst, direction, reps=30):
     gbs = 2 * 16 * Nz * nf * Nr / (us * 1e-6) / 1e9
     print('Nz=%d Nr=%d nf=%2d strides %6d->%6d dir %+d : %7.1f us  %7.0f GB/s' % (Nz, Nr, nf, rs_s, rs_d, direction, us, gbs), flush=True)
 
-for (Nz, Nr, Nm) in ((1024, 128, 2), (2048, 512, 4)):
-    NFi, NFs, NFx = 10 * Nm, 11 * Nm, 6 * Nm
-    for pad in (0, 8, 16, 24, 40, 72, 136):
-        run(Nz, Nr, 3 * Nm, NFi, NFx, pad, pad, -1)
-        run(Nz, Nr, 6 * Nm, NFx, NFi, pad, pad, +1)
-        run(Nz, Nr, Nm, NFi, NFx, pad, pad, -1)
+from fbpic_amd.fields.spectral_transform import fourier
+pads = (0, 8) if '--pads' not in sys.argv else (0, 8, 16, 24, 40, 72, 136)
+for use_zfft in (False, True):
+    fourier.USE_ZFFT = use_zfft
+    print('--- hand-written kernel' if use_zfft else '--- rocFFT')
+    for (Nz, Nr, Nm) in ((256, 64, 2), (512, 128, 2), (1024, 128, 2), (2048, 512, 4), (4096, 256, 2)):
+        NFi, NFs, NFx = 10 * Nm, 11 * Nm, 6 * Nm
+        for pad in pads:
+            run(Nz, Nr, 3 * Nm, NFi, NFx, pad, pad, -1)
+            run(Nz, Nr, 6 * Nm, NFx, NFi, pad, pad, +1)
+            run(Nz, Nr, Nm, NFi, NFx, pad, pad, -1)
