@@ -53,6 +53,17 @@ constexpr size_t HK_LDS_BYTES = (size_t)2 * (HK_ABUF + HK_BBUF) * 8;
 // [16 wz, +16) and columns [32 wn, +32): 2 column sub-tiles x (re, im) = 4 accumulator
 // chains.  The small tile keeps the launch balanced over 256 CUs (C2: 768 workgroups for
 // E+B, 3 per CU, two co-resident so one's load latency hides under the other's MFMAs).
+// Measured limits (rocprofv3 + tools/hankel_probe.py): 55-58 % MfmaUtil at 2048 x 512 and
+// 4096 x 256, 30-40 % at 1024 x 128 where a launch holds only 2-12 transforms of 67 MFLOP
+// (LdsUtil 7-20 %, no bank conflicts, L2 hit rate 83 %).  Variants tried and discarded
+// because they changed nothing at the headline size: all operands of a chunk requested up
+// front, XCD-aware tile order, matrix column block stationary in LDS with fragment-shaped
+// global loads of the input (with and without split-K across waves), matrix columns
+// stationary in registers with the input tile streamed through LDS by a persistent
+// workgroup.  All land on ~2 us per transform = its memory phase (~1 us for 4 MB in + out,
+// measured with the MFMAs removed) plus its MFMA phase (~0.9 us): at this size the two do
+// not overlap whatever the tiling.  A register-only loop of the same MFMA sustains 66-72
+// TFLOP/s (tools/mfma4_probe.hip), so the instruction itself is not the limit.
 // K is walked in chunks of 32:
 //   global -> registers (coalesced: full 512-B row segments of the complex input and of the
 //   matrix) for chunk c+1 is issued BEFORE the 32 MFMAs (2048 cycles) of chunk c, then

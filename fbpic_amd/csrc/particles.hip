@@ -277,7 +277,11 @@ __global__ __launch_bounds__(256) void k_gather(int Nm_arg, long n,
                                     fr = __builtin_fma(w_, v.x, fr); fi = __builtin_fma(w_, v.y, fi);
                                 }
                         }
-                        F[k] += factor * (fr * er - fi * ei);
+                        // m = 0: exptheta = 1 + 0i and factor = 1, so the term is fr exactly
+                        // (fr * 1 - fi * 0 for finite fields); skipping the products also lets
+                        // the compiler drop the imaginary accumulation of mode 0
+                        if (NMT && m == 0) F[k] += fr;
+                        else F[k] += factor * (fr * er - fi * ei);
                     }
                     const double nr_ = er * cs - ei * (-sn);
                     const double ni_ = er * (-sn) + ei * cs;

@@ -51,8 +51,49 @@ __global__ void k_rate_dep(double *out, int iters, long long *clk)
     if (threadIdx.x == 0 && blockIdx.x == 0) *clk = t1 - t0;
 }
 
+typedef double d4 __attribute__((ext_vector_type(4)));
+template <int NCHAIN>
+__global__ void k_rate16(double *out, int iters)
+{
+    double a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 1e-4;
+    d4 c[NCHAIN];
+    for (int j = 0; j < NCHAIN; j++) c[j] = (d4){0., 0., 0., 0.};
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int j = 0; j < NCHAIN; j++) c[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c[j], 0, 0, 0);
+    }
+    double s = 0.;
+    for (int j = 0; j < NCHAIN; j++) s += c[j][0] + c[j][1] + c[j][2] + c[j][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int NCHAIN>
+static void rate16(double *o, int waves_per_block, int nblocks, int iters)
+{
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    k_rate16<NCHAIN><<<nblocks, 64 * waves_per_block>>>(o, iters);
+    hipEventRecord(e0);
+    k_rate16<NCHAIN><<<nblocks, 64 * waves_per_block>>>(o, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    double flops = (double)nblocks * waves_per_block * iters * NCHAIN * 2048.0;
+    printf("16x16x4 f64: %d chains, %d waves/block, %d blocks: %.3f ms  %.1f TFLOP/s\n", NCHAIN,
+           waves_per_block, nblocks, ms, flops / (ms * 1e-3) / 1e12);
+}
+
 int main()
 {
+    {
+        double *o16; hipMalloc(&o16, 4096 * 512 * 8);
+        rate16<1>(o16, 4, 256, 4000);
+        rate16<2>(o16, 4, 256, 4000);
+        rate16<4>(o16, 4, 256, 2000);
+        rate16<8>(o16, 4, 256, 1000);
+        rate16<2>(o16, 8, 256, 4000);
+        rate16<2>(o16, 4, 512, 4000);
+        rate16<4>(o16, 4, 1024, 2000);
+        rate16<2>(o16, 8, 512, 4000);
+    }
     int *d; hipMalloc(&d, 64 * 64 * sizeof(int));
     k_layout<<<1, 64>>>(d);
     std::vector<int> h(64 * 64);
