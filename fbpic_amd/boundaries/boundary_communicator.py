@@ -185,21 +185,33 @@ class BoundaryCommunicator(object):
             return
         t = _capi.torch()
         names = ('Er', 'Et', 'Ez', 'Br', 'Bt', 'Bz')
+        owner = getattr(interp[0], '_owner', None)
+        slab = None
+        if owner is not None and owner.data_is_on_gpu and len(interp) == owner.Nm:
+            # E and B of all modes are the first 6*Nm fields of the z-major slab: one
+            # multiplication per end instead of 6*Nm
+            slab = owner.d_interp[:, 0:6 * owner.Nm, :]
         if self.left_proc is None:
             if self.d_left_damp is None:
                 self.d_left_damp = t.as_tensor(self.left_damp, device=interp[0].Er.device)
             nd = self.d_left_damp.shape[0]
-            for g in interp:
-                for k in names:
-                    getattr(g, k)[:nd, :] *= self.d_left_damp[:, None]
+            if slab is not None:
+                slab[:nd] *= self.d_left_damp[:, None, None]
+            else:
+                for g in interp:
+                    for k in names:
+                        getattr(g, k)[:nd, :] *= self.d_left_damp[:, None]
         if self.right_proc is None:
             if self.d_right_damp is None:
                 self.d_right_damp = t.as_tensor(self.right_damp[::-1].copy(),
                                                 device=interp[0].Er.device)
             nd = self.d_right_damp.shape[0]
-            for g in interp:
-                for k in names:
-                    getattr(g, k)[-nd:, :] *= self.d_right_damp[:, None]
+            if slab is not None:
+                slab[-nd:] *= self.d_right_damp[:, None, None]
+            else:
+                for g in interp:
+                    for k in names:
+                        getattr(g, k)[-nd:, :] *= self.d_right_damp[:, None]
 
     # ---------------------------------------------------------------- field exchange
     def exchange_fields(self, interp, fldtype, method):
@@ -209,8 +221,10 @@ class BoundaryCommunicator(object):
         if self.size == 1:
             return
         ng = self.n_guard
+        # 'EB': E and B in ONE message per neighbour (they are adjacent in the slab and always
+        # exchanged together, main.py:745-746) - half the point-to-point latency per step
         names = {'E': ('Er', 'Et', 'Ez'), 'B': ('Br', 'Bt', 'Bz'), 'J': ('Jr', 'Jt', 'Jz'),
-                 'rho': ('rho',)}[fldtype]
+                 'EB': ('Er', 'Et', 'Ez', 'Br', 'Bt', 'Bz'), 'rho': ('rho',)}[fldtype]
         t = _capi.torch()
         Nz = getattr(interp[0], names[0]).shape[0]
         if method == 'replace':

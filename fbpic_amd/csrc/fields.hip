@@ -192,6 +192,7 @@ __global__ __launch_bounds__(256) void k_psatd_step(PsatdModes M, long rs, doubl
             jm = cadd(jm, rmul(-0.5 * krr, F));
             jz = cadd(jz, rmul(kzz, imul(rmul(-1., F))));
             st(f[6] + o, jp); st(f[7] + o, jm); st(f[8] + o, jz);
+            if (correct == 2) continue;          // correction only (the J guard exchange follows)
         }
         cplx rho_diff;
         if (use_true_rho) {

@@ -1,4 +1,5 @@
-// Hand-written batched complex128 FFT along z for power-of-two lengths (64 .. 4096), on the
+// Hand-written batched complex128 FFT along z for power-of-two lengths (64 .. 4096) and for
+// 9 x 2^k (576, 1152, 2304: a power-of-two slab plus its 2 x 64 guard cells), on the
 // strided (Nz, ncols) view of the z-major field slabs: element (iz, col) at base + iz*stride
 // + col.  rocFFT's strided-batch kernel reaches ~1.0-1.1 TB/s on this layout (measured,
 // tools/fft_stride_probe.py); the grids of the PIC cycle are cache-resident, so a transform is
@@ -76,31 +77,90 @@ template <bool FWD> struct Dft<8, FWD> {
     }
 };
 
-// compile-time pass plan: radices of passes 0..3 for N = 2^LOG2N (1 = no pass)
-template <int LOG2N> struct Plan;
-template <> struct Plan<6> { static constexpr int r[4] = {8, 8, 1, 1}; };
-template <> struct Plan<7> { static constexpr int r[4] = {8, 4, 4, 1}; };
-template <> struct Plan<8> { static constexpr int r[4] = {8, 8, 4, 1}; };
-template <> struct Plan<9> { static constexpr int r[4] = {8, 8, 8, 1}; };
-template <> struct Plan<10> { static constexpr int r[4] = {8, 8, 4, 4}; };
-template <> struct Plan<11> { static constexpr int r[4] = {8, 8, 8, 4}; };
-template <> struct Plan<12> { static constexpr int r[4] = {8, 8, 8, 8}; };
+template <bool FWD> struct Dft<3, FWD> {
+    __device__ __forceinline__ static void run(cx *v)
+    {
+        constexpr double h = 0.86602540378443864676;      // sin(2 pi / 3)
+        const cx t1 = cadd(v[1], v[2]);
+        const cx t2 = make_double2(v[0].x - 0.5 * t1.x, v[0].y - 0.5 * t1.y);
+        const cx d = csub(v[1], v[2]);
+        // (-+ i h) d
+        const cx t3 = FWD ? make_double2(h * d.y, -h * d.x) : make_double2(-h * d.y, h * d.x);
+        v[0] = cadd(v[0], t1);
+        v[1] = cadd(t2, t3);
+        v[2] = csub(t2, t3);
+    }
+};
+template <bool FWD> struct Dft<9, FWD> {
+    // 9 = 3 x 3 Cooley-Tukey: X[k1 + 3 k2] = sum_n2 W3^(n2 k2) W9^(n2 k1) sum_n1 W3^(n1 k1) x[3 n1 + n2]
+    __device__ __forceinline__ static void run(cx *v)
+    {
+        cx y[3][3];
+#pragma unroll
+        for (int n2 = 0; n2 < 3; n2++) {
+            cx t[3] = {v[n2], v[3 + n2], v[6 + n2]};
+            Dft<3, FWD>::run(t);
+#pragma unroll
+            for (int k1 = 0; k1 < 3; k1++) y[n2][k1] = t[k1];
+        }
+        // W9^m = exp(-+ 2 pi i m / 9), m = 1, 2, 4
+        constexpr double c1 = 0.76604444311897803520, s1 = 0.64278760968653932632;
+        constexpr double c2 = 0.17364817766693034885, s2 = 0.98480775301220805937;
+        constexpr double c4 = -0.93969262078590838405, s4 = 0.34202014332566873304;
+        const cx w1 = make_double2(c1, FWD ? -s1 : s1), w2 = make_double2(c2, FWD ? -s2 : s2);
+        const cx w4 = make_double2(c4, FWD ? -s4 : s4);
+        y[1][1] = cmul(y[1][1], w1); y[1][2] = cmul(y[1][2], w2);
+        y[2][1] = cmul(y[2][1], w2); y[2][2] = cmul(y[2][2], w4);
+#pragma unroll
+        for (int k1 = 0; k1 < 3; k1++) {
+            cx t[3] = {y[0][k1], y[1][k1], y[2][k1]};
+            Dft<3, FWD>::run(t);
+#pragma unroll
+            for (int k2 = 0; k2 < 3; k2++) v[k1 + 3 * k2] = t[k2];
+        }
+    }
+};
 
-constexpr int ZF_POINTS = 4096;                       // points per workgroup tile
-constexpr int ZF_LDS_CX = ZF_POINTS + ZF_POINTS / 8;  // complex slots incl. padding
+// Compile-time configuration of one length: N points per column, C adjacent columns per
+// workgroup, NTHR lanes, up to 5 Stockham passes of radix R0..R4 (1 = no pass).  Every lane
+// keeps N C / NTHR points in registers; each pass must give every lane a whole number of
+// butterflies: (N / R) C / NTHR integer.
+template <int N_, int C_, int NTHR_, int R0_, int R1_, int R2_, int R3_, int R4_>
+struct ZCfg {
+    static constexpr int N = N_, C = C_, NTHR = NTHR_;
+    static constexpr int R0 = R0_, R1 = R1_, R2 = R2_, R3 = R3_, R4 = R4_;
+    static constexpr int E = N * C / NTHR;                  // points per lane
+    static constexpr int LDS_CX = N * C + N / 8 + 1;        // complex slots incl. the row padding
+    static_assert(R0 * R1 * R2 * R3 * R4 == N, "pass plan");
+    static_assert(N * C % NTHR == 0 && NTHR % C == 0, "tile shape");
+};
+// powers of two: 4096 points per 256-lane workgroup (16 per lane), radix 8 / 4
+typedef ZCfg<64, 64, 256, 8, 8, 1, 1, 1> ZC64;
+typedef ZCfg<128, 32, 256, 8, 4, 4, 1, 1> ZC128;
+typedef ZCfg<256, 16, 256, 8, 8, 4, 1, 1> ZC256;
+typedef ZCfg<512, 8, 256, 8, 8, 8, 1, 1> ZC512;
+typedef ZCfg<1024, 4, 256, 8, 8, 4, 4, 1> ZC1024;
+typedef ZCfg<2048, 2, 256, 8, 8, 8, 4, 1> ZC2048;
+typedef ZCfg<4096, 1, 256, 8, 8, 8, 8, 1> ZC4096;
+// 9 x 2^k (a power-of-two slab plus 2 x 64 guard cells, e.g. 1024 + 128): 4608 points per
+// 128-lane workgroup (36 per lane), radix 9 then 4 / 2
+typedef ZCfg<576, 8, 128, 9, 4, 4, 4, 1> ZC576;
+typedef ZCfg<1152, 4, 128, 9, 4, 4, 4, 2> ZC1152;
+typedef ZCfg<2304, 2, 128, 9, 4, 4, 4, 4> ZC2304;
 
 // One Stockham pass of radix R over the tile (NS = product of the previous radices):
 //   butterfly jj in [0, N/R): inputs rows jj + t N/R, twiddled by W_{NS R}^{t (jj mod NS)},
 //   R-point DFT, outputs to rows (jj - jj mod NS) R + jj mod NS + t NS.
 // The first pass reads the grid, the last one writes it; the others exchange in place
-// through LDS: every lane reads all of its 16 points, barrier, then writes them.
-template <int LOG2N, int R, int NS, bool FWD, bool FIRST, bool LAST>
+// through LDS: every lane reads all of its points, barrier, then writes them.
+template <class Z, int R, int NS, bool FWD, bool FIRST, bool LAST>
 __device__ __forceinline__ void zf_pass(cx *lds, const cx *__restrict__ tw,
         const cx *gin, long in_stride, cx *gout, long out_stride,
         int c, int jj0, bool col_ok, double scale)
 {
-    constexpr int N = 1 << LOG2N, C = ZF_POINTS / N, NB = 16 / R, JSTEP = 256 / C;
+    constexpr int N = Z::N, C = Z::C, NB = Z::E / R, JSTEP = Z::NTHR / C;
     constexpr int NR = N / R;
+    static_assert(Z::E % R == 0, "whole butterflies per lane");
     cx v[NB][R];
     if (!FIRST) __syncthreads();                       // the previous pass has written
 #pragma unroll
@@ -117,7 +177,7 @@ __device__ __forceinline__ void zf_pass(cx *lds, const cx *__restrict__ tw,
     for (int b = 0; b < NB; b++) {
         const int jj = jj0 + b * JSTEP;
         if (!FIRST) {
-            const int k = jj & (NS - 1);
+            const int k = jj % NS;
             constexpr int TSTEP = N / (NS * R);
 #pragma unroll
             for (int t = 1; t < R; t++) {
@@ -132,7 +192,7 @@ __device__ __forceinline__ void zf_pass(cx *lds, const cx *__restrict__ tw,
 #pragma unroll
     for (int b = 0; b < NB; b++) {
         const int jj = jj0 + b * JSTEP;
-        const int k = jj & (NS - 1);
+        const int k = jj % NS;
         const int j0 = (jj - k) * R + k;
 #pragma unroll
         for (int t = 0; t < R; t++) {
@@ -147,12 +207,11 @@ __device__ __forceinline__ void zf_pass(cx *lds, const cx *__restrict__ tw,
     }
 }
 
-template <int LOG2N, bool FWD>
-__global__ __launch_bounds__(256) void k_zfft(long ncols, const cx *in, long in_stride,
+template <class Z, bool FWD>
+__global__ __launch_bounds__(Z::NTHR) void k_zfft(long ncols, const cx *in, long in_stride,
         cx *out, long out_stride, const cx *__restrict__ tw, double scale, int ntiles)
 {
-    constexpr int N = 1 << LOG2N, C = ZF_POINTS / N;
-    using P = Plan<LOG2N>;
+    constexpr int C = Z::C;
     extern __shared__ double2 zf_lds[];
     // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs; give each XCD a
     // contiguous range of tiles so that neighbouring column tiles share its L2
@@ -165,20 +224,15 @@ __global__ __launch_bounds__(256) void k_zfft(long ncols, const cx *in, long in_
     const bool col_ok = col < ncols;
     const cx *gin = in + col;
     cx *gout = out + col;
-    constexpr int R0 = P::r[0], R1 = P::r[1], R2 = P::r[2], R3 = P::r[3];
-    constexpr int NPASS = (R1 == 1) ? 1 : (R2 == 1) ? 2 : (R3 == 1) ? 3 : 4;
-    static_assert(R0 * R1 * R2 * R3 == N, "pass plan");
-    zf_pass<LOG2N, R0, 1, FWD, true, NPASS == 1>(zf_lds, tw, gin, in_stride, gout, out_stride,
-                                                 c, jj0, col_ok, scale);
-    if constexpr (NPASS >= 2)
-        zf_pass<LOG2N, R1, R0, FWD, false, NPASS == 2>(zf_lds, tw, gin, in_stride, gout,
-                                                       out_stride, c, jj0, col_ok, scale);
-    if constexpr (NPASS >= 3)
-        zf_pass<LOG2N, R2, R0 * R1, FWD, false, NPASS == 3>(zf_lds, tw, gin, in_stride, gout,
-                                                            out_stride, c, jj0, col_ok, scale);
-    if constexpr (NPASS >= 4)
-        zf_pass<LOG2N, R3, R0 * R1 * R2, FWD, false, true>(zf_lds, tw, gin, in_stride, gout,
-                                                           out_stride, c, jj0, col_ok, scale);
+    constexpr int R0 = Z::R0, R1 = Z::R1, R2 = Z::R2, R3 = Z::R3, R4 = Z::R4;
+    constexpr int NPASS = (R1 == 1) ? 1 : (R2 == 1) ? 2 : (R3 == 1) ? 3 : (R4 == 1) ? 4 : 5;
+#define ZF_ARGS zf_lds, tw, gin, in_stride, gout, out_stride, c, jj0, col_ok, scale
+    zf_pass<Z, R0, 1, FWD, true, NPASS == 1>(ZF_ARGS);
+    if constexpr (NPASS >= 2) zf_pass<Z, R1, R0, FWD, false, NPASS == 2>(ZF_ARGS);
+    if constexpr (NPASS >= 3) zf_pass<Z, R2, R0 * R1, FWD, false, NPASS == 3>(ZF_ARGS);
+    if constexpr (NPASS >= 4) zf_pass<Z, R3, R0 * R1 * R2, FWD, false, NPASS == 4>(ZF_ARGS);
+    if constexpr (NPASS >= 5) zf_pass<Z, R4, R0 * R1 * R2 * R3, FWD, false, true>(ZF_ARGS);
+#undef ZF_ARGS
 }
 
 // ---- twiddle tables, one per length, built once
@@ -206,29 +260,29 @@ static int get_twiddles(int N, const cx **out)
     return 0;
 }
 
-template <int LOG2N>
+template <class Z>
 static int zfft_launch(long ncols, const cx *in, long is, cx *out, long os, int direction,
                        const cx *tw, hipStream_t s)
 {
-    constexpr int N = 1 << LOG2N, C = ZF_POINTS / N;
+    constexpr int N = Z::N, C = Z::C;
     const int ntiles = (int)((ncols + C - 1) / C);
-    const size_t lds_bytes = (size_t)ZF_LDS_CX * sizeof(cx);
+    const size_t lds_bytes = (size_t)Z::LDS_CX * sizeof(cx);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_zfft<LOG2N, true>,
+        hipError_t e = hipFuncSetAttribute((const void *)k_zfft<Z, true>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void *)k_zfft<LOG2N, false>,
+            e = hipFuncSetAttribute((const void *)k_zfft<Z, false>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return check(e, "fb_zfft(attr)");
         attr_set = true;
     }
     const int nblocks = (ntiles + 7) & ~7;             // multiple of 8 for the XCD mapping
     if (direction < 0)
-        hipLaunchKernelGGL((k_zfft<LOG2N, true>), dim3(nblocks), dim3(256), lds_bytes, s, ncols, in,
+        hipLaunchKernelGGL((k_zfft<Z, true>), dim3(nblocks), dim3(Z::NTHR), lds_bytes, s, ncols, in,
                            is, out, os, tw, 1.0, ntiles);
     else
-        hipLaunchKernelGGL((k_zfft<LOG2N, false>), dim3(nblocks), dim3(256), lds_bytes, s, ncols, in,
+        hipLaunchKernelGGL((k_zfft<Z, false>), dim3(nblocks), dim3(Z::NTHR), lds_bytes, s, ncols, in,
                            is, out, os, tw, 1.0 / (double)N, ntiles);
     return check(hipGetLastError(), "fb_zfft");
 }
@@ -239,13 +293,22 @@ using namespace fb;
 
 extern "C" int fb_zfft_supported(int Nz)
 {
-    return Nz >= 64 && Nz <= 4096 && (Nz & (Nz - 1)) == 0;
+    switch (Nz) {
+    case 64: case 128: case 256: case 512: case 1024: case 2048: case 4096:
+    case 576: case 1152: case 2304:
+        return 1;
+    default:
+        return 0;
+    }
 }
 
 extern "C" int fb_zfft(int Nz, long ncols, const void *in, long in_stride, void *out,
                        long out_stride, int direction, void *stream)
 {
-    if (!fb_zfft_supported(Nz)) { set_error("fb_zfft", "Nz must be a power of two in [64, 4096]"); return -1; }
+    if (!fb_zfft_supported(Nz)) {
+        set_error("fb_zfft", "unsupported Nz (2^k in [64, 4096] or 9 * 2^k in [576, 2304])");
+        return -1;
+    }
     if (ncols <= 0) return 0;
     if (in == out && in_stride != out_stride) { set_error("fb_zfft", "in-place needs equal strides"); return -1; }
     const cx *tw = nullptr;
@@ -254,13 +317,12 @@ extern "C" int fb_zfft(int Nz, long ncols, const void *in, long in_stride, void 
     hipStream_t s = (hipStream_t)stream;
     const cx *a = (const cx *)in;
     cx *b = (cx *)out;
+#define ZF_CASE(n, Z) case n: return zfft_launch<Z>(ncols, a, in_stride, b, out_stride, direction, tw, s)
     switch (Nz) {
-    case 64: return zfft_launch<6>(ncols, a, in_stride, b, out_stride, direction, tw, s);
-    case 128: return zfft_launch<7>(ncols, a, in_stride, b, out_stride, direction, tw, s);
-    case 256: return zfft_launch<8>(ncols, a, in_stride, b, out_stride, direction, tw, s);
-    case 512: return zfft_launch<9>(ncols, a, in_stride, b, out_stride, direction, tw, s);
-    case 1024: return zfft_launch<10>(ncols, a, in_stride, b, out_stride, direction, tw, s);
-    case 2048: return zfft_launch<11>(ncols, a, in_stride, b, out_stride, direction, tw, s);
-    default: return zfft_launch<12>(ncols, a, in_stride, b, out_stride, direction, tw, s);
+    ZF_CASE(64, ZC64); ZF_CASE(128, ZC128); ZF_CASE(256, ZC256); ZF_CASE(512, ZC512);
+    ZF_CASE(1024, ZC1024); ZF_CASE(2048, ZC2048); ZF_CASE(4096, ZC4096);
+    ZF_CASE(576, ZC576); ZF_CASE(1152, ZC1152); ZF_CASE(2304, ZC2304);
     }
+#undef ZF_CASE
+    return -1;
 }

@@ -272,10 +272,13 @@ class Fields(object):
             self.spect[m].push_eb_with(self.psatd[m], use_true_rho)
             self.spect[m].push_rho()
 
-    def psatd_step(self, correct_currents=True, use_true_rho=False):
+    def psatd_step(self, correct_currents=True, use_true_rho=False, only_correct=False):
         """correct_currents() + push() for all modes in ONE launch (the three updates are
         cell-local).  Used by Simulation.step on a single domain, where no guard-cell
-        exchange of J separates the correction from the push (main.py:530-542)."""
+        exchange of J separates the correction from the push (main.py:530-542).  On a
+        decomposed domain the step calls it twice around that exchange: `only_correct`
+        (correction of all modes, one launch), then correct_currents=False (push + rho
+        shift of all modes, one launch)."""
         self._need_gpu()
         from scipy.constants import c, epsilon_0, mu_0
         fields, tables = [], []
@@ -286,7 +289,8 @@ class Fields(object):
                        sp.d_kr, sp.d_kz, sp.d_inv_k2]
         rc = _capi.lib().fb_psatd_step_standard(
             self.Nm, _capi.ptr_array(fields), self.d_spect.stride(0), _capi.ptr_array(tables),
-            self.dt, int(bool(correct_currents)), int(bool(use_true_rho)), c, epsilon_0, mu_0,
+            self.dt, 2 if only_correct else int(bool(correct_currents)), int(bool(use_true_rho)),
+            c, epsilon_0, mu_0,
             self.Nz, self.Nr, _capi.stream())
         _capi.check(rc, 'fb_psatd_step_standard')
 

@@ -146,8 +146,7 @@ class Simulation(object):
     def _step_loop(self, N, correct_currents, use_true_rho, move_positions, move_momenta):
         ptcl, fld, dt = self.ptcl, self.fld, self.dt
         # E and B go to spectral space once; afterwards only spectral -> interp
-        self.comm.exchange_fields(fld.interp, 'E', 'replace')
-        self.comm.exchange_fields(fld.interp, 'B', 'replace')
+        self.comm.exchange_fields(fld.interp, 'EB', 'replace')
         self.comm.damp_EB_open_boundary(fld.interp)
         fld.interp2spect('EB')
         for i_step in range(N):
@@ -205,12 +204,14 @@ class Simulation(object):
                     fld.exchanged_source['J'] = True
             else:
                 if correct_currents:
-                    fld.correct_currents(check_exchanges=True)
+                    assert fld.exchanged_source['J'] is False
+                    fld.psatd_step(use_true_rho=use_true_rho, only_correct=True)
                     fld.spect2partial_interp('J')
                     self.comm.exchange_fields(fld.interp, 'J', 'add')
                     fld.partial_interp2spect('J')
                     fld.exchanged_source['J'] = True
-                fld.push(use_true_rho, check_exchanges=True)
+                assert fld.exchanged_source['J'] is True
+                fld.psatd_step(correct_currents=False, use_true_rho=use_true_rho)
             if self.comm.moving_win is not None:
                 self.comm.move_grids(fld, ptcl, dt, self.time)
             self.exchange_and_damp_EB()
@@ -267,8 +268,7 @@ class Simulation(object):
         needs_partial = (self.comm.size > 1) or (self.comm.nz_damp != 0) or len(self.mirrors) > 0
         if needs_partial:
             fld.spect2partial_interp('EB')
-            self.comm.exchange_fields(fld.interp, 'E', 'replace')
-            self.comm.exchange_fields(fld.interp, 'B', 'replace')
+            self.comm.exchange_fields(fld.interp, 'EB', 'replace')
             self.comm.damp_EB_open_boundary(fld.interp)
             for mirror in self.mirrors:
                 mirror.set_fields_to_zero(fld.interp, self.comm, self.time)

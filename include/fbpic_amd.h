@@ -220,7 +220,10 @@ int fb_push_eb_standard(void *Ep, void *Em, void *Ez, void *Bp, void *Bm, void *
  * -> :416-417 (rho shift).  fields: HOST array of 11*Nm device pointers, per mode in
  * SpectralGrid order Ep,Em,Ez,Bp,Bm,Bz,Jp,Jm,Jz,rho_prev,rho_next; tables: HOST array of
  * 8*Nm device pointers, per mode rho_prev_coef,rho_next_coef,j_coef,C,S_w,kr,kz,inv_k2
- * (each real (Nz,Nr) contiguous).  Same results as the three separate entry points. */
+ * (each real (Nz,Nr) contiguous).  Same results as the three separate entry points.
+ * correct_currents: 0 = push + rho shift only, 1 = correction + push + rho shift,
+ * 2 = correction only (decomposed domains: the J guard exchange of main.py:537 sits between
+ * the correction and the push, so the step makes one call with 2 and one with 0). */
 int fb_psatd_step_standard(int Nm, void *const *fields, long row_stride,
         const double *const *tables, double dt, int correct_currents, int use_true_rho,
         double c, double epsilon_0, double mu_0, int Nz, int Nr, void *stream);
@@ -254,7 +257,7 @@ int fb_fft_plan_create(int Nz, long ncols, long in_stride, long out_stride, int 
 int fb_fft_exec(void *plan, int direction, const void *in, void *out, void *stream);
 int fb_fft_plan_destroy(void *plan);
 
-/* Hand-written z-FFT for power-of-two Nz in [64, 4096] (csrc/zfft.hip): same transform and
+/* Hand-written z-FFT for Nz = 2^k in [64, 4096] and 9 * 2^k in [576, 2304] (csrc/zfft.hip): same transform and
  * conventions as fb_fft_exec (fourier.py:104-168; forward unnormalised, backward x 1/Nz) on
  * the strided (Nz, ncols) view, without a plan object; in == out allowed when the strides
  * are equal.  fb_zfft_supported(Nz) tells the host which path to take; other lengths go

@@ -28,7 +28,7 @@ pads = (0, 8) if '--pads' not in sys.argv else (0, 8, 16, 24, 40, 72, 136)
 for use_zfft in (False, True):
     fourier.USE_ZFFT = use_zfft
     print('--- hand-written kernel' if use_zfft else '--- rocFFT')
-    for (Nz, Nr, Nm) in ((256, 64, 2), (512, 128, 2), (1024, 128, 2), (2048, 512, 4), (4096, 256, 2)):
+    for (Nz, Nr, Nm) in ((256, 64, 2), (512, 128, 2), (1024, 128, 2), (1152, 128, 2), (2048, 512, 4), (4096, 256, 2)):
         NFi, NFs, NFx = 10 * Nm, 11 * Nm, 6 * Nm
         for pad in pads:
             run(Nz, Nr, 3 * Nm, NFi, NFx, pad, pad, -1)
