@@ -287,9 +287,186 @@ static int zfft_launch(long ncols, const cx *in, long is, cx *out, long os, int 
     return check(hipGetLastError(), "fb_zfft");
 }
 
+// Direct DFT of odd prime length R = 2 h + 1 with the conjugate symmetry of the roots folded
+// in: X[u], X[R-u] = (v0 + sum_t c_tu S_t) -+ i (sum_t s_tu D_t) with S_t = v[t] + v[R-t],
+// D_t = v[t] - v[R-t], c/s = cos/sin(2 pi (t u mod R) / R): 4 FMAs per (t, u) pair instead of
+// the 8 flops x 4 pairs of the plain double loop.  cr/sr hold cos/sin(2 pi m / R), m < R.
+template <int R, bool FWD>
+__device__ __forceinline__ void dft_odd(cx *v, const double *cr, const double *sr)
+{
+    constexpr int H = R / 2;
+    cx S[H + 1], D[H + 1];
+    cx x0 = v[0];
+#pragma unroll
+    for (int t = 1; t <= H; t++) {
+        S[t] = cadd(v[t], v[R - t]);
+        D[t] = csub(v[t], v[R - t]);
+        x0 = cadd(x0, S[t]);
+    }
+    cx out[R];
+    out[0] = x0;
+#pragma unroll
+    for (int u = 1; u <= H; u++) {
+        cx P = v[0], Q = make_double2(0., 0.);
+#pragma unroll
+        for (int t = 1; t <= H; t++) {
+            const int m = (t * u) % R;
+            P.x = __builtin_fma(cr[m], S[t].x, P.x); P.y = __builtin_fma(cr[m], S[t].y, P.y);
+            Q.x = __builtin_fma(sr[m], D[t].x, Q.x); Q.y = __builtin_fma(sr[m], D[t].y, Q.y);
+        }
+        // forward: X[u] = P - i Q, X[R-u] = P + i Q ; backward: the other way round
+        const cx a = make_double2(P.x + Q.y, P.y - Q.x), b = make_double2(P.x - Q.y, P.y + Q.x);
+        out[u] = FWD ? a : b;
+        out[R - u] = FWD ? b : a;
+    }
+#pragma unroll
+    for (int u = 0; u < R; u++) v[u] = out[u];
+}
+
+// roots of unity of order R from the table of N-th roots (tw[j] = exp(-2 pi i j / N))
+template <int R>
+__device__ __forceinline__ void load_roots(const cx *__restrict__ tw, int NR, double *cr, double *sr)
+{
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+        const cx w = tw[m * NR];
+        cr[m] = w.x; sr[m] = -w.y;
+    }
+}
+
+// ---- any other length: one Stockham pass per launch through global memory --------------
+// rocFFT (ROCm 7.2) refuses some lengths outright (e.g. 4416 = 2^6 * 3 * 23, the local grid of
+// the 4096-cell laser-wakefield run with its guard, damping and injection cells), so the
+// fallback is self-contained: the same pass as zf_pass, one lane per (butterfly, column),
+// radix 8 / 4 / 2 butterflies or a direct O(R^2) DFT for an odd prime R <= 31, ping-pong
+// between the destination and a scratch slab.  Coalesced along the columns; every pass is a
+// full sweep over the group, so the transform is bound by passes x 32 B per point (measured on
+// the 4416-row laser-wakefield grid: 1.4 ms per step for its 44 field transforms, i.e. the
+// HBM rate).  An LDS-resident variant (one column per workgroup, 2 x 70 KiB) was slower: one
+// wave per SIMD and 16-B row pieces leave it latency-bound.
+template <int R, bool FWD>
+__global__ __launch_bounds__(256) void k_fft_pass(int N, int NS, long ncols, const cx *in, long is,
+        cx *out, long os, const cx *__restrict__ tw, double scale)
+{
+    const long col = (long)blockIdx.x * 256 + threadIdx.x;
+    if (col >= ncols) return;
+    const int NR = N / R;
+    double cr[R], sr[R];
+    if constexpr (!(R == 2 || R == 4 || R == 8 || R == 3 || R == 9)) load_roots<R>(tw, NR, cr, sr);
+    for (int jj = blockIdx.y; jj < NR; jj += gridDim.y) {
+        const int k = jj % NS;
+        const int tstep = N / (NS * R);
+        cx v[R];
+#pragma unroll
+        for (int t = 0; t < R; t++) {
+            v[t] = in[(long)(jj + t * NR) * is + col];
+            if (t > 0 && NS > 1) {
+                cx w = tw[t * k * tstep];
+                if (!FWD) w.y = -w.y;
+                v[t] = cmul(v[t], w);
+            }
+        }
+        cx X[R];
+        if constexpr (R == 2 || R == 4 || R == 8 || R == 3 || R == 9) {
+            Dft<R, FWD>::run(v);
+#pragma unroll
+            for (int u = 0; u < R; u++) X[u] = v[u];
+        } else {
+            dft_odd<R, FWD>(v, cr, sr);
+#pragma unroll
+            for (int u = 0; u < R; u++) X[u] = v[u];
+        }
+        const long j0 = (long)(jj - k) * R + k;
+#pragma unroll
+        for (int u = 0; u < R; u++)
+            out[(j0 + (long)u * NS) * os + col] = make_double2(X[u].x * scale, X[u].y * scale);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fft_copy(int N, long ncols, const cx *in, long is, cx *out, long os)
+{
+    const long col = (long)blockIdx.x * 256 + threadIdx.x;
+    if (col >= ncols) return;
+    for (int r = blockIdx.y; r < N; r += gridDim.y) out[(long)r * os + col] = in[(long)r * is + col];
+}
+
+template <int R>
+static void pass_launch(bool fwd, dim3 grid, hipStream_t s, int N, int NS, long ncols, const cx *in, long is,
+                        cx *out, long os, const cx *tw, double scale)
+{
+    if (fwd) hipLaunchKernelGGL((k_fft_pass<R, true>), grid, dim3(256), 0, s, N, NS, ncols, in, is, out, os, tw, scale);
+    else hipLaunchKernelGGL((k_fft_pass<R, false>), grid, dim3(256), 0, s, N, NS, ncols, in, is, out, os, tw, scale);
+}
+
+// radices of the passes for length N (largest power-of-two radices first), 0 if a prime
+// factor exceeds 31
+static int factorize(int N, int *radix)
+{
+    int n = N, np = 0;
+    while (n % 8 == 0) { radix[np++] = 8; n /= 8; }
+    while (n % 4 == 0) { radix[np++] = 4; n /= 4; }
+    while (n % 2 == 0) { radix[np++] = 2; n /= 2; }
+    while (n % 9 == 0) { radix[np++] = 9; n /= 9; }
+    const int primes[] = {3, 5, 7, 11, 13, 17, 19, 23, 29, 31};
+    for (int p : primes)
+        while (n % p == 0) { radix[np++] = p; n /= p; }
+    return n == 1 ? np : 0;
+}
+
 }  // namespace fb
 
 using namespace fb;
+
+extern "C" int fb_fft_generic_supported(int Nz)
+{
+    int radix[40];
+    return Nz >= 2 && factorize(Nz, radix) > 0;
+}
+
+extern "C" int fb_fft_generic(int Nz, long ncols, const void *in, long in_stride, void *out,
+                              long out_stride, void *scratch, long scratch_stride, int direction,
+                              void *stream)
+{
+    int radix[40];
+    const int np = factorize(Nz, radix);
+    if (Nz < 2 || np == 0) { set_error("fb_fft_generic", "Nz has a prime factor > 31"); return -1; }
+    if (ncols <= 0) return 0;
+    if (!scratch || scratch == in || scratch == out) { set_error("fb_fft_generic", "a distinct scratch slab is needed"); return -1; }
+    const cx *tw = nullptr;
+    int r = get_twiddles(Nz, &tw);
+    if (r) return r;
+    hipStream_t s = (hipStream_t)stream;
+    const bool fwd = direction < 0;
+    const dim3 grid((unsigned)((ncols + 255) / 256), (unsigned)(Nz / radix[np - 1] < 1024 ? Nz / radix[np - 1] : 1024));
+    // buffers alternate so that the last pass lands in `out`; pass 0 must not write what it
+    // reads: in place with an odd number of passes starts with a copy to the scratch slab
+    const cx *src = (const cx *)in;
+    long src_stride = in_stride;
+    cx *bufs[2] = {(cx *)out, (cx *)scratch};
+    long strides[2] = {out_stride, scratch_stride};
+    int which = (np % 2 == 1) ? 0 : 1;                 // destination of pass 0
+    if (in == out && which == 0) {
+        hipLaunchKernelGGL(k_fft_copy, grid, dim3(256), 0, s, Nz, ncols, src, src_stride, bufs[1], strides[1]);
+        src = bufs[1]; src_stride = strides[1];
+    }
+    int NS = 1;
+    for (int p = 0; p < np; p++) {
+        const double scale = (p == np - 1 && !fwd) ? 1.0 / (double)Nz : 1.0;
+        cx *dst = bufs[which];
+        const long ds = strides[which];
+#define FB_PASS(R) case R: pass_launch<R>(fwd, grid, s, Nz, NS, ncols, src, src_stride, dst, ds, tw, scale); break
+        switch (radix[p]) {
+        FB_PASS(2); FB_PASS(3); FB_PASS(4); FB_PASS(5); FB_PASS(7); FB_PASS(8); FB_PASS(9); FB_PASS(11);
+        FB_PASS(13); FB_PASS(17); FB_PASS(19); FB_PASS(23); FB_PASS(29); FB_PASS(31);
+        }
+#undef FB_PASS
+        NS *= radix[p];
+        src = dst; src_stride = ds;
+        which ^= 1;
+    }
+    return check(hipGetLastError(), "fb_fft_generic");
+}
+
 
 extern "C" int fb_zfft_supported(int Nz)
 {

@@ -251,7 +251,9 @@ int fb_shift_spect(int nfields, void *const *ptrs, long row_stride, const void *
  * base + iz*stride + col (stride in complex elements), i.e. a (Nz, ncols) strided view
  * covering one or several side-by-side (Nz, Nr) grids.  No transpose copies.
  * direction: -1 forward (unnormalised), +1 backward (includes the 1/Nz of
- * fourier.py:157 through the rocFFT plan's scale factor). */
+ * fourier.py:157 through the rocFFT plan's scale factor).
+ * Plan creation fails (rocfft_status 1) for some lengths, e.g. Nz = 4416 = 2^6*3*23 (in any
+ * layout): the host then uses fb_fft_generic below. */
 int fb_fft_plan_create(int Nz, long ncols, long in_stride, long out_stride, int inplace,
                        void **plan_fwd_bwd);
 int fb_fft_exec(void *plan, int direction, const void *in, void *out, void *stream);
@@ -265,6 +267,15 @@ int fb_fft_plan_destroy(void *plan);
 int fb_zfft_supported(int Nz);
 int fb_zfft(int Nz, long ncols, const void *in, long in_stride, void *out, long out_stride,
             int direction, void *stream);
+
+/* Self-contained fallback for every other length whose prime factors are <= 31 (rocFFT of
+ * ROCm 7.2 refuses some, e.g. Nz = 4416): one Stockham pass per launch through global
+ * memory, ping-pong between `out` and a caller-provided scratch slab of the same shape
+ * (scratch_stride in complex elements); in == out allowed. */
+int fb_fft_generic_supported(int Nz);
+int fb_fft_generic(int Nz, long ncols, const void *in, long in_stride, void *out,
+                   long out_stride, void *scratch, long scratch_stride, int direction,
+                   void *stream);
 
 /* ---- Hankel transform along r (fp64 MFMA GEMM) ------------------------------------ */
 /* fields/spectral_transform/hankel.py:196-205, 227-236 (copy_2dC_to_2dR + cublas dgemm

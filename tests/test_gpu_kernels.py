@@ -305,10 +305,35 @@ def test_spectral_kernels(hip, oracle):
 
 
 # ------------------------------------------------------------------ FFT / Hankel
+@pytest.mark.parametrize('Nz', [6, 60, 62, 690, 4416, 1024])
+def test_fft_generic_any_length(hip, Nz):
+    """fb_fft_generic (pass-per-launch fallback for the lengths rocFFT refuses) against numpy:
+    out of place and in place, odd and even pass counts, radices 2..31."""
+    rng = np.random.default_rng(5)
+    t = hip.torch()
+    ncols = 37
+    a = rng.normal(size=(Nz, ncols + 3)) + 1j * rng.normal(size=(Nz, ncols + 3))
+    assert hip.lib().fb_fft_generic_supported(Nz)
+    assert not hip.lib().fb_fft_generic_supported(37 * 2)
+    src = dev(hip, a)
+    dst = t.zeros((Nz, ncols + 5), dtype=t.complex128, device='cuda')
+    scr = t.zeros((Nz, ncols + 1), dtype=t.complex128, device='cuda')
+    call = hip.lib().fb_fft_generic
+    hip.check(call(Nz, ncols, src.data_ptr(), ncols + 3, dst.data_ptr(), ncols + 5, scr.data_ptr(),
+                   ncols + 1, -1, hip.stream()), 'generic fwd')
+    assert rel_err(host(dst[:, :ncols]), np.fft.fft(a[:, :ncols], axis=0)) < TOL
+    assert np.all(host(dst[:, ncols:]) == 0)
+    hip.check(call(Nz, ncols, src.data_ptr(), ncols + 3, src.data_ptr(), ncols + 3, scr.data_ptr(),
+                   ncols + 1, +1, hip.stream()), 'generic bwd in place')
+    assert rel_err(host(src[:, :ncols]), np.fft.ifft(a[:, :ncols], axis=0)) < TOL
+    assert np.array_equal(host(src[:, ncols:]), a[:, ncols:])
+
+
+
 @pytest.mark.parametrize('Nz,Nr,nf', [(32, 16, 1), (200, 64, 3), (254, 50, 2), (1024, 128, 6),
                                       (64, 24, 2), (128, 33, 3), (256, 64, 2), (512, 20, 1),
                                       (2048, 16, 3), (4096, 9, 2), (576, 24, 2), (1152, 128, 3),
-                                      (2304, 10, 1)])
+                                      (2304, 10, 1), (4416, 6, 2), (4288, 5, 2), (4119, 3, 1)])
 def test_fft_matches_numpy(hip, Nz, Nr, nf):
     """Both z-FFT paths (hand-written kernel for Nz = 2^k in [64, 4096] and 9 * 2^k, rocFFT for
     the rest) against numpy, on a strided sub-view of a slab; ragged column counts included."""
