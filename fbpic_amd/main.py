@@ -160,8 +160,9 @@ class Simulation(object):
                 self.deposit('J', exchange=True)
             for species in ptcl:
                 species.keep_fields_sorted = True
+            diag_due = any(getattr(d, 'due', lambda it: True)(self.iteration) for d in self.diags)
             if (self.fuse_gather_push and move_momenta and move_positions
-                    and not self.external_fields and not self.diags):
+                    and not self.external_fields and not diag_due):
                 # nothing observes the particles between gather and the half position push:
                 # one pass instead of three (gather, push_p, push_x)
                 for species in ptcl:

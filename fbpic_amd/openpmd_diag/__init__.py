@@ -1,0 +1,7 @@
+"""Diagnostics hook without HDF5: the two hook points of
+Simulation.step (main.py:478-482 after the gather, :564-565 at the end of an iteration) and
+the copy-out convention of the reference's diagnostics, writing `.npz` files instead of
+openPMD/HDF5 (h5py is not part of this build)."""
+from .npz_diag import FieldDiagnostic, ParticleDiagnostic, Checkpoint
+
+__all__ = ['FieldDiagnostic', 'ParticleDiagnostic', 'Checkpoint']
