@@ -223,6 +223,86 @@ __global__ __launch_bounds__(256) void k_psatd_step(PsatdModes M, long rs, doubl
     }
 }
 
+// ---- Galilean / comoving-current PSATD (fields/numba_methods.py:217-241, 278-355) --------
+// Same cell-local structure as the standard scheme; the Theta coefficients T_eb, T_cc, T_rho,
+// the corrected-current coefficient and the three source coefficients are complex tables
+// (contiguous (Nz,Nr) complex128), C, S_w, kr, kz, inv_k2 real.
+__device__ __forceinline__ cplx cmul(cplx a, cplx b)
+{
+    return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+}
+
+__global__ __launch_bounds__(256) void k_correct_currents_comoving(const cplx *__restrict__ rho_prev,
+        const cplx *__restrict__ rho_next, cplx *__restrict__ Jp, cplx *__restrict__ Jm,
+        cplx *__restrict__ Jz, long rs, const double *__restrict__ kz, const double *__restrict__ kr,
+        const double *__restrict__ inv_k2, const cplx *__restrict__ j_corr_coef,
+        const cplx *__restrict__ T_eb, const cplx *__restrict__ T_cc, int Nz, int Nr)
+{
+    FB_GRID_LOOP(idx, iz, ir) {
+        const long o = (long)iz * rs + ir;
+        const double kzz = kz[idx], krr = kr[idx];
+        const cplx jp = ld(Jp + o), jm = ld(Jm + o), jz = ld(Jz + o);
+        const cplx t1 = cmul(cmul(ld(T_cc + idx), ld(j_corr_coef + idx)),
+                             csub(ld(rho_next + o), cmul(ld(rho_prev + o), ld(T_eb + idx))));
+        const cplx t2 = rmul(kzz, imul(jz));
+        const cplx t3 = rmul(krr, csub(jp, jm));
+        const cplx F = rmul(-inv_k2[idx], cadd(cadd(t1, t2), t3));
+        st(Jp + o, cadd(jp, rmul(0.5 * krr, F)));
+        st(Jm + o, cadd(jm, rmul(-0.5 * krr, F)));
+        st(Jz + o, cadd(jz, rmul(kzz, imul(rmul(-1., F)))));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_push_eb_comoving(cplx *__restrict__ Ep, cplx *__restrict__ Em,
+        cplx *__restrict__ Ez, cplx *__restrict__ Bp, cplx *__restrict__ Bm, cplx *__restrict__ Bz,
+        const cplx *__restrict__ Jp, const cplx *__restrict__ Jm, const cplx *__restrict__ Jz,
+        const cplx *__restrict__ rho_prev, const cplx *__restrict__ rho_next, long rs,
+        const cplx *__restrict__ rho_prev_coef, const cplx *__restrict__ rho_next_coef,
+        const cplx *__restrict__ j_coef, const double *__restrict__ C, const double *__restrict__ S_w,
+        const cplx *__restrict__ T_eb, const cplx *__restrict__ T_cc, const cplx *__restrict__ T_rho,
+        const double *__restrict__ kr, const double *__restrict__ kz, double V, int use_true_rho,
+        double c2, double eps0, double mu0, int Nz, int Nr)
+{
+    FB_GRID_LOOP(idx, iz, ir) {
+        const long o = (long)iz * rs + ir;
+        const double krr = kr[idx], kzz = kz[idx], Cc = C[idx], Sw = S_w[idx];
+        const cplx jc = ld(j_coef + idx), Teb = ld(T_eb + idx), Tcc = ld(T_cc + idx);
+        const cplx rnc = ld(rho_next_coef + idx), rpc = ld(rho_prev_coef + idx);
+        const cplx ep = ld(Ep + o), em = ld(Em + o), ez = ld(Ez + o);
+        const cplx bp = ld(Bp + o), bm = ld(Bm + o), bz = ld(Bz + o);
+        const cplx jp = ld(Jp + o), jm = ld(Jm + o), jz = ld(Jz + o);
+        cplx rho_diff;
+        if (use_true_rho) {
+            rho_diff = csub(cmul(rnc, ld(rho_next + o)), cmul(rpc, ld(rho_prev + o)));
+        } else {
+            const cplx divE = cadd(rmul(krr, csub(ep, em)), rmul(kzz, imul(ez)));
+            const cplx divJ = cadd(rmul(krr, csub(jp, jm)), rmul(kzz, imul(jz)));
+            const cplx a = rmul(eps0, csub(cmul(Teb, rnc), rpc));
+            rho_diff = cadd(cmul(a, divE), cmul(cmul(ld(T_rho + idx), rnc), divJ));
+        }
+        const cplx TC = rmul(Cc, Teb);
+        const cplx jikzV = cmul(jc, cplx{0., kzz * V});
+        const cplx TS = rmul(c2 * Sw, Teb);
+        const cplx mihkBz = rmul(0.5 * krr, imul(rmul(-1., bz)));
+        st(Ep + o, cadd(cadd(cadd(cmul(TC, ep), rmul(0.5 * krr, rho_diff)), cmul(jikzV, jp)),
+                        cmul(TS, csub(cadd(mihkBz, rmul(kzz, bp)), rmul(mu0, cmul(Tcc, jp))))));
+        st(Em + o, cadd(cadd(csub(cmul(TC, em), rmul(0.5 * krr, rho_diff)), cmul(jikzV, jm)),
+                        cmul(TS, csub(csub(mihkBz, rmul(kzz, bm)), rmul(mu0, cmul(Tcc, jm))))));
+        st(Ez + o, cadd(cadd(csub(cmul(TC, ez), rmul(kzz, imul(rho_diff))), cmul(jikzV, jz)),
+                        cmul(TS, csub(cadd(rmul(krr, imul(bp)), rmul(krr, imul(bm))),
+                                      rmul(mu0, cmul(Tcc, jz))))));
+        const cplx TSb = rmul(Sw, Teb);
+        const cplx mihkEz = rmul(0.5 * krr, imul(rmul(-1., ez)));
+        const cplx mihkJz = rmul(0.5 * krr, imul(rmul(-1., jz)));
+        st(Bp + o, cadd(csub(cmul(TC, bp), cmul(TSb, cadd(mihkEz, rmul(kzz, ep)))),
+                        cmul(jc, cadd(mihkJz, rmul(kzz, jp)))));
+        st(Bm + o, cadd(csub(cmul(TC, bm), cmul(TSb, csub(mihkEz, rmul(kzz, em)))),
+                        cmul(jc, csub(mihkJz, rmul(kzz, jm)))));
+        st(Bz + o, cadd(csub(cmul(TC, bz), cmul(TSb, cadd(rmul(krr, imul(ep)), rmul(krr, imul(em))))),
+                        cmul(jc, cadd(rmul(krr, imul(jp)), rmul(krr, imul(jm))))));
+    }
+}
+
 // boundaries/moving_window.py:204-239 (shift_spect_array_cpu): F[iz,:] *= shift[iz]^n_move,
 // the power by repeated multiplication, conjugated for n_move < 0
 __global__ __launch_bounds__(256) void k_shift_spect(int nf, Ptrs48 P, long rs,
@@ -359,6 +439,36 @@ extern "C" int fb_push_eb_standard(void *Ep, void *Em, void *Ez, void *Bp, void 
                        rho_next_coef, j_coef, C, S_w, kr, kz, dt, use_true_rho, c * c,
                        epsilon_0, mu_0, Nz, Nr);
     FB_CHECK_LAUNCH("fb_push_eb_standard");
+}
+
+extern "C" int fb_correct_currents_curlfree_comoving(const void *rho_prev, const void *rho_next,
+        void *Jp, void *Jm, void *Jz, long rs, const double *kz, const double *kr,
+        const double *inv_k2, const void *j_corr_coef, const void *T_eb, const void *T_cc,
+        int Nz, int Nr, void *stream)
+{
+    hipLaunchKernelGGL(k_correct_currents_comoving, dim3(grid_for(Nz, Nr)), dim3(256), 0,
+                       (hipStream_t)stream, (const cplx *)rho_prev, (const cplx *)rho_next, (cplx *)Jp,
+                       (cplx *)Jm, (cplx *)Jz, rs, kz, kr, inv_k2, (const cplx *)j_corr_coef,
+                       (const cplx *)T_eb, (const cplx *)T_cc, Nz, Nr);
+    FB_CHECK_LAUNCH("fb_correct_currents_curlfree_comoving");
+}
+
+extern "C" int fb_push_eb_comoving(void *Ep, void *Em, void *Ez, void *Bp, void *Bm, void *Bz,
+        const void *Jp, const void *Jm, const void *Jz, const void *rho_prev,
+        const void *rho_next, long rs, const void *rho_prev_coef, const void *rho_next_coef,
+        const void *j_coef, const double *C, const double *S_w, const void *T_eb, const void *T_cc,
+        const void *T_rho, const double *kr, const double *kz, double dt, double V,
+        int use_true_rho, double c, double epsilon_0, double mu_0, int Nz, int Nr, void *stream)
+{
+    (void)dt;
+    hipLaunchKernelGGL(k_push_eb_comoving, dim3(grid_for(Nz, Nr)), dim3(256), 0, (hipStream_t)stream,
+                       (cplx *)Ep, (cplx *)Em, (cplx *)Ez, (cplx *)Bp, (cplx *)Bm, (cplx *)Bz,
+                       (const cplx *)Jp, (const cplx *)Jm, (const cplx *)Jz, (const cplx *)rho_prev,
+                       (const cplx *)rho_next, rs, (const cplx *)rho_prev_coef,
+                       (const cplx *)rho_next_coef, (const cplx *)j_coef, C, S_w, (const cplx *)T_eb,
+                       (const cplx *)T_cc, (const cplx *)T_rho, kr, kz, V, use_true_rho, c * c,
+                       epsilon_0, mu_0, Nz, Nr);
+    FB_CHECK_LAUNCH("fb_push_eb_comoving");
 }
 
 extern "C" int fb_push_rho(void *rho_prev, void *rho_next, long rs, int Nz, int Nr, void *stream)

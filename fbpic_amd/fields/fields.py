@@ -38,14 +38,14 @@ class Fields(object):
                  use_pml=False, use_galilean=True, current_correction='curl-free',
                  use_cuda=True, smoother=None, create_threading_buffers=False,
                  use_ruyten_shapes=True, use_modified_volume=True):
-        if v_comoving is not None:
-            raise NotImplementedError('Galilean / comoving schemes are outside the fbpic_amd scope')
         if current_correction not in ('curl-free', 'cross-deposition'):
             raise ValueError('Unkown current correction:%s' % current_correction)
         self.Nz, self.Nr, self.rmax, self.Nm, self.dt = Nz, Nr, rmax, Nm, dt
         self.n_order = n_order
-        self.v_comoving = None
-        self.use_galilean = False
+        self.v_comoving = v_comoving
+        self.use_galilean = use_galilean if v_comoving is not None else False
+        if v_comoving is not None and current_correction != 'curl-free':
+            raise NotImplementedError('cross-deposition is outside the fbpic_amd scope')
         self.smoother = smoother if smoother is not None else \
             BinomialSmoother(n_passes=1, compensator=False)
         self.use_cuda = use_cuda
@@ -69,7 +69,8 @@ class Fields(object):
                                            self.interp[m].dr, current_correction, self.smoother,
                                            use_pml=use_pml, use_cuda=use_cuda))
             self.psatd.append(PsatdCoeffs(self.spect[m].kz, self.spect[m].kr, m, dt, Nz, Nr,
-                                          V=None, use_cuda=use_cuda))
+                                          V=self.v_comoving, use_galilean=self.use_galilean,
+                                          use_cuda=use_cuda))
         self.exchanged_source = {'J': False, 'rho_prev': False, 'rho_new': False,
                                  'rho_next_xy': False, 'rho_next_z': False}
         # device state (allocated at the first send_fields_to_gpu)

@@ -45,8 +45,19 @@ class SpectralGrid(object):
             self._tables_up = True
 
     def correct_currents(self, dt, ps, current_correction):
-        if ps.V is not None or current_correction != 'curl-free':
-            raise NotImplementedError('only the standard curl-free correction is implemented')
+        if current_correction != 'curl-free':
+            raise NotImplementedError('only the curl-free correction is implemented')
+        if ps.V is not None:
+            # Galilean / comoving-current scheme (spectral_grid.py:240-247)
+            t = ps.device_tables()
+            rc = _capi.lib().fb_correct_currents_curlfree_comoving(
+                _capi.ptr(self.rho_prev), _capi.ptr(self.rho_next), _capi.ptr(self.Jp),
+                _capi.ptr(self.Jm), _capi.ptr(self.Jz), _capi.row_stride(self.Jp),
+                _capi.ptr(self.d_kz), _capi.ptr(self.d_kr), _capi.ptr(self.d_inv_k2),
+                _capi.ptr(t['j_corr_coef']), _capi.ptr(t['T_eb']), _capi.ptr(t['T_cc']),
+                self.Nz, self.Nr, _capi.stream())
+            _capi.check(rc, 'fb_correct_currents_curlfree_comoving')
+            return
         rc = _capi.lib().fb_correct_currents_curlfree_standard(
             _capi.ptr(self.rho_prev), _capi.ptr(self.rho_next), _capi.ptr(self.Jp),
             _capi.ptr(self.Jm), _capi.ptr(self.Jz), _capi.row_stride(self.Jp),
@@ -61,6 +72,17 @@ class SpectralGrid(object):
         assert self.m == ps.m
         t = ps.device_tables()
         p = _capi.ptr
+        if ps.V is not None:
+            # Galilean / comoving-current scheme (spectral_grid.py:357-368)
+            rc = _capi.lib().fb_push_eb_comoving(
+                p(self.Ep), p(self.Em), p(self.Ez), p(self.Bp), p(self.Bm), p(self.Bz),
+                p(self.Jp), p(self.Jm), p(self.Jz), p(self.rho_prev), p(self.rho_next),
+                _capi.row_stride(self.Ep), p(t['rho_prev_coef']), p(t['rho_next_coef']),
+                p(t['j_coef']), p(t['C']), p(t['S_w']), p(t['T_eb']), p(t['T_cc']), p(t['T_rho']),
+                p(self.d_kr), p(self.d_kz), ps.dt, ps.V, int(bool(use_true_rho)), c, epsilon_0,
+                mu_0, self.Nz, self.Nr, _capi.stream())
+            _capi.check(rc, 'fb_push_eb_comoving')
+            return
         rc = _capi.lib().fb_push_eb_standard(
             p(self.Ep), p(self.Em), p(self.Ez), p(self.Bp), p(self.Bm), p(self.Bz),
             p(self.Jp), p(self.Jm), p(self.Jz), p(self.rho_prev), p(self.rho_next),

@@ -67,25 +67,27 @@ class Simulation(object):
         if not use_cuda:
             raise ValueError('fbpic_amd executes only on the GPU (use_cuda=True); the CPU '
                              'path of the reference is not part of this backend.')
-        if v_comoving is not None or gamma_boost is not None:
-            raise NotImplementedError('Galilean/comoving and boosted-frame runs are outside '
-                                      'the scope of the fbpic_amd hot path')
+        if gamma_boost is not None:
+            raise NotImplementedError('boosted-frame input conversion (gamma_boost) is outside '
+                                      'the scope of fbpic_amd: pass boosted-frame quantities')
         self.use_cuda = True
         self.use_threading = False
         self.cpu_threads = 1
-        self.v_comoving = None
-        self.use_galilean = False
+        # Galilean / comoving-current PSATD (main.py:269-273)
+        self.v_comoving = v_comoving
+        self.use_galilean = use_galilean if v_comoving is not None else False
         self.boost = None
         self.dt = dt
         cdt_over_dr = c * dt / (rmax / Nr)
-        self.comm = BoundaryCommunicator(Nz, zmin, zmax, Nr, rmax, Nm, dt, None, False,
-                                         boundaries, n_order, n_guard, n_damp, cdt_over_dr,
+        self.comm = BoundaryCommunicator(Nz, zmin, zmax, Nr, rmax, Nm, dt, self.v_comoving,
+                                         self.use_galilean, boundaries, n_order, n_guard, n_damp, cdt_over_dr,
                                          None, exchange_period, use_all_mpi_ranks)
         self.use_pml = self.comm.use_pml
         zmin, zmax, Nz = self.comm.divide_into_domain()
         Nr = self.comm.get_Nr(with_damp=True)
         rmax = self.comm.get_rmax(with_damp=True)
         self.fld = Fields(Nz, zmax, Nr, rmax, Nm, dt, n_order=n_order, zmin=zmin,
+                          v_comoving=self.v_comoving, use_galilean=self.use_galilean,
                           current_correction=current_correction, use_cuda=True,
                           smoother=smoother, use_ruyten_shapes=use_ruyten_shapes,
                           use_modified_volume=use_modified_volume)
@@ -180,12 +182,15 @@ class Simulation(object):
                 if move_positions:
                     for species in ptcl:
                         species.push_x(0.5 * dt)
+            if self.use_galilean:
+                self.shift_galilean_boundaries(0.5 * dt)
             for species in ptcl:
                 species.handle_elementary_processes(self.time + 0.5 * dt)
             for species in ptcl:
                 species.keep_fields_sorted = False
-            if move_positions:
+            if move_positions and not self.use_galilean:
                 # the J deposition also ranks the particles for the sort after the push below
+                # (not with a Galilean grid: zmin moves between this deposit and that sort)
                 for species in ptcl:
                     species.push_after_deposit_J = (0.5 * dt, 1., 1., 1.)
             self.deposit('J', exchange=(correct_currents is False))
@@ -195,10 +200,22 @@ class Simulation(object):
                 # deferred: the push is folded into the sort that deposit('rho_next') triggers
                 for species in ptcl:
                     species.push_x(0.5 * dt, defer=True)
+            if self.use_galilean:
+                self.shift_galilean_boundaries(0.5 * dt)
             self.deposit('rho_next', exchange=(use_true_rho is True))
             for species in ptcl:
                 species.flush_pending_push()      # species that did not deposit
-            if self.comm.size == 1:
+            if self.v_comoving is not None:
+                # Galilean / comoving scheme: per-mode correction and push (complex tables)
+                if correct_currents:
+                    fld.correct_currents(check_exchanges=(self.comm.size > 1))
+                    if self.comm.size > 1:
+                        fld.spect2partial_interp('J')
+                        self.comm.exchange_fields(fld.interp, 'J', 'add')
+                        fld.partial_interp2spect('J')
+                    fld.exchanged_source['J'] = True
+                fld.push(use_true_rho, check_exchanges=(self.comm.size > 1))
+            elif self.comm.size == 1:
                 # single domain: correction, push and rho shift are cell-local -> one launch
                 fld.psatd_step(correct_currents, use_true_rho)
                 if correct_currents:
@@ -226,6 +243,15 @@ class Simulation(object):
         fld.spect2interp('rho_prev')
         if (not fld.exchanged_source['rho_prev']) and (self.comm.size > 1):
             self.comm.exchange_fields(fld.interp, 'rho', 'add')
+
+    def shift_galilean_boundaries(self, dt):
+        """Shift the interpolation grids by v_comoving * dt: only the position attributes
+        change (main.py:772-790)."""
+        shift_distance = self.v_comoving * dt
+        self.comm.shift_global_domain_positions(shift_distance)
+        for m in range(self.fld.Nm):
+            self.fld.interp[m].zmin += shift_distance
+            self.fld.interp[m].zmax += shift_distance
 
     def deposit(self, fieldtype, exchange=False, update_spectral=True, species_list=None):
         """Deposit rho or J on the interpolation grid, then transform and filter

@@ -215,6 +215,22 @@ int fb_push_eb_standard(void *Ep, void *Em, void *Ez, void *Bp, void *Bm, void *
         const double *C, const double *S_w, const double *kr, const double *kz,
         double dt, int use_true_rho, double c, double epsilon_0, double mu_0,
         int Nz, int Nr, void *stream);
+/* Galilean / comoving-current PSATD (fields/spectral_grid.py:240-247, 357-368 ->
+ * cuda_correct_currents_curlfree_comoving, cuda_push_eb_comoving; same argument order as
+ * fields/numba_methods.py:217-241, 278-355 + c, epsilon_0, mu_0).  rho_prev_coef,
+ * rho_next_coef, j_coef, T_eb, T_cc, T_rho, j_corr_coef: complex128 (Nz,Nr) contiguous
+ * tables; C, S_w, kr, kz, inv_k2: float64. */
+int fb_correct_currents_curlfree_comoving(const void *rho_prev, const void *rho_next,
+        void *Jp, void *Jm, void *Jz, long row_stride, const double *kz, const double *kr,
+        const double *inv_k2, const void *j_corr_coef, const void *T_eb, const void *T_cc,
+        int Nz, int Nr, void *stream);
+int fb_push_eb_comoving(void *Ep, void *Em, void *Ez, void *Bp, void *Bm, void *Bz,
+        const void *Jp, const void *Jm, const void *Jz,
+        const void *rho_prev, const void *rho_next, long row_stride,
+        const void *rho_prev_coef, const void *rho_next_coef, const void *j_coef,
+        const double *C, const double *S_w, const void *T_eb, const void *T_cc,
+        const void *T_rho, const double *kr, const double *kz, double dt, double V,
+        int use_true_rho, double c, double epsilon_0, double mu_0, int Nz, int Nr, void *stream);
 /* Single-launch fusion of the three cell-local spectral updates for ALL modes:
  * fields/spectral_grid.py:225-230 (curl-free correction, optional) -> :350-355 (PSATD push)
  * -> :416-417 (rho shift).  fields: HOST array of 11*Nm device pointers, per mode in

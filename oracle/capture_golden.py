@@ -435,13 +435,99 @@ def cap_lwfa():
         save('lwfa_' + shape, **res)
 
 
+def cap_galilean():
+    """Galilean / comoving-current PSATD: coefficient tables, the two
+    spectral kernels, and short whole-cycle trajectories of a drifting periodic plasma."""
+    from fbpic.fields import Fields
+    from fbpic.fields.numba_methods import numba_push_eb_comoving, \
+        numba_correct_currents_curlfree_comoving
+    from fbpic.main import Simulation
+    rng = np.random.default_rng(505)
+    Nz, Nr, Nm = 32, 16, 2
+    dz, dr = 0.25e-6, 0.5e-6
+    dt = dz / c
+    names = ['Ep', 'Em', 'Ez', 'Bp', 'Bm', 'Bz', 'Jp', 'Jm', 'Jz', 'rho_prev', 'rho_next']
+    res = dict(Nz=Nz, Nr=Nr, Nm=Nm, dz=dz, dr=dr, dt=dt)
+    for tag, V, gal in (('gal', 0.9 * c, True), ('com', -0.5 * c, False), ('gal0', 0., True)):
+        f = Fields(Nz, Nz * dz, Nr, Nr * dr, Nm, dt, n_order=-1, zmin=0.,
+                   current_correction='curl-free', v_comoving=V, use_galilean=gal)
+        res['%s_V' % tag] = V
+        for m in range(Nm):
+            sp, ps = f.spect[m], f.psatd[m]
+            for k in ('C', 'S_w', 'j_coef', 'rho_prev_coef', 'rho_next_coef', 'T_eb', 'T_cc',
+                      'T_rho', 'j_corr_coef'):
+                res['%s_%s_m%d' % (tag, k, m)] = np.asarray(getattr(ps, k))
+            for k in ('kz', 'kr', 'inv_k2'):
+                res['%s_%s_m%d' % (tag, k, m)] = np.asarray(getattr(sp, k))
+            scale = dict(E=1e9, B=3., J=1e12, r=1e4)
+            arrs = {k: (rng.normal(size=(Nz, Nr)) + 1j * rng.normal(size=(Nz, Nr))) * scale[k[0]]
+                    for k in names}
+            for k in names:
+                res['%s_in_%s_m%d' % (tag, k, m)] = arrs[k].copy()
+            cc = {k: arrs[k].copy() for k in names}
+            numba_correct_currents_curlfree_comoving(
+                cc['rho_prev'], cc['rho_next'], cc['Jp'], cc['Jm'], cc['Jz'], sp.kz, sp.kr,
+                sp.inv_k2, ps.j_corr_coef, ps.T_eb, ps.T_cc, 1. / dt, Nz, Nr)
+            for k in ('Jp', 'Jm', 'Jz'):
+                res['%s_cc_%s_m%d' % (tag, k, m)] = cc[k]
+            for utr in (False, True):
+                pe = {k: arrs[k].copy() for k in names}
+                numba_push_eb_comoving(
+                    pe['Ep'], pe['Em'], pe['Ez'], pe['Bp'], pe['Bm'], pe['Bz'], pe['Jp'], pe['Jm'],
+                    pe['Jz'], pe['rho_prev'], pe['rho_next'], ps.rho_prev_coef, ps.rho_next_coef,
+                    ps.j_coef, ps.C, ps.S_w, ps.T_eb, ps.T_cc, ps.T_rho, sp.kr, sp.kz, ps.dt,
+                    ps.V, utr, Nz, Nr)
+                for k in names[:6]:
+                    res['%s_pe%d_%s_m%d' % (tag, int(utr), k, m)] = pe[k]
+    save('galilean_kernels', **res)
+    # whole cycle: periodic box, plasma drifting at uz_m, grid following it (Galilean) or
+    # currents assumed comoving
+    # (comoving currents without a Galilean grid: the plasma crosses ~1 cell of the periodic
+    # box per step, which the reference's cubic deposition only tolerates up to half a cell
+    # beyond the box -> linear shape there, cubic with the Galilean grid)
+    for name, shape, gal, n_order in (('cycle_galilean_cub_16x8', 'cubic', True, -1),
+                                      ('cycle_comoving_lin_16x8', 'linear', False, -1),
+                                      ('cycle_galilean_lin_32x8_o8', 'linear', True, 8)):
+        Nz = 32 if n_order > 0 else 16
+        Nr, Nm = 8, 2
+        dz = 0.2e-6
+        zmax, rmax = Nz * dz, Nr * 0.3125e-6
+        dt = dz / c
+        gamma_b = 3.
+        beta_b = -np.sqrt(1. - 1. / gamma_b**2)
+        np.random.seed(9)
+        sim = Simulation(Nz, zmax, Nr, rmax, Nm, dt, 0., zmax, 0., 0.9 * rmax, 2, 2, 4, 2.e24,
+                         n_order=n_order, particle_shape=shape, verbose_level=0,
+                         v_comoving=beta_b * c, use_galilean=gal, initialize_ions=False,
+                         n_guard=(None if n_order == -1 else 8))
+        sp0 = sim.ptcl[0]
+        rng2 = np.random.default_rng(2)
+        sp0.uz[:] = gamma_b * beta_b + 0.01 * rng2.normal(size=sp0.Ntot)
+        sp0.ux[:] = 0.01 * rng2.normal(size=sp0.Ntot)
+        sp0.uy[:] = 0.01 * rng2.normal(size=sp0.Ntot)
+        sp0.inv_gamma[:] = 1. / np.sqrt(1. + sp0.ux**2 + sp0.uy**2 + sp0.uz**2)
+        res = dict(Nz=Nz, Nr=Nr, Nm=Nm, zmax=zmax, rmax=rmax, dt=dt, n_order=n_order, shape=shape,
+                   v_comoving=beta_b * c, use_galilean=gal, n_species=1,
+                   q=np.array([s.q for s in sim.ptcl]), m=np.array([s.m for s in sim.ptcl]))
+        snapshot(sim, 's0', res, spect=False)
+        res['s0_zmin'] = sim.fld.interp[0].zmin
+        done = 0
+        for upto in (1, 2, 5):
+            sim.step(upto - done, show_progress=False)
+            done = upto
+            snapshot(sim, 's%d' % upto, res)
+            res['s%d_zmin' % upto] = sim.fld.interp[0].zmin
+        save(name, **res)
+
+
 def cap_uniform_rho():
     """Counterpart of tests/test_uniform_rho_deposition.py: only the assertion values."""
     # The assertions are analytic (rho = -n e inside the plasma); no fixture needed.
 
 
 ALL = dict(push=cap_push, gather=cap_gather, deposit=cap_deposit, grid_setup=cap_grid_setup,
-           spectral=cap_spectral, cycle=cap_cycle, bunch=cap_bunch, lwfa=cap_lwfa)
+           spectral=cap_spectral, cycle=cap_cycle, bunch=cap_bunch, lwfa=cap_lwfa,
+           galilean=cap_galilean)
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(ALL)

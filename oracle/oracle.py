@@ -173,6 +173,25 @@ def push_eb_standard(Ep, Em, Ez, Bp, Bm, Bz, Jp, Jm, Jz, rho_prev, rho_next,
                                c_i(int(use_true_rho)), c_i(Nz), c_i(Nr))
 
 
+def correct_currents_curlfree_comoving(rho_prev, rho_next, Jp, Jm, Jz, kz, kr, inv_k2,
+                                       j_corr_coef, T_eb, T_cc):
+    Nz, Nr = Jp.shape
+    lib().orc_correct_currents_curlfree_comoving(
+        _c128(rho_prev), _c128(rho_next), _c128(Jp), _c128(Jm), _c128(Jz), _f64(kz), _f64(kr),
+        _f64(inv_k2), _c128(j_corr_coef), _c128(T_eb), _c128(T_cc), c_i(Nz), c_i(Nr))
+
+
+def push_eb_comoving(Ep, Em, Ez, Bp, Bm, Bz, Jp, Jm, Jz, rho_prev, rho_next,
+                     rho_prev_coef, rho_next_coef, j_coef, C, S_w, T_eb, T_cc, T_rho, kr, kz,
+                     dt, V, use_true_rho):
+    Nz, Nr = Ep.shape
+    lib().orc_push_eb_comoving(
+        _c128(Ep), _c128(Em), _c128(Ez), _c128(Bp), _c128(Bm), _c128(Bz), _c128(Jp), _c128(Jm),
+        _c128(Jz), _c128(rho_prev), _c128(rho_next), _c128(rho_prev_coef), _c128(rho_next_coef),
+        _c128(j_coef), _f64(C), _f64(S_w), _c128(T_eb), _c128(T_cc), _c128(T_rho), _f64(kr),
+        _f64(kz), c_d(dt), c_d(V), c_i(int(use_true_rho)), c_i(Nz), c_i(Nr))
+
+
 def fft_z(a):
     """fourier.py:104-126: unnormalised forward DFT along axis 0."""
     return np.fft.fft(a, axis=0)
@@ -241,7 +260,11 @@ class OracleSim:
     """
 
     def __init__(self, Nz, Nr, Nm, zmin, zmax, rmax, dt, shape, tables, species,
-                 nthreads=1, filter_currents=True):
+                 nthreads=1, filter_currents=True, v_comoving=None, use_galilean=False):
+        # Galilean / comoving-current PSATD (main.py:269-273, 496-497, 524-525): tables then
+        # also hold T_eb, T_cc, T_rho, j_corr_coef and complex source coefficients
+        self.v_comoving = v_comoving
+        self.use_galilean = bool(use_galilean) if v_comoving is not None else False
         self.Nz, self.Nr, self.Nm = Nz, Nr, Nm
         self.zmin, self.zmax, self.rmax = zmin, zmax, rmax
         self.dz = (zmax - zmin) / Nz
@@ -347,6 +370,11 @@ class OracleSim:
                    self.invdz, self.zmin, self.Nz, self.invdr, 0., self.Nr, grids,
                    s['Ex'], s['Ey'], s['Ez'], s['Bx'], s['By'], s['Bz'])
 
+    def shift_galilean_boundaries(self, dt):
+        """main.py:772-790: only the grid position moves."""
+        self.zmin += self.v_comoving * dt
+        self.zmax += self.v_comoving * dt
+
     def step(self, N=1, correct_currents=True, use_true_rho=False):
         dt = self.dt
         self.interp2spect('E')
@@ -365,21 +393,38 @@ class OracleSim:
                            s['Bx'], s['By'], s['Bz'], s['q'], s['m'], dt)
             for s in self.species:
                 push_x(s['x'], s['y'], s['z'], s['ux'], s['uy'], s['uz'], s['inv_gamma'], 0.5 * dt)
+            if self.use_galilean:
+                self.shift_galilean_boundaries(0.5 * dt)
             self.deposit('J')
             for s in self.species:
                 push_x(s['x'], s['y'], s['z'], s['ux'], s['uy'], s['uz'], s['inv_gamma'], 0.5 * dt)
+            if self.use_galilean:
+                self.shift_galilean_boundaries(0.5 * dt)
             self.deposit('rho_next')
+            V = self.v_comoving
             if correct_currents:
                 for m in range(self.Nm):
                     sp, t = self.spect[m], self.t[m]
-                    correct_currents_curlfree(sp['rho_prev'], sp['rho_next'], sp['Jp'], sp['Jm'],
-                                              sp['Jz'], t['kz'], t['kr'], t['inv_k2'], 1. / dt)
+                    if V is None:
+                        correct_currents_curlfree(sp['rho_prev'], sp['rho_next'], sp['Jp'], sp['Jm'],
+                                                  sp['Jz'], t['kz'], t['kr'], t['inv_k2'], 1. / dt)
+                    else:
+                        correct_currents_curlfree_comoving(
+                            sp['rho_prev'], sp['rho_next'], sp['Jp'], sp['Jm'], sp['Jz'], t['kz'],
+                            t['kr'], t['inv_k2'], t['j_corr_coef'], t['T_eb'], t['T_cc'])
             for m in range(self.Nm):
                 sp, t = self.spect[m], self.t[m]
-                push_eb_standard(sp['Ep'], sp['Em'], sp['Ez'], sp['Bp'], sp['Bm'], sp['Bz'],
-                                 sp['Jp'], sp['Jm'], sp['Jz'], sp['rho_prev'], sp['rho_next'],
-                                 t['rho_prev_coef'], t['rho_next_coef'], t['j_coef'],
-                                 t['C'], t['S_w'], t['kr'], t['kz'], dt, use_true_rho)
+                if V is None:
+                    push_eb_standard(sp['Ep'], sp['Em'], sp['Ez'], sp['Bp'], sp['Bm'], sp['Bz'],
+                                     sp['Jp'], sp['Jm'], sp['Jz'], sp['rho_prev'], sp['rho_next'],
+                                     t['rho_prev_coef'], t['rho_next_coef'], t['j_coef'],
+                                     t['C'], t['S_w'], t['kr'], t['kz'], dt, use_true_rho)
+                else:
+                    push_eb_comoving(sp['Ep'], sp['Em'], sp['Ez'], sp['Bp'], sp['Bm'], sp['Bz'],
+                                     sp['Jp'], sp['Jm'], sp['Jz'], sp['rho_prev'], sp['rho_next'],
+                                     t['rho_prev_coef'], t['rho_next_coef'], t['j_coef'], t['C'],
+                                     t['S_w'], t['T_eb'], t['T_cc'], t['T_rho'], t['kr'], t['kz'],
+                                     dt, V, use_true_rho)
                 sp['rho_prev'][:] = sp['rho_next']
                 sp['rho_next'][:] = 0.
             self.partial_roundtrip('E')
@@ -412,6 +457,10 @@ def tables_from_sim(sim):
             C=ps.C, S_w=ps.S_w, j_coef=ps.j_coef, rho_prev_coef=ps.rho_prev_coef,
             rho_next_coef=ps.rho_next_coef, invvol=it.invvol,
             ruyten_linear=it.ruyten_linear_coef, ruyten_cubic=it.ruyten_cubic_coef))
+        if ps.V is not None:
+            for k in ('j_coef', 'rho_prev_coef', 'rho_next_coef', 'T_eb', 'T_cc', 'T_rho',
+                      'j_corr_coef'):
+                tabs[-1][k] = np.ascontiguousarray(getattr(ps, k), dtype=np.complex128)
     return tabs
 
 
@@ -428,7 +477,8 @@ def from_sim(sim, nthreads=1):
         species.append(d)
     o = OracleSim(fld.Nz, fld.Nr, fld.Nm, g0.zmin, g0.zmax, fld.rmax, sim.dt,
                   sim.particle_shape, tables_from_sim(sim), species, nthreads=nthreads,
-                  filter_currents=sim.filter_currents)
+                  filter_currents=sim.filter_currents, v_comoving=sim.v_comoving,
+                  use_galilean=sim.use_galilean)
     for m in range(fld.Nm):
         for k in INTERP:
             o.interp[m][k][:] = getattr(fld.interp[m], k)

@@ -70,6 +70,22 @@ def test_cycle_vs_reference_golden(name):
         compare_state(sim, g, 's%d' % upto, tol, tol)
 
 
+@pytest.mark.parametrize('name', ['cycle_galilean_cub_16x8', 'cycle_comoving_lin_16x8',
+                                  'cycle_galilean_lin_32x8_o8'])
+def test_galilean_cycle_vs_reference_golden(name):
+    """Galilean / comoving-current PSATD against the reference's
+    trajectory of a plasma drifting at gamma = 3: all grids, all particle arrays, and the
+    position of the (Galilean) grid after 1, 2 and 5 steps."""
+    g = golden(name)
+    sim = build_from_golden(g, name)
+    done = 0
+    for upto, tol in ((1, 5e-13), (2, 2e-12), (5, 2e-11)):
+        sim.step(upto - done)
+        done = upto
+        compare_state(sim, g, 's%d' % upto, tol, tol)
+        assert abs(sim.fld.interp[0].zmin - float(g['s%d_zmin' % upto])) <= 1e-15 * float(g['zmax'])
+
+
 @pytest.mark.parametrize('shape', ['linear', 'cubic'])
 def test_bunch_deposition_vs_reference_golden(shape):
     """Counterpart of tests/test_cpu_gpu_deposition.py: rho and J of a Gaussian bunch

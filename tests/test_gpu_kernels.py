@@ -481,6 +481,46 @@ def test_psatd_step_fused_equals_separate(hip, oracle):
                         (correct, utr, m, k)
 
 
+@pytest.mark.parametrize('tag', ['gal', 'com', 'gal0'])
+def test_comoving_spectral_kernels_vs_golden(hip, tag):
+    """fb_correct_currents_curlfree_comoving / fb_push_eb_comoving against the reference's
+    numba kernels (Galilean V = 0.9 c, comoving V = -0.5 c, Galilean V = 0), on slab views."""
+    g = golden('galilean_kernels')
+    Nz, Nr, Nm = int(g['Nz']), int(g['Nr']), int(g['Nm'])
+    V, dt = float(g[tag + '_V']), float(g['dt'])
+    names = ['Ep', 'Em', 'Ez', 'Bp', 'Bm', 'Bz', 'Jp', 'Jm', 'Jz', 'rho_prev', 'rho_next']
+    t = hip.torch()
+    p = hip.ptr
+    for m in range(Nm):
+        tb = {k: dev(hip, np.ascontiguousarray(g['%s_%s_m%d' % (tag, k, m)], dtype=np.complex128))
+              for k in ('j_coef', 'rho_prev_coef', 'rho_next_coef', 'T_eb', 'T_cc', 'T_rho', 'j_corr_coef')}
+        tr = {k: dev(hip, np.ascontiguousarray(g['%s_%s_m%d' % (tag, k, m)], dtype=np.float64))
+              for k in ('C', 'S_w', 'kz', 'kr', 'inv_k2')}
+
+        def slab_with_inputs():
+            slab = t.zeros((Nz, 12, Nr), dtype=t.complex128, device='cuda')
+            for i, k in enumerate(names):
+                slab[:, i, :] = dev(hip, g['%s_in_%s_m%d' % (tag, k, m)])
+            return slab, {k: slab[:, i, :] for i, k in enumerate(names)}
+        slab, a = slab_with_inputs()
+        hip.check(hip.lib().fb_correct_currents_curlfree_comoving(
+            p(a['rho_prev']), p(a['rho_next']), p(a['Jp']), p(a['Jm']), p(a['Jz']), 12 * Nr,
+            p(tr['kz']), p(tr['kr']), p(tr['inv_k2']), p(tb['j_corr_coef']), p(tb['T_eb']),
+            p(tb['T_cc']), Nz, Nr, hip.stream()), 'cc comoving')
+        for k in ('Jp', 'Jm', 'Jz'):
+            assert rel_err(host(a[k]), g['%s_cc_%s_m%d' % (tag, k, m)]) < TOL, (m, k)
+        for utr in (0, 1):
+            slab, a = slab_with_inputs()
+            hip.check(hip.lib().fb_push_eb_comoving(
+                *[p(a[k]) for k in names], 12 * Nr, p(tb['rho_prev_coef']), p(tb['rho_next_coef']),
+                p(tb['j_coef']), p(tr['C']), p(tr['S_w']), p(tb['T_eb']), p(tb['T_cc']), p(tb['T_rho']),
+                p(tr['kr']), p(tr['kz']), dt, V, utr, c, epsilon_0, mu_0, Nz, Nr, hip.stream()),
+                'push comoving')
+            for k in names[:6]:
+                assert rel_err(host(a[k]), g['%s_pe%d_%s_m%d' % (tag, utr, k, m)]) < TOL, (m, utr, k)
+            assert np.all(host(slab[:, 11, :]) == 0)
+
+
 @pytest.mark.parametrize('shape', ['linear', 'cubic'])
 def test_gather_push_fused_is_bit_identical_to_sequence(hip, shape):
     """fb_gather_push == fb_gather -> fb_push_p -> fb_push_x (same arithmetic, same bits)."""

@@ -59,3 +59,22 @@ def test_oracle_bunch_vs_reference(oracle, shape):
                 grp = [0, 1, 2] if i < 3 else [3]
                 tol = 1.e-13 * 2 * np.abs(ref[:, grp]).max()
                 assert np.abs(o.interp[m][k] - ref[m, i]).max() <= tol, (it, m, k)
+
+
+GALILEAN = ['cycle_galilean_cub_16x8', 'cycle_comoving_lin_16x8', 'cycle_galilean_lin_32x8_o8']
+
+
+@pytest.mark.parametrize('name', GALILEAN)
+def test_oracle_galilean_cycle_vs_reference(oracle, name):
+    """Galilean / comoving-current PSATD: drifting periodic plasma, grid
+    following it (Galilean) or comoving currents, infinite and finite stencil order."""
+    g = golden(name)
+    sim = helpers.build_from_golden(g, name)
+    assert sim.use_galilean == bool(g['use_galilean']) and sim.v_comoving == float(g['v_comoving'])
+    o = oracle.from_sim(sim, nthreads=1)
+    done = 0
+    for upto, tol in ((1, 1e-13), (2, 5e-13), (5, 5e-12)):
+        o.step(upto - done)
+        done = upto
+        _check(o, g, 's%d' % upto, tol)
+        assert abs(o.zmin - float(g['s%d_zmin' % upto])) <= 1e-15 * abs(float(g['zmax']))
