@@ -36,8 +36,9 @@ WORK = {
     'fb_push_x': ('hbm', lambda a: 80.0 * a[0]),
     'fb_push_p': ('hbm', lambda a: 112.0 * a[0]),
     'fb_gather': ('hbm', lambda a: 72.0 * a[2]),
-    # fused gather+push_p+push_x: 56 B read + 56 B written + 48 B of stored E,B (union rule)
-    'fb_gather_push': ('hbm', lambda a: 160.0 * a[2]),
+    # fused gather+push_p+push_x: 56 B read + 56 B written (+ 48 B when E,B are stored for an
+    # observer: last iteration of a step() call), union rule of SURVEY.md 8d
+    'fb_gather_push': ('hbm', lambda a: (160.0 if a[19] is not None else 112.0) * a[2]),
     'fb_deposit_rho': ('hbm', lambda a: 32.0 * a[2]),
     'fb_deposit_J': ('hbm', lambda a: 64.0 * a[2]),
     # J deposition + cell/rank of the pushed position for the next sort: 64 B read + 8 B written

@@ -25,7 +25,7 @@ _SIGNATURES = {
     'fb_shift_periodic': (I, [L, P, D, D, P]),
     'fb_gather': (I, [I, I, L, P, P, P, D, D, D, I, D, D, I, _PP, L, P, P, P, P, P, P, P]),
     'fb_gather_push': (I, [I, I, L, P, P, P, P, P, P, P, D, D, D, I, D, D, I, _PP, L,
-                           P, P, P, P, P, P, D, D, D, D, D, P]),
+                           P, P, P, P, P, P, D, D, D, D, D, D, D, P]),
     'fb_cell_index': (I, [L, P, P, P, D, D, I, D, D, I, P, P, P]),
     'fb_sort_workspace_bytes': (Z, [L, I]),
     'fb_sort_by_cell': (I, [L, I, P, P, P, P, ctypes.POINTER(I), P, P, Z, P]),

@@ -132,6 +132,9 @@ struct PushArgs {
     double *ux, *uy, *uz, *ig;    // null -> gather only
     double econst, bconst;        // q dt / (m c), q dt / (2 m)
     double chdt;                  // c * dt_x ; 0 -> no position push
+    // periodic wrap of z into [wzmin, wzmax) before the gather (k_shift_periodic folded in;
+    // only with the position push, which rewrites z anyway); wzmax <= wzmin -> off
+    double wzmin, wzmax;
 };
 
 __device__ __forceinline__ double2 ldc(const cplx *p) { return *(const double2 *)p; }
@@ -178,7 +181,13 @@ __global__ __launch_bounds__(256) void k_gather(int Nm_arg, long n,
         double cs = 1., sn = 0., Sz[S], Sr[S];
         int kz = G_NOKEY, kr = G_NOKEY;
         bool inside = false;
-        const double xj = xn, yj = yn, zj = zn;
+        const double xj = xn, yj = yn;
+        double zj = zn;
+        if (PA.wzmax > PA.wzmin) {
+            const double l_box = PA.wzmax - PA.wzmin;
+            while (zj >= PA.wzmax) zj -= l_box;
+            while (zj < PA.wzmin) zj += l_box;
+        }
         if (ch + 1 < chunks_per_wave && i + 64 < n) { xn = x[i + 64]; yn = y[i + 64]; zn = z[i + 64]; }
         double pux = 0., puy = 0., puz = 0., pig = 0.;
         if (PA.ux && act) { pux = PA.ux[i]; puy = PA.uy[i]; puz = PA.uz[i]; pig = PA.ig[i]; }
@@ -434,7 +443,8 @@ extern "C" int fb_gather_push(int shape, int Nm, long n, double *x, double *y, d
         double rmax_gather, double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
         const void *const *grids, long row_stride,
         double *Ex, double *Ey, double *Ez, double *Bx, double *By, double *Bz,
-        double q, double m, double c, double dt, double dt_x, void *stream)
+        double q, double m, double c, double dt, double dt_x, double wrap_zmin, double wrap_zmax,
+        void *stream)
 {
     PushArgs PA;
     PA.x = x; PA.y = y; PA.z = z;
@@ -442,6 +452,11 @@ extern "C" int fb_gather_push(int shape, int Nm, long n, double *x, double *y, d
     PA.econst = q * dt / (m * c);
     PA.bconst = 0.5 * q * dt / m;
     PA.chdt = c * dt_x;
+    PA.wzmin = wrap_zmin; PA.wzmax = wrap_zmax;
+    if (wrap_zmax > wrap_zmin && dt_x == 0.) {
+        set_error("fb_gather_push", "the periodic wrap needs the position push (dt_x != 0)");
+        return -1;
+    }
     return launch_gather(shape, Nm, n, x, y, z, rmax_gather, invdz, zmin, Nz, invdr, rmin, Nr,
                          grids, row_stride, Ex, Ey, Ez, Bx, By, Bz, PA, (hipStream_t)stream,
                          "fb_gather_push");

@@ -228,6 +228,30 @@ class Fields(object):
             _capi.check(lib.fb_hankel(nf, pa(scr_f), self.d_scratch.stride(0), pa(out), self.d_spect.stride(0),
                                       pa(mats), 1.0, Nz, Nr, st), 'fb_hankel')
 
+    def interp2spect_J_and_rho_next(self, fuse_filter=False):
+        """interp2spect('J') and interp2spect('rho_next') of freshly deposited (un-normalised)
+        sources in ONE z-FFT launch and ONE Hankel launch: J and rho are adjacent in the
+        interpolation slab, and a Hankel launch takes any list of jobs.  Same arithmetic per
+        field as the two separate calls with fuse_divide_by_volume=True."""
+        self._need_gpu()
+        Nm, Nz, Nr = self.Nm, self.Nz, self.Nr
+        lib, pa, st = _capi.lib(), _capi.ptr_array, _capi.stream()
+        nJ, nf = 3 * Nm, 4 * Nm
+        fft_exec(self.d_interp[:, 6 * Nm, :], self.d_scratch[:, 0, :], -1, ncols=nf * Nr)
+        scr_f = self._field_views(self.d_scratch, 0, nf)
+        r, t = pa(scr_f[0:nJ:3]), pa(scr_f[1:nJ:3])
+        _capi.check(lib.fb_rt_to_pm(Nm, r, t, r, t, self.d_scratch.stride(0), Nz, Nr, st),
+                    'fb_rt_to_pm')
+        out = self._field_views(self.d_spect, 6 * Nm, nJ) + self._field_views(self.d_spect, 10 * Nm, Nm)
+        mats = self._mats['vec_fwd'] + self._mats['scal_fwd']
+        mode_of = [(j // 3) % Nm for j in range(nJ)] + list(range(Nm))
+        sk = [self.interp[m].d_invvol for m in mode_of]
+        fz = [self.spect[m].d_filter_array_z if fuse_filter else None for m in mode_of]
+        fr = [self.spect[m].d_filter_array_r if fuse_filter else None for m in mode_of]
+        _capi.check(lib.fb_hankel_scaled(nf, pa(scr_f), self.d_scratch.stride(0), pa(out),
+                                         self.d_spect.stride(0), pa(mats), pa(sk), pa(fz), pa(fr),
+                                         1.0, Nz, Nr, st), 'fb_hankel_scaled')
+
     def spect2interp(self, fieldtype):
         """inverse DHT(r) then inverse FFT(z) (reference: fields.py:370-429)."""
         self._need_gpu()

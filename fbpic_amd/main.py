@@ -108,6 +108,7 @@ class Simulation(object):
         self.external_fields = []
         self.diags = []
         self.checkpoints = []
+        self._J_transform_pending = False
         self.laser_antennas = []
         self.mirrors = []
         # On a single z-periodic domain the reference re-deposits rho_prev at every step
@@ -152,23 +153,36 @@ class Simulation(object):
         self.comm.damp_EB_open_boundary(fld.interp)
         fld.interp2spect('EB')
         for i_step in range(N):
+            diag_due = any(getattr(d, 'due', lambda it: True)(self.iteration) for d in self.diags)
+            fused = (self.fuse_gather_push and move_momenta and move_positions
+                     and not self.external_fields and not diag_due)
+            wrap_z = None
             if self.iteration % self.comm.exchange_period == 0 or i_step == 0:
-                for species in ptcl:
-                    self.comm.exchange_particles(species, fld, self.time)
-                if (i_step == 0 or self.comm.n_guard != 0 or self.redeposit_rho_prev_every_step
-                        or use_true_rho):
+                need_rho_prev = (i_step == 0 or self.comm.n_guard != 0
+                                 or self.redeposit_rho_prev_every_step or use_true_rho)
+                if fused and not need_rho_prev and self.comm.n_guard == 0:
+                    # single periodic domain: the wrap of z into the box rides along in the
+                    # gather+push launch that comes next (nothing reads z in between)
+                    wrap_z = (fld.interp[0].zmin, fld.interp[0].zmax)
+                else:
+                    for species in ptcl:
+                        self.comm.exchange_particles(species, fld, self.time)
+                if need_rho_prev:
                     self.deposit('rho_prev', exchange=(use_true_rho is True))
             if i_step == 0:
                 self.deposit('J', exchange=True)
             for species in ptcl:
                 species.keep_fields_sorted = True
-            diag_due = any(getattr(d, 'due', lambda it: True)(self.iteration) for d in self.diags)
-            if (self.fuse_gather_push and move_momenta and move_positions
-                    and not self.external_fields and not diag_due):
+            if fused:
                 # nothing observes the particles between gather and the half position push:
                 # one pass instead of three (gather, push_p, push_x)
+                # the gathered E, B are consumed in registers; the per-particle Ex..Bz arrays
+                # are only materialised where something can observe them: on the last
+                # iteration of this call (they then hold the fields of that gather, as after
+                # the reference's step) - diagnostics take the unfused branch below
                 for species in ptcl:
-                    species.gather_push(fld.interp, self.comm, 0.5 * dt)
+                    species.gather_push(fld.interp, self.comm, 0.5 * dt,
+                                        store_fields=(i_step == N - 1), wrap_z=wrap_z)
             else:
                 for species in ptcl:
                     species.gather(fld.interp, self.comm)
@@ -193,7 +207,7 @@ class Simulation(object):
                 # (not with a Galilean grid: zmin moves between this deposit and that sort)
                 for species in ptcl:
                     species.push_after_deposit_J = (0.5 * dt, 1., 1., 1.)
-            self.deposit('J', exchange=(correct_currents is False))
+            self.deposit('J', exchange=(correct_currents is False), defer_transform=True)
             for species in ptcl:
                 species.push_after_deposit_J = None
             if move_positions:
@@ -244,6 +258,12 @@ class Simulation(object):
         if (not fld.exchanged_source['rho_prev']) and (self.comm.size > 1):
             self.comm.exchange_fields(fld.interp, 'rho', 'add')
 
+    def _flush_J_transform(self):
+        """Transform a J whose interp2spect was deferred (see deposit)."""
+        if self._J_transform_pending:
+            self._J_transform_pending = False
+            self.fld.interp2spect('J', fuse_divide_by_volume=True, fuse_filter=self.filter_currents)
+
     def shift_galilean_boundaries(self, dt):
         """Shift the interpolation grids by v_comoving * dt: only the position attributes
         change (main.py:772-790)."""
@@ -253,9 +273,12 @@ class Simulation(object):
             self.fld.interp[m].zmin += shift_distance
             self.fld.interp[m].zmax += shift_distance
 
-    def deposit(self, fieldtype, exchange=False, update_spectral=True, species_list=None):
+    def deposit(self, fieldtype, exchange=False, update_spectral=True, species_list=None,
+                defer_transform=False):
         """Deposit rho or J on the interpolation grid, then transform and filter
-        (main.py:588-670)."""
+        (main.py:588-670).  `defer_transform` (used by step for the J deposit that is followed
+        by deposit('rho_next')): J stays on the interpolation grid and is transformed
+        together with rho_next, in one FFT and one Hankel launch."""
         fld = self.fld
         if species_list is None:
             species_list = [s for s in self.ptcl if not s.is_tracer]
@@ -273,10 +296,20 @@ class Simulation(object):
             # inside step(): divide-by-volume and filter ride along in the Hankel GEMM
             # (the interpolation-grid J / rho are overwritten from spectral space before
             # anything reads them, main.py:572-577)
-            fld.interp2spect(fieldtype, fuse_divide_by_volume=True,
-                             fuse_filter=self.filter_currents)
+            if defer_transform and fieldtype == 'J':
+                self._J_transform_pending = True
+                fld.exchanged_source[fieldtype] = exchange
+                return
+            if fieldtype == 'rho_next' and self._J_transform_pending:
+                self._J_transform_pending = False
+                fld.interp2spect_J_and_rho_next(fuse_filter=self.filter_currents)
+            else:
+                self._flush_J_transform()
+                fld.interp2spect(fieldtype, fuse_divide_by_volume=True,
+                                 fuse_filter=self.filter_currents)
             fld.exchanged_source[fieldtype] = exchange
             return
+        self._flush_J_transform()
         fld.divide_by_volume(kind)
         if exchange and self.comm.size > 1:
             self.comm.exchange_fields(fld.interp, kind, 'add')

@@ -244,13 +244,17 @@ class Particles(object):
                                    p(self.Bz), _capi.stream())
         _capi.check(rc, 'fb_gather')
 
-    def gather_push(self, grid, comm, dt_x, store_fields=True):
+    def gather_push(self, grid, comm, dt_x, store_fields=True, wrap_z=None):
         """gather -> push_p -> push_x(dt_x) in one pass (fb_gather_push): the fused form of
         the three consecutive calls of Simulation.step (main.py:469-490).  Results are
         identical to calling gather(), push_p(), push_x(dt_x) one after the other."""
         self._need_gpu()
         self.flush_pending_push()
         if self.q == 0:
+            if wrap_z is not None:
+                rc = _capi.lib().fb_shift_periodic(self.Ntot, _capi.ptr(self.z), float(wrap_z[0]),
+                                                   float(wrap_z[1]), _capi.stream())
+                _capi.check(rc, 'fb_shift_periodic')
             self.push_x(dt_x)
             return
         Nm = len(grid)
@@ -260,12 +264,14 @@ class Particles(object):
             views += [grid[m].Er, grid[m].Et, grid[m].Ez, grid[m].Br, grid[m].Bt, grid[m].Bz]
         p = _capi.ptr
         eb = [p(getattr(self, k)) if store_fields else None for k in _FIELDS]
+        # wrap_z = (zmin, zmax): the periodic wrap of comm.exchange_particles folded in
+        wz = (0., 0.) if wrap_z is None else (float(wrap_z[0]), float(wrap_z[1]))
         rc = _capi.lib().fb_gather_push(
             _SHAPE[self.particle_shape], Nm, self.Ntot, p(self.x), p(self.y), p(self.z),
             p(self.ux), p(self.uy), p(self.uz), p(self.inv_gamma),
             comm.get_rmax(with_damp=False), g0.invdz, g0.zmin, g0.Nz, g0.invdr, g0.rmin, g0.Nr,
             _capi.ptr_array(views), _capi.row_stride(views[0]), *eb,
-            self.q, self.m, c, self.dt, dt_x, _capi.stream())
+            self.q, self.m, c, self.dt, dt_x, wz[0], wz[1], _capi.stream())
         _capi.check(rc, 'fb_gather_push')
         self._prerank = None
         self.sorted = False

@@ -73,14 +73,17 @@ int fb_gather(int shape, int Nm, long n,
  * in one pass over the particles: E,B stay in registers, the momenta are read and written
  * once.  Same arithmetic as the three separate entry points (bit-identical momenta and
  * positions for identical fields).  Ex..Bz may be NULL (fields not stored); dt_x = 0 skips
- * the position push. */
+ * the position push.  wrap_zmax > wrap_zmin: z is first wrapped into [wrap_zmin, wrap_zmax)
+ * exactly as fb_shift_periodic does (the single-domain periodic exchange_particles that
+ * precedes the gather, main.py:442 / particle_buffer_handling.py:528-531). */
 int fb_gather_push(int shape, int Nm, long n, double *x, double *y, double *z,
                    double *ux, double *uy, double *uz, double *inv_gamma,
                    double rmax_gather, double invdz, double zmin, int Nz,
                    double invdr, double rmin, int Nr,
                    const void *const *grids, long row_stride,
                    double *Ex, double *Ey, double *Ez, double *Bx, double *By, double *Bz,
-                   double q, double m, double c, double dt, double dt_x, void *stream);
+                   double q, double m, double c, double dt, double dt_x,
+                   double wrap_zmin, double wrap_zmax, void *stream);
 
 /* ---- cell sort ---------------------------------------------------------------- */
 /* particles/particles.py:1075-1081 -> get_cell_idx_per_particle

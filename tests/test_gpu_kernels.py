@@ -552,14 +552,28 @@ def test_gather_push_fused_is_bit_identical_to_sequence(hip, shape):
     pos2, mom2, F2 = fresh()
     hip.check(hip.lib().fb_gather_push(sh, nm, n, *[p(a) for a in pos2], *[p(a) for a in mom2], *geom,
                                        hip.ptr_array(views), Nr, *[p(f) for f in F2], -e, m_e, c, dt,
-                                       0.5 * dt, hip.stream()), 'gather_push')
+                                       0.5 * dt, 0., 0., hip.stream()), 'gather_push')
     for a, b in zip(pos + mom + F, pos2 + mom2 + F2):
+        assert np.array_equal(host(a), host(b))
+    # with the periodic wrap folded in == fb_shift_periodic first, then the same call
+    zlo = float(g['z'].min()) + 0.2 * float(g['z'].max() - g['z'].min())
+    zhi = float(g['z'].max()) - 0.2 * float(g['z'].max() - g['z'].min())
+    pos4, mom4, F4 = fresh()
+    hip.check(hip.lib().fb_shift_periodic(n, p(pos4[2]), zlo, zhi, hip.stream()), 'shift')
+    hip.check(hip.lib().fb_gather_push(sh, nm, n, *[p(a) for a in pos4], *[p(a) for a in mom4], *geom,
+                                       hip.ptr_array(views), Nr, *[p(f) for f in F4], -e, m_e, c, dt,
+                                       0.5 * dt, 0., 0., hip.stream()), 'gather_push')
+    pos5, mom5, F5 = fresh()
+    hip.check(hip.lib().fb_gather_push(sh, nm, n, *[p(a) for a in pos5], *[p(a) for a in mom5], *geom,
+                                       hip.ptr_array(views), Nr, *[p(f) for f in F5], -e, m_e, c, dt,
+                                       0.5 * dt, zlo, zhi, hip.stream()), 'gather_push wrap')
+    for a, b in zip(pos4 + mom4 + F4, pos5 + mom5 + F5):
         assert np.array_equal(host(a), host(b))
     # fields not stored, no position push
     pos3, mom3, _ = fresh()
     hip.check(hip.lib().fb_gather_push(sh, nm, n, *[p(a) for a in pos3], *[p(a) for a in mom3], *geom,
                                        hip.ptr_array(views), Nr, *([None] * 6), -e, m_e, c, dt,
-                                       0., hip.stream()), 'gather_push')
+                                       0., 0., 0., hip.stream()), 'gather_push')
     for a, b in zip(mom, mom3):
         assert np.array_equal(host(a), host(b))
     for k, b in zip(('x', 'y', 'z'), pos3):
