@@ -234,11 +234,24 @@ def pmc_traffic(entry):
                                  f['kernel'])}
 
 
+def available_cores():
+    """Cores this process may really use: CPU affinity capped by the cgroup CPU quota (the GPU
+    boxes expose 256 logical CPUs but grant a quota of 16)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(sim, args):
     """CPU oracle (port of the reference's Numba-threaded CPU path) on the same workload:
-    `cpu_steps` full PIC cycles at full size, all host cores."""
+    `cpu_steps` full PIC cycles at full size, one thread per available core."""
     from oracle import oracle as orc
-    nthreads = orc.max_threads()
+    nthreads = min(orc.max_threads(), available_cores())
     o = orc.from_sim(sim, nthreads=nthreads)
     o.step(1)                       # warm-up (thread pools, FFT plans)
     t0 = time.perf_counter()
