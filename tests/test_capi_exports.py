@@ -51,3 +51,31 @@ def test_product_never_imports_the_oracle():
             if f.endswith(('.py', '.hip', '.h')):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert 'oracle' not in txt.lower().replace('no cpu oracle', ''), os.path.join(dirpath, f)
+
+
+def test_fft_length_dispatch_tables():
+    """Host-only queries of the library: which z lengths take the LDS kernel, which the
+    generic pass-per-launch FFT, and the smooth convolution length of the Bluestein fallback."""
+    from fbpic_amd import _capi
+    from fbpic_amd.fields.spectral_transform.fourier import _smooth_length
+    lib = _capi.lib()
+    lds = [n for n in range(2, 5000) if lib.fb_zfft_supported(n)]
+    assert lds == [64, 128, 256, 512, 576, 1024, 1152, 2048, 2304, 4096]
+    assert lib.fb_fft_generic_supported(4416) and lib.fb_fft_generic_supported(2 * 3 * 5 * 7 * 11 * 13)
+    assert lib.fb_fft_generic_supported(31 * 29 * 4)
+    assert not lib.fb_fft_generic_supported(4288) and not lib.fb_fft_generic_supported(37)
+    for n in (1, 2, 97, 8575, 8237, 16385):
+        m = _smooth_length(n)
+        assert m >= n
+        k = m
+        for p in (2, 3, 5):
+            while k % p == 0:
+                k //= p
+        assert k == 1
+        assert all(_smooth_length(n) <= c for c in (1 << (n - 1).bit_length(),))
+
+
+def test_cpu_baseline_uses_the_cores_it_is_given():
+    import bench
+    n = bench.available_cores()
+    assert 1 <= n <= len(__import__('os').sched_getaffinity(0))

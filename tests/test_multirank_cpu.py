@@ -68,6 +68,24 @@ def _worker(rank, world, port, boundary, q):
             for g in interp:
                 for k in names:
                     assert np.array_equal(getattr(g, k).numpy(), getattr(g, k + '_expect')), k
+        # ---------------- 'EB' = E and B in one message per neighbour (what step() uses)
+        names6 = ('Er', 'Et', 'Ez', 'Br', 'Bt', 'Bz')
+        if boundary == 'periodic':
+            interp = []
+            for m in range(NM):
+                g = _Grid()
+                for i, k in enumerate(names6):
+                    G = _global_field(300 + 10 * m + i, NZ)
+                    idx = (np.arange(Nz_l) + iz0) % NZ
+                    loc = G[idx].copy()
+                    loc[:NG] = -7.; loc[-NG:] = -7.
+                    setattr(g, k, torch.from_numpy(loc))
+                    setattr(g, k + '_expect', G[idx])
+                interp.append(g)
+            comm.exchange_fields(interp, 'EB', 'replace')
+            for g in interp:
+                for k in names6:
+                    assert np.array_equal(getattr(g, k).numpy(), getattr(g, k + '_expect')), k
         # ---------------- 'add': overlapping [0,2ng) / [Nz-2ng,Nz) regions are summed
         def local_J(r, m, i, nz):
             return _global_field(1000 + 100 * r + 10 * m + i, nz)
