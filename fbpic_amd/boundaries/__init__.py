@@ -1,0 +1,1 @@
+"""fbpic_amd.boundaries: part of the MI355X (gfx950) backend of the FBPIC per-step PIC cycle."""

@@ -323,6 +323,33 @@ __device__ __forceinline__ void dft_odd(cx *v, const double *cr, const double *s
     for (int u = 0; u < R; u++) v[u] = out[u];
 }
 
+// Composite radix 24 = 3 x 8 in registers (Cooley-Tukey): one pass instead of a radix-8 and a
+// radix-3 pass, i.e. one sweep less over the slab for lengths like 4416 = 24 * 8 * 23.
+//   X[k1 + 3 k2] = sum_n2 W8^(n2 k2) W24^(n2 k1) sum_n1 W3^(n1 k1) x[8 n1 + n2]
+// w24[m] = exp(-+ 2 pi i m / 24) for m < 15 (largest n2 k1 = 7 * 2).
+template <bool FWD>
+__device__ __forceinline__ void dft24(cx *v, const cx *w24)
+{
+    cx y[8][3];
+#pragma unroll
+    for (int n2 = 0; n2 < 8; n2++) {
+        cx t[3] = {v[n2], v[8 + n2], v[16 + n2]};
+        Dft<3, FWD>::run(t);
+        y[n2][0] = t[0];
+        y[n2][1] = n2 ? cmul(t[1], w24[n2]) : t[1];
+        y[n2][2] = n2 ? cmul(t[2], w24[2 * n2]) : t[2];
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < 3; k1++) {
+        cx t[8];
+#pragma unroll
+        for (int n2 = 0; n2 < 8; n2++) t[n2] = y[n2][k1];
+        Dft<8, FWD>::run(t);
+#pragma unroll
+        for (int k2 = 0; k2 < 8; k2++) v[k1 + 3 * k2] = t[k2];
+    }
+}
+
 // roots of unity of order R from the table of N-th roots (tw[j] = exp(-2 pi i j / N))
 template <int R>
 __device__ __forceinline__ void load_roots(const cx *__restrict__ tw, int NR, double *cr, double *sr)
@@ -352,7 +379,7 @@ __global__ __launch_bounds__(256) void k_fft_pass(int N, int NS, long ncols, con
     if (col >= ncols) return;
     const int NR = N / R;
     double cr[R], sr[R];
-    if constexpr (!(R == 2 || R == 4 || R == 8 || R == 3 || R == 9)) load_roots<R>(tw, NR, cr, sr);
+    if constexpr (!(R == 2 || R == 4 || R == 8 || R == 3 || R == 9 || R == 24)) load_roots<R>(tw, NR, cr, sr);
     for (int jj = blockIdx.y; jj < NR; jj += gridDim.y) {
         const int k = jj % NS;
         const int tstep = N / (NS * R);
@@ -367,7 +394,17 @@ __global__ __launch_bounds__(256) void k_fft_pass(int N, int NS, long ncols, con
             }
         }
         cx X[R];
-        if constexpr (R == 2 || R == 4 || R == 8 || R == 3 || R == 9) {
+        if constexpr (R == 24) {
+            cx w24[15];
+#pragma unroll
+            for (int m = 0; m < 15; m++) {
+                w24[m] = tw[m * NR];
+                if (!FWD) w24[m].y = -w24[m].y;
+            }
+            dft24<FWD>(v, w24);
+#pragma unroll
+            for (int u = 0; u < R; u++) X[u] = v[u];
+        } else if constexpr (R == 2 || R == 4 || R == 8 || R == 3 || R == 9) {
             Dft<R, FWD>::run(v);
 #pragma unroll
             for (int u = 0; u < R; u++) X[u] = v[u];
@@ -403,6 +440,7 @@ static void pass_launch(bool fwd, dim3 grid, hipStream_t s, int N, int NS, long 
 static int factorize(int N, int *radix)
 {
     int n = N, np = 0;
+    if (n % 24 == 0 && n % 9 != 0) { radix[np++] = 24; n /= 24; }      // 3 x 8 in one pass
     while (n % 8 == 0) { radix[np++] = 8; n /= 8; }
     while (n % 4 == 0) { radix[np++] = 4; n /= 4; }
     while (n % 2 == 0) { radix[np++] = 2; n /= 2; }
@@ -457,7 +495,7 @@ extern "C" int fb_fft_generic(int Nz, long ncols, const void *in, long in_stride
 #define FB_PASS(R) case R: pass_launch<R>(fwd, grid, s, Nz, NS, ncols, src, src_stride, dst, ds, tw, scale); break
         switch (radix[p]) {
         FB_PASS(2); FB_PASS(3); FB_PASS(4); FB_PASS(5); FB_PASS(7); FB_PASS(8); FB_PASS(9); FB_PASS(11);
-        FB_PASS(13); FB_PASS(17); FB_PASS(19); FB_PASS(23); FB_PASS(29); FB_PASS(31);
+        FB_PASS(13); FB_PASS(17); FB_PASS(19); FB_PASS(23); FB_PASS(24); FB_PASS(29); FB_PASS(31);
         }
 #undef FB_PASS
         NS *= radix[p];
