@@ -35,6 +35,13 @@ struct HankelJobs {
     cplx *out[HK_MAXJOBS];
     const double *mat[HK_MAXJOBS];
 };
+// Optional (r, t) -> (p | m) combination fused into the operand load (rt_to_pm of
+// spectral_transformer.py:208-210 without a sweep of its own): the input of job j is
+// 0.5 * (in[j] + sgn[j] * i * in2[j]) when in2[j] != 0, i.e. p for sgn = -1, m for sgn = +1.
+struct HankelPairs {
+    const cplx *in2[HK_MAXJOBS];
+    double sgn[HK_MAXJOBS];
+};
 struct HankelScales {
     const double *sk[HK_MAXJOBS];     // per input column k (e.g. 1/volume), or null
     const double *fz[HK_MAXJOBS];     // per output row iz (filter along z), or null
@@ -70,13 +77,15 @@ constexpr size_t HK_LDS_BYTES = (size_t)2 * (HK_ABUF + HK_BBUF) * 8;
 //   written to the other LDS buffer; one barrier per chunk.  MFMA operands come from LDS
 //   (padded panels, conflict-free ds_read_b128 / ds_read_b64), so the vector-memory path
 //   only sees coalesced traffic and each matrix element is fetched once per workgroup.
-template <bool SCALED>
-__global__ __launch_bounds__(256) void k_hankel(HankelJobs J, HankelScales Sc, long irs, long ors,
-                                                double alpha, int Nz, int Nr)
+template <bool SCALED, bool PAIRED>
+__global__ __launch_bounds__(256) void k_hankel(HankelJobs J, HankelScales Sc, HankelPairs Pr, long irs,
+                                                long ors, double alpha, int Nz, int Nr)
 {
     extern __shared__ double hk_lds[];
     const int job = blockIdx.z;
     const cplx *__restrict__ in = J.in[job];
+    const cplx *__restrict__ in2 = PAIRED ? Pr.in2[job] : nullptr;
+    const double psgn = PAIRED ? Pr.sgn[job] : 0.;
     cplx *__restrict__ out = J.out[job];
     const double *__restrict__ mat = J.mat[job];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -104,6 +113,12 @@ __global__ __launch_bounds__(256) void k_hankel(HankelJobs J, HankelScales Sc, l
             double2 v = make_double2(0., 0.);
             if (zz < Nz && k < Nr) {
                 v = *(const double2 *)(in + (long)zz * irs + k);
+                if (PAIRED && in2) {
+                    // numba_rt_to_pm: p = 0.5 (r - i t), m = 0.5 (r + i t)
+                    const double2 w_ = *(const double2 *)(in2 + (long)zz * irs + k);
+                    v.x = 0.5 * (v.x - psgn * w_.y);
+                    v.y = 0.5 * (v.y + psgn * w_.x);
+                }
                 if (SCALED && sk) { const double s_ = sk[k]; v.x *= s_; v.y *= s_; }
             }
             ra[j] = v;
@@ -179,15 +194,20 @@ __global__ __launch_bounds__(256) void k_hankel(HankelJobs J, HankelScales Sc, l
 
 static int launch(int njobs, const void *const *in, long irs, void *const *out, long ors,
                   const double *const *mat, const double *const *sk, const double *const *fz,
-                  const double *const *fr, double alpha, int Nz, int Nr, hipStream_t s)
+                  const double *const *fr, double alpha, int Nz, int Nr, hipStream_t s,
+                  const void *const *in2 = nullptr, const double *pair_sign = nullptr)
 {
-    const bool scaled = sk || fz || fr;
+    const bool scaled = sk || fz || fr || in2;
+    const bool paired = in2 != nullptr;
     for (int j0 = 0; j0 < njobs; j0 += HK_MAXJOBS) {
         const int nj = njobs - j0 < HK_MAXJOBS ? njobs - j0 : HK_MAXJOBS;
         HankelJobs J;
         HankelScales Sc;
+        HankelPairs Pr;
         for (int j = 0; j < HK_MAXJOBS; j++) {
             const bool v = j < nj;
+            Pr.in2[j] = (v && paired) ? (const cplx *)in2[j0 + j] : nullptr;
+            Pr.sgn[j] = (v && paired && pair_sign) ? pair_sign[j0 + j] : 0.;
             J.in[j] = v ? (const cplx *)in[j0 + j] : nullptr;
             J.out[j] = v ? (cplx *)out[j0 + j] : nullptr;
             J.mat[j] = v ? mat[j0 + j] : nullptr;
@@ -198,18 +218,24 @@ static int launch(int njobs, const void *const *in, long irs, void *const *out, 
         dim3 grid((Nz + HK_TZ - 1) / HK_TZ, (Nr + 63) / 64, nj);
         static bool attr_done = false;
         if (!attr_done) {
-            hipError_t e1 = hipFuncSetAttribute((const void *)k_hankel<true>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)HK_LDS_BYTES);
-            hipError_t e2 = hipFuncSetAttribute((const void *)k_hankel<false>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)HK_LDS_BYTES);
-            if (e1 != hipSuccess) return check(e1, "fb_hankel(attr)");
-            if (e2 != hipSuccess) return check(e2, "fb_hankel(attr)");
+            const void *ks[3] = {(const void *)k_hankel<true, true>, (const void *)k_hankel<true, false>,
+                                 (const void *)k_hankel<false, false>};
+            for (int i = 0; i < 3; i++) {
+                hipError_t e1 = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    (int)HK_LDS_BYTES);
+                if (e1 != hipSuccess) return check(e1, "fb_hankel(attr)");
+            }
             attr_done = true;
         }
-        if (scaled)
-            hipLaunchKernelGGL(k_hankel<true>, grid, dim3(256), HK_LDS_BYTES, s, J, Sc, irs, ors, alpha, Nz, Nr);
+        if (paired)
+            hipLaunchKernelGGL((k_hankel<true, true>), grid, dim3(256), HK_LDS_BYTES, s, J, Sc, Pr, irs, ors,
+                               alpha, Nz, Nr);
+        else if (scaled)
+            hipLaunchKernelGGL((k_hankel<true, false>), grid, dim3(256), HK_LDS_BYTES, s, J, Sc, Pr, irs, ors,
+                               alpha, Nz, Nr);
         else
-            hipLaunchKernelGGL(k_hankel<false>, grid, dim3(256), HK_LDS_BYTES, s, J, Sc, irs, ors, alpha, Nz, Nr);
+            hipLaunchKernelGGL((k_hankel<false, false>), grid, dim3(256), HK_LDS_BYTES, s, J, Sc, Pr, irs, ors,
+                               alpha, Nz, Nr);
         int r = check(hipGetLastError(), "fb_hankel");
         if (r) return r;
     }
@@ -238,4 +264,18 @@ extern "C" int fb_hankel_scaled(int njobs, const void *const *in, long in_row_st
     if (njobs <= 0) return 0;
     return launch(njobs, in, in_row_stride, out, out_row_stride, mat, in_col_scale, out_row_scale,
                   out_col_scale, alpha, Nz, Nr, (hipStream_t)stream);
+}
+
+extern "C" int fb_hankel_rt_to_pm_scaled(int njobs, const void *const *in, const void *const *in2,
+                                         const double *pair_sign, long in_row_stride,
+                                         void *const *out, long out_row_stride,
+                                         const double *const *mat, const double *const *in_col_scale,
+                                         const double *const *out_row_scale,
+                                         const double *const *out_col_scale, double alpha, int Nz,
+                                         int Nr, void *stream)
+{
+    if (njobs <= 0) return 0;
+    if (!in2 || !pair_sign) { set_error("fb_hankel_rt_to_pm_scaled", "in2 and pair_sign are required"); return -1; }
+    return launch(njobs, in, in_row_stride, out, out_row_stride, mat, in_col_scale, out_row_scale,
+                  out_col_scale, alpha, Nz, Nr, (hipStream_t)stream, in2, pair_sign);
 }

@@ -153,10 +153,13 @@ typedef ZCfg<2304, 2, 128, 9, 4, 4, 4, 4> ZC2304;
 //   R-point DFT, outputs to rows (jj - jj mod NS) R + jj mod NS + t NS.
 // The first pass reads the grid, the last one writes it; the others exchange in place
 // through LDS: every lane reads all of its points, barrier, then writes them.
+// pm: 0 = plain load; 1 = this column is an r slot, r = p + m with m one field (gin2) to the
+// right; 2 = a t slot, t = i (p - m) with p one field to the left (numba_pm_to_rt,
+// spectral_transformer.py:140-142, folded into the first pass of the backward transform)
 template <class Z, int R, int NS, bool FWD, bool FIRST, bool LAST>
 __device__ __forceinline__ void zf_pass(cx *lds, const cx *__restrict__ tw,
         const cx *gin, long in_stride, cx *gout, long out_stride,
-        int c, int jj0, bool col_ok, double scale)
+        int c, int jj0, bool col_ok, double scale, int pm = 0, const cx *gin2 = nullptr)
 {
     constexpr int N = Z::N, C = Z::C, NB = Z::E / R, JSTEP = Z::NTHR / C;
     constexpr int NR = N / R;
@@ -169,8 +172,15 @@ __device__ __forceinline__ void zf_pass(cx *lds, const cx *__restrict__ tw,
 #pragma unroll
         for (int t = 0; t < R; t++) {
             const int row = jj + t * NR;
-            if (FIRST) v[b][t] = col_ok ? gin[(long)row * in_stride] : make_double2(0., 0.);
-            else v[b][t] = lds[row * C + c + (row >> 3)];
+            if (FIRST) {
+                cx a = col_ok ? gin[(long)row * in_stride] : make_double2(0., 0.);
+                if (pm != 0 && col_ok) {
+                    const cx o = gin2[(long)row * in_stride];
+                    if (pm == 1) a = cadd(a, o);                               // p + m
+                    else { const cx d = csub(o, a); a = make_double2(-d.y, d.x); }  // i (p - m)
+                }
+                v[b][t] = a;
+            } else v[b][t] = lds[row * C + c + (row >> 3)];
         }
     }
 #pragma unroll
@@ -209,7 +219,7 @@ __device__ __forceinline__ void zf_pass(cx *lds, const cx *__restrict__ tw,
 
 template <class Z, bool FWD>
 __global__ __launch_bounds__(Z::NTHR) void k_zfft(long ncols, const cx *in, long in_stride,
-        cx *out, long out_stride, const cx *__restrict__ tw, double scale, int ntiles)
+        cx *out, long out_stride, const cx *__restrict__ tw, double scale, int ntiles, int pm_Nr)
 {
     constexpr int C = Z::C;
     extern __shared__ double2 zf_lds[];
@@ -224,10 +234,18 @@ __global__ __launch_bounds__(Z::NTHR) void k_zfft(long ncols, const cx *in, long
     const bool col_ok = col < ncols;
     const cx *gin = in + col;
     cx *gout = out + col;
+    // pm_Nr > 0: the columns are groups of (p, m, z) fields of pm_Nr columns each
+    int pm = 0;
+    const cx *gin2 = nullptr;
+    if (pm_Nr > 0) {
+        const int slot = (int)((col / pm_Nr) % 3);
+        if (slot == 0) { pm = 1; gin2 = gin + pm_Nr; }
+        else if (slot == 1) { pm = 2; gin2 = gin - pm_Nr; }
+    }
     constexpr int R0 = Z::R0, R1 = Z::R1, R2 = Z::R2, R3 = Z::R3, R4 = Z::R4;
     constexpr int NPASS = (R1 == 1) ? 1 : (R2 == 1) ? 2 : (R3 == 1) ? 3 : (R4 == 1) ? 4 : 5;
 #define ZF_ARGS zf_lds, tw, gin, in_stride, gout, out_stride, c, jj0, col_ok, scale
-    zf_pass<Z, R0, 1, FWD, true, NPASS == 1>(ZF_ARGS);
+    zf_pass<Z, R0, 1, FWD, true, NPASS == 1>(ZF_ARGS, pm, gin2);
     if constexpr (NPASS >= 2) zf_pass<Z, R1, R0, FWD, false, NPASS == 2>(ZF_ARGS);
     if constexpr (NPASS >= 3) zf_pass<Z, R2, R0 * R1, FWD, false, NPASS == 3>(ZF_ARGS);
     if constexpr (NPASS >= 4) zf_pass<Z, R3, R0 * R1 * R2, FWD, false, NPASS == 4>(ZF_ARGS);
@@ -262,7 +280,7 @@ static int get_twiddles(int N, const cx **out)
 
 template <class Z>
 static int zfft_launch(long ncols, const cx *in, long is, cx *out, long os, int direction,
-                       const cx *tw, hipStream_t s)
+                       const cx *tw, hipStream_t s, int pm_Nr = 0)
 {
     constexpr int N = Z::N, C = Z::C;
     const int ntiles = (int)((ncols + C - 1) / C);
@@ -280,10 +298,10 @@ static int zfft_launch(long ncols, const cx *in, long is, cx *out, long os, int 
     const int nblocks = (ntiles + 7) & ~7;             // multiple of 8 for the XCD mapping
     if (direction < 0)
         hipLaunchKernelGGL((k_zfft<Z, true>), dim3(nblocks), dim3(Z::NTHR), lds_bytes, s, ncols, in,
-                           is, out, os, tw, 1.0, ntiles);
+                           is, out, os, tw, 1.0, ntiles, pm_Nr);
     else
         hipLaunchKernelGGL((k_zfft<Z, false>), dim3(nblocks), dim3(Z::NTHR), lds_bytes, s, ncols, in,
-                           is, out, os, tw, 1.0 / (double)N, ntiles);
+                           is, out, os, tw, 1.0 / (double)N, ntiles, pm_Nr);
     return check(hipGetLastError(), "fb_zfft");
 }
 
@@ -517,22 +535,42 @@ extern "C" int fb_zfft_supported(int Nz)
     }
 }
 
+static int zfft_dispatch(const char *who, int Nz, long ncols, const void *in, long in_stride, void *out,
+                         long out_stride, int direction, int pm_Nr, void *stream);
+
+extern "C" int fb_zfft_pm_to_rt(int Nz, long ncols, const void *in, long in_stride, void *out,
+                                long out_stride, int Nr, void *stream)
+{
+    if (Nr <= 0 || ncols % (3L * Nr) != 0) {
+        set_error("fb_zfft_pm_to_rt", "ncols must be a multiple of 3 * Nr");
+        return -1;
+    }
+    if (in == out) { set_error("fb_zfft_pm_to_rt", "out of place only (a column reads its neighbour field)"); return -1; }
+    return zfft_dispatch("fb_zfft_pm_to_rt", Nz, ncols, in, in_stride, out, out_stride, +1, Nr, stream);
+}
+
 extern "C" int fb_zfft(int Nz, long ncols, const void *in, long in_stride, void *out,
                        long out_stride, int direction, void *stream)
 {
+    return zfft_dispatch("fb_zfft", Nz, ncols, in, in_stride, out, out_stride, direction, 0, stream);
+}
+
+static int zfft_dispatch(const char *who, int Nz, long ncols, const void *in, long in_stride, void *out,
+                         long out_stride, int direction, int pm_Nr, void *stream)
+{
     if (!fb_zfft_supported(Nz)) {
-        set_error("fb_zfft", "unsupported Nz (2^k in [64, 4096] or 9 * 2^k in [576, 2304])");
+        set_error(who, "unsupported Nz (2^k in [64, 4096] or 9 * 2^k in [576, 2304])");
         return -1;
     }
     if (ncols <= 0) return 0;
-    if (in == out && in_stride != out_stride) { set_error("fb_zfft", "in-place needs equal strides"); return -1; }
+    if (in == out && in_stride != out_stride) { set_error(who, "in-place needs equal strides"); return -1; }
     const cx *tw = nullptr;
     int r = get_twiddles(Nz, &tw);
     if (r) return r;
     hipStream_t s = (hipStream_t)stream;
     const cx *a = (const cx *)in;
     cx *b = (cx *)out;
-#define ZF_CASE(n, Z) case n: return zfft_launch<Z>(ncols, a, in_stride, b, out_stride, direction, tw, s)
+#define ZF_CASE(n, Z) case n: return zfft_launch<Z>(ncols, a, in_stride, b, out_stride, direction, tw, s, pm_Nr)
     switch (Nz) {
     ZF_CASE(64, ZC64); ZF_CASE(128, ZC128); ZF_CASE(256, ZC256); ZF_CASE(512, ZC512);
     ZF_CASE(1024, ZC1024); ZF_CASE(2048, ZC2048); ZF_CASE(4096, ZC4096);

@@ -191,6 +191,20 @@ class Fields(object):
             raise NotImplementedError('%s is outside the fbpic_amd scope' % fieldtype)
         raise ValueError('Invalid string for fieldtype: %s' % fieldtype)
 
+    def _rt_pairs(self, scr_f, n_vec):
+        """Job tables of fb_hankel_rt_to_pm_scaled for `n_vec` vector fields (triples r, t, z
+        in `scr_f`) followed by scalar fields: (in, in2, sign) per job."""
+        import ctypes
+        ins, in2, sgn = [], [], []
+        for j, f in enumerate(scr_f):
+            if j < n_vec and j % 3 == 0:        # p = 0.5 (r - i t)
+                ins.append(scr_f[j]); in2.append(scr_f[j + 1]); sgn.append(-1.)
+            elif j < n_vec and j % 3 == 1:      # m = 0.5 (r + i t)
+                ins.append(scr_f[j - 1]); in2.append(scr_f[j]); sgn.append(+1.)
+            else:
+                ins.append(f); in2.append(None); sgn.append(0.)
+        return ins, in2, (ctypes.c_double * len(sgn))(*sgn)
+
     def interp2spect(self, fieldtype, fuse_divide_by_volume=False, fuse_filter=False):
         """FFT(z) then DHT(r) of one field group, all modes at once
         (reference: fields.py:313-368 + spectral_transformer.py:157-223).
@@ -206,21 +220,22 @@ class Fields(object):
         scr = self.d_scratch[:, 0, :]
         fft_exec(src, scr, -1, ncols=nf * Nr)
         scr_f = self._field_views(self.d_scratch, 0, nf)
-        if vec:
-            r = pa(scr_f[0::3])
-            t = pa(scr_f[1::3])
-            _capi.check(lib.fb_rt_to_pm(nf // 3, r, t, r, t, self.d_scratch.stride(0), Nz, Nr, st),
-                        'fb_rt_to_pm')
         out = self._field_views(self.d_spect, fs, nf)
         mats = self._mats['vec_fwd' if vec else 'scal_fwd']
         if fieldtype == 'EB':
             mats = mats + mats
-        if fuse_divide_by_volume or fuse_filter:
-            per = 3 if vec else 1
-            mode_of = [(j // per) % self.Nm for j in range(nf)]
-            sk = [self.interp[m].d_invvol if fuse_divide_by_volume else None for m in mode_of]
-            fz = [self.spect[m].d_filter_array_z if fuse_filter else None for m in mode_of]
-            fr = [self.spect[m].d_filter_array_r if fuse_filter else None for m in mode_of]
+        per = 3 if vec else 1
+        mode_of = [(j // per) % self.Nm for j in range(nf)]
+        sk = [self.interp[m].d_invvol if fuse_divide_by_volume else None for m in mode_of]
+        fz = [self.spect[m].d_filter_array_z if fuse_filter else None for m in mode_of]
+        fr = [self.spect[m].d_filter_array_r if fuse_filter else None for m in mode_of]
+        if vec:
+            # (r, t) -> (p, m) rides along in the operand load of the Hankel GEMM
+            ins, in2, sgn = self._rt_pairs(scr_f, nf)
+            _capi.check(lib.fb_hankel_rt_to_pm_scaled(
+                nf, pa(ins), pa(in2), sgn, self.d_scratch.stride(0), pa(out), self.d_spect.stride(0),
+                pa(mats), pa(sk), pa(fz), pa(fr), 1.0, Nz, Nr, st), 'fb_hankel_rt_to_pm_scaled')
+        elif fuse_divide_by_volume or fuse_filter:
             _capi.check(lib.fb_hankel_scaled(nf, pa(scr_f), self.d_scratch.stride(0), pa(out), self.d_spect.stride(0),
                                              pa(mats), pa(sk), pa(fz), pa(fr), 1.0, Nz, Nr, st),
                         'fb_hankel_scaled')
@@ -239,18 +254,16 @@ class Fields(object):
         nJ, nf = 3 * Nm, 4 * Nm
         fft_exec(self.d_interp[:, 6 * Nm, :], self.d_scratch[:, 0, :], -1, ncols=nf * Nr)
         scr_f = self._field_views(self.d_scratch, 0, nf)
-        r, t = pa(scr_f[0:nJ:3]), pa(scr_f[1:nJ:3])
-        _capi.check(lib.fb_rt_to_pm(Nm, r, t, r, t, self.d_scratch.stride(0), Nz, Nr, st),
-                    'fb_rt_to_pm')
         out = self._field_views(self.d_spect, 6 * Nm, nJ) + self._field_views(self.d_spect, 10 * Nm, Nm)
         mats = self._mats['vec_fwd'] + self._mats['scal_fwd']
         mode_of = [(j // 3) % Nm for j in range(nJ)] + list(range(Nm))
         sk = [self.interp[m].d_invvol for m in mode_of]
         fz = [self.spect[m].d_filter_array_z if fuse_filter else None for m in mode_of]
         fr = [self.spect[m].d_filter_array_r if fuse_filter else None for m in mode_of]
-        _capi.check(lib.fb_hankel_scaled(nf, pa(scr_f), self.d_scratch.stride(0), pa(out),
-                                         self.d_spect.stride(0), pa(mats), pa(sk), pa(fz), pa(fr),
-                                         1.0, Nz, Nr, st), 'fb_hankel_scaled')
+        ins, in2, sgn = self._rt_pairs(scr_f, nJ)
+        _capi.check(lib.fb_hankel_rt_to_pm_scaled(
+            nf, pa(ins), pa(in2), sgn, self.d_scratch.stride(0), pa(out), self.d_spect.stride(0),
+            pa(mats), pa(sk), pa(fz), pa(fr), 1.0, Nz, Nr, st), 'fb_hankel_rt_to_pm_scaled')
 
     def spect2interp(self, fieldtype):
         """inverse DHT(r) then inverse FFT(z) (reference: fields.py:370-429)."""
@@ -265,6 +278,13 @@ class Fields(object):
             mats = mats + mats
         _capi.check(lib.fb_hankel(nf, pa(inp), self.d_spect.stride(0), pa(scr_f), self.d_scratch.stride(0),
                                   pa(mats), 1.0, Nz, Nr, st), 'fb_hankel')
+        if vec and lib.fb_zfft_supported(Nz):
+            # (p, m) -> (r, t) rides along in the first pass of the backward z-FFT
+            _capi.check(lib.fb_zfft_pm_to_rt(Nz, nf * Nr, self.d_scratch[:, 0, :].data_ptr(),
+                                             self.d_scratch.stride(0),
+                                             self.d_interp[:, fi, :].data_ptr(),
+                                             self.d_interp.stride(0), Nr, st), 'fb_zfft_pm_to_rt')
+            return
         if vec:
             p = pa(scr_f[0::3])
             mm = pa(scr_f[1::3])
@@ -334,9 +354,12 @@ class Fields(object):
     def erase(self, fieldtype):
         """Zero a field group on the interpolation grid, all modes in one launch."""
         self._need_gpu()
-        if fieldtype not in ('E', 'B', 'J', 'rho'):
+        if fieldtype not in ('E', 'B', 'J', 'rho', 'J+rho'):
             raise ValueError('Invalid string for fieldtype: %s' % fieldtype)
-        fi, _, nf, _ = self._group('rho_prev' if fieldtype == 'rho' else fieldtype)
+        if fieldtype == 'J+rho':      # adjacent in the slab: both source groups in one launch
+            fi, nf = 6 * self.Nm, 4 * self.Nm
+        else:
+            fi, _, nf, _ = self._group('rho_prev' if fieldtype == 'rho' else fieldtype)
         views = self._field_views(self.d_interp, fi, nf)
         _capi.check(_capi.lib().fb_erase(nf, _capi.ptr_array(views), self.d_interp.stride(0),
                                          self.Nz, self.Nr, _capi.stream()), 'fb_erase')

@@ -109,6 +109,7 @@ class Simulation(object):
         self.diags = []
         self.checkpoints = []
         self._J_transform_pending = False
+        self._rho_already_erased = False
         self.laser_antennas = []
         self.mirrors = []
         # On a single z-periodic domain the reference re-deposits rho_prev at every step
@@ -288,7 +289,16 @@ class Simulation(object):
             kind = 'J'
         else:
             raise ValueError('Unknown fieldtype: %s' % fieldtype)
-        fld.erase(kind)
+        fused = self._in_step and update_spectral and not (exchange and self.comm.size > 1)
+        if fused and defer_transform and fieldtype == 'J':
+            # deposit('rho_next') follows: zero both source groups in one launch
+            fld.erase('J+rho')
+            self._rho_already_erased = True
+        elif kind == 'rho' and self._rho_already_erased and fieldtype == 'rho_next':
+            self._rho_already_erased = False
+        else:
+            self._rho_already_erased = False
+            fld.erase(kind)
         for species in species_list:
             species.deposit(fld, kind)
         fld.sum_reduce_deposition_array(kind)

@@ -287,6 +287,14 @@ int fb_zfft_supported(int Nz);
 int fb_zfft(int Nz, long ncols, const void *in, long in_stride, void *out, long out_stride,
             int direction, void *stream);
 
+/* Backward fb_zfft with the (p, m) -> (r, t) combination of spectral_transformer.py:140-142
+ * (numba_pm_to_rt) folded into its first pass: the ncols columns are groups of (p, m, z)
+ * fields of Nr columns each; an r column reads p + m, a t column i (p - m), a z column
+ * itself.  Same arithmetic as fb_pm_to_rt followed by fb_zfft(..., +1), one sweep less.
+ * Out of place only. */
+int fb_zfft_pm_to_rt(int Nz, long ncols, const void *in, long in_stride, void *out,
+                     long out_stride, int Nr, void *stream);
+
 /* Self-contained fallback for every other length whose prime factors are <= 31 (rocFFT of
  * ROCm 7.2 refuses some, e.g. Nz = 4416): one Stockham pass per launch through global
  * memory, ping-pong between `out` and a caller-provided scratch slab of the same shape
@@ -317,6 +325,19 @@ int fb_hankel_scaled(int njobs, const void *const *in, long in_row_stride,
                      const double *const *in_col_scale, const double *const *out_row_scale,
                      const double *const *out_col_scale, double alpha, int Nz, int Nr,
                      void *stream);
+
+/* fb_hankel_scaled with the (r, t) -> (p | m) combination of spectral_transformer.py:208-210
+ * (numba_rt_to_pm) fused into the operand load: the input of job j is
+ * 0.5 * (in[j] + pair_sign[j] * i * in2[j]) when in2[j] is not NULL (p: in = r, in2 = t,
+ * sign -1; m: in = r, in2 = t, sign +1), in[j] itself otherwise (z components, scalars).
+ * Same arithmetic as fb_rt_to_pm followed by fb_hankel_scaled, one sweep less. */
+int fb_hankel_rt_to_pm_scaled(int njobs, const void *const *in, const void *const *in2,
+                              const double *pair_sign, long in_row_stride,
+                              void *const *out, long out_row_stride,
+                              const double *const *mat, const double *const *in_col_scale,
+                              const double *const *out_row_scale,
+                              const double *const *out_col_scale, double alpha, int Nz, int Nr,
+                              void *stream);
 
 #ifdef __cplusplus
 }

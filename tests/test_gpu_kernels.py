@@ -437,6 +437,58 @@ def test_hankel_scaled_fusions(hip):
         assert np.abs(host(dst[:, j, :]) - ref).max() < 1e-14 * scale, j
 
 
+def test_rt_pm_fused_into_hankel_and_fft(hip):
+    """fb_hankel_rt_to_pm_scaled == fb_rt_to_pm then fb_hankel_scaled (bit-identical: same
+    operand values, same MFMA order); fb_zfft_pm_to_rt == fb_pm_to_rt then fb_zfft backward."""
+    import ctypes
+    rng = np.random.default_rng(9)
+    Nz, Nr = 128, 48
+    t = hip.torch()
+    pa = hip.ptr_array
+    nf = 7                                   # two vector triples + one scalar
+    a = rng.normal(size=(Nz, nf, Nr)) + 1j * rng.normal(size=(Nz, nf, Nr))
+    mats = [dev(hip, rng.normal(size=(Nr, Nr))) for _ in range(nf)]
+    sk = [dev(hip, rng.uniform(0.5, 2., Nr)) for _ in range(nf)]
+    fz = [dev(hip, rng.uniform(0., 1., Nz)) for _ in range(nf)]
+    fr = [dev(hip, rng.uniform(0., 1., Nr)) for _ in range(nf)]
+    # reference sequence
+    s1 = dev(hip, a)
+    f1 = [s1[:, j, :] for j in range(nf)]
+    r_, t_ = pa(f1[0:6:3]), pa(f1[1:6:3])
+    hip.check(hip.lib().fb_rt_to_pm(2, r_, t_, r_, t_, nf * Nr, Nz, Nr, hip.stream()), 'rt_to_pm')
+    d1 = t.zeros((Nz, nf, Nr), dtype=t.complex128, device='cuda')
+    hip.check(hip.lib().fb_hankel_scaled(nf, pa(f1), nf * Nr, pa([d1[:, j, :] for j in range(nf)]),
+                                         nf * Nr, pa(mats), pa(sk), pa(fz), pa(fr), 1.0, Nz, Nr,
+                                         hip.stream()), 'hks')
+    # fused
+    s2 = dev(hip, a)
+    f2 = [s2[:, j, :] for j in range(nf)]
+    ins = [f2[0], f2[0], f2[2], f2[3], f2[3], f2[5], f2[6]]
+    in2 = [f2[1], f2[1], None, f2[4], f2[4], None, None]
+    sgn = (ctypes.c_double * nf)(-1., 1., 0., -1., 1., 0., 0.)
+    d2 = t.zeros((Nz, nf, Nr), dtype=t.complex128, device='cuda')
+    hip.check(hip.lib().fb_hankel_rt_to_pm_scaled(
+        nf, pa(ins), pa(in2), sgn, nf * Nr, pa([d2[:, j, :] for j in range(nf)]), nf * Nr, pa(mats),
+        pa(sk), pa(fz), pa(fr), 1.0, Nz, Nr, hip.stream()), 'hk rt')
+    assert np.array_equal(host(d1), host(d2))
+    assert np.array_equal(host(s2), a)                      # inputs untouched
+    # backward FFT with (p, m) -> (r, t) on load
+    b = rng.normal(size=(Nz, 6, Nr)) + 1j * rng.normal(size=(Nz, 6, Nr))
+    s3 = dev(hip, b)
+    f3 = [s3[:, j, :] for j in range(6)]
+    p_, m_ = pa(f3[0::3]), pa(f3[1::3])
+    hip.check(hip.lib().fb_pm_to_rt(2, p_, m_, p_, m_, 6 * Nr, Nz, Nr, hip.stream()), 'pm_to_rt')
+    o3 = t.zeros((Nz, 7, Nr), dtype=t.complex128, device='cuda')
+    hip.check(hip.lib().fb_zfft(Nz, 6 * Nr, s3.data_ptr(), 6 * Nr, o3[:, 1, :].data_ptr(), 7 * Nr, +1,
+                                hip.stream()), 'zfft')
+    s4 = dev(hip, b)
+    o4 = t.zeros((Nz, 7, Nr), dtype=t.complex128, device='cuda')
+    hip.check(hip.lib().fb_zfft_pm_to_rt(Nz, 6 * Nr, s4.data_ptr(), 6 * Nr, o4[:, 1, :].data_ptr(),
+                                         7 * Nr, Nr, hip.stream()), 'zfft pm')
+    assert np.array_equal(host(o3), host(o4))
+    assert np.array_equal(host(s4), b)
+
+
 def test_psatd_step_fused_equals_separate(hip, oracle):
     """fb_psatd_step_standard == correct_currents -> push_eb -> push_rho (oracle, per mode)."""
     g = golden('spectral')
