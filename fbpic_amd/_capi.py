@@ -33,11 +33,11 @@ _SIGNATURES = {
     'fb_bin_sort_particles': (I, [L, I, P, P, P, D, D, I, D, D, I, I, _PP, _PP, P, P, P, P, Z, P]),
     'fb_push_x_bin_sort_particles': (I, [L, I, P, P, P, P, P, P, P, D, D, D, D, D, D, D, I, D, D, I, I, _PP,
                                          _PP, P, P, P, P, Z, I, P]),
-    'fb_deposit_J_rank_next': (I, [I, I, L, P, P, P, P, D, P, P, P, P, D, D, D, I, D, D, I, _PP, L, P, P, P,
+    'fb_deposit_J_rank_next': (I, [I, I, L, P, P, P, P, D, P, P, P, P, D, D, D, I, D, D, I, _PP, L, L, P, P, P,
                                    D, D, D, D, I, P, Z, P]),
     'fb_permute': (I, [L, P, I, _PP, _PP, P]),
-    'fb_deposit_rho': (I, [I, I, L, P, P, P, P, D, D, D, I, D, D, I, _PP, L, P, P, P, P, P]),
-    'fb_deposit_J': (I, [I, I, L, P, P, P, P, D, P, P, P, P, D, D, D, I, D, D, I, _PP, L,
+    'fb_deposit_rho': (I, [I, I, L, P, P, P, P, D, D, D, I, D, D, I, _PP, L, L, P, P, P, P, P]),
+    'fb_deposit_J': (I, [I, I, L, P, P, P, P, D, P, P, P, P, D, D, D, I, D, D, I, _PP, L, L,
                          P, P, P, P, P]),
     'fb_erase': (I, [I, _PP, L, I, I, P]),
     'fb_divide_by_volume': (I, [I, _PP, L, P, I, I, P]),
@@ -58,6 +58,7 @@ _SIGNATURES = {
     'fb_zfft_supported': (I, [I]),
     'fb_zfft': (I, [I, L, P, L, P, L, I, P]),
     'fb_zfft_pm_to_rt': (I, [I, L, P, L, P, L, I, P]),
+    'fb_zfft_from_records': (I, [I, I, I, P, L, I, P, L, P]),
     'fb_fft_generic_supported': (I, [I]),
     'fb_fft_generic': (I, [I, L, P, L, P, L, P, L, I, P]),
     'fb_hankel': (I, [I, _PP, L, _PP, L, _PP, D, I, I, P]),

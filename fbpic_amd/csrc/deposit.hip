@@ -31,7 +31,13 @@
 
 namespace fb {
 
-struct DepGrids { cplx *g[3 * FB_MAX_MODES]; };   // [comp + NCOMP*m]
+// g[comp + NCOMP*m]: base of each target array; element (iz, ir) at g + iz*rs + ir*cs.
+// cs = 1 for the (Nz, Nr) grids of the reference; cs = record length for a node-major
+// ("array of structures") target in which all components and modes of one node share a
+// cache line -- global atomics cost one L2 operation per LINE touched by an instruction
+// (tools/atomic_probe.hip: 48 lanes on 48 lines 2.0 ns, on 3 lines 0.27 ns), so flushing a
+// cell into 2-4 lines instead of 24-48 is what makes the J deposition's atomics cheap.
+struct DepGrids { cplx *g[3 * FB_MAX_MODES]; long cs; };
 
 template <int SHAPE> struct ShapeTraits;
 template <> struct ShapeTraits<FB_SHAPE_LINEAR> { static constexpr int S = 2, H = 1; };
@@ -227,6 +233,9 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
     auto flush = [&](bool keep_upper) {
         if (cur_z == DEP_NOKEY) return;
         my_flushes++;
+        const bool interior = cur_z >= 0 && cur_z + S <= Nz && cur_r >= 0 && cur_r + S <= Nr;
+        const long cs = G.cs;
+        const long cell_base = (long)cur_z * rs + (long)cur_r * cs;
 #pragma unroll
         for (int qq = 0; qq < NQ; qq++) {
             // add the 4 blocks of each tile, then keep the tile this lane writes in this round
@@ -243,10 +252,16 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
             }
             const int jr = SLIDE ? (f_jr[qq] ^ par) : f_jr[qq];
             if (!f_ok[qq] || v == 0. || (keep_upper && jr != 0)) continue;
-            int gz = cur_z + f_jz[qq], gr = cur_r + jr;
-            fold_node(gz, gr, Nz, Nr);
-            if (jr < cur_nb) v *= f_sgn[qq];            // node below the axis: signed fold
-            atomicAdd(f_ptr[qq] + 2 * ((long)gz * rs + gr), v);
+            if (interior) {
+                // all S x S nodes inside the grid (wave-uniform test): no guard folding, no
+                // axis sign; the cell's base offset is scalar arithmetic
+                atomicAdd(f_ptr[qq] + 2 * (cell_base + (long)f_jz[qq] * rs + (long)jr * cs), v);
+            } else {
+                int gz = cur_z + f_jz[qq], gr = cur_r + jr;
+                fold_node(gz, gr, Nz, Nr);
+                if (jr < cur_nb) v *= f_sgn[qq];            // node below the axis: signed fold
+                atomicAdd(f_ptr[qq] + 2 * ((long)gz * rs + (long)gr * cs), v);
+            }
         }
     };
 
@@ -277,8 +292,14 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
             const double wj = q * pc[3];
             const double rj = sqrt(xj * xj + yj * yj);
             double cs, sn;
-            if (rj != 0.) { double invr = 1. / rj; cs = xj * invr; sn = yj * invr; }
-            else { cs = 1.; sn = 0.; }
+            if (rj != 0.) {
+                // 1/r by hardware reciprocal + two Newton steps (< 1 ulp): the deposition is
+                // compared at 1e-13, only the cell index below needs the exactly rounded r
+                double r0 = __builtin_amdgcn_rcp(rj);
+                r0 = __builtin_fma(r0, __builtin_fma(-rj, r0, 1.), r0);
+                const double invr = __builtin_fma(r0, __builtin_fma(-rj, r0, 1.), r0);
+                cs = xj * invr; sn = yj * invr;
+            } else { cs = 1.; sn = 0.; }
             double are[NCOMP], aim[NCOMP];
             if constexpr (NCOMP == 1) {
                 are[0] = wj; aim[0] = 0.;
@@ -517,7 +538,7 @@ using namespace fb;
 
 extern "C" int fb_deposit_rho(int shape, int Nm, long n, const double *x, const double *y,
         const double *z, const double *w, double q, double invdz, double zmin, int Nz,
-        double invdr, double rmin, int Nr, void *const *rho, long row_stride,
+        double invdr, double rmin, int Nr, void *const *rho, long row_stride, long col_stride,
         const int *prefix_sum, const double *ruyten_m0, const double *ruyten_mh,
         unsigned long long *nflush, void *stream)
 {
@@ -525,6 +546,7 @@ extern "C" int fb_deposit_rho(int shape, int Nm, long n, const double *x, const 
     if (n <= 0) return 0;
     if (Nm < 1 || Nm > FB_MAX_MODES) { set_error("fb_deposit_rho", "Nm out of range"); return -1; }
     DepGrids G;
+    G.cs = col_stride > 0 ? col_stride : 1;
     for (int i = 0; i < 3 * FB_MAX_MODES; i++) G.g[i] = i < Nm ? (cplx *)rho[i] : nullptr;
     hipStream_t s = (hipStream_t)stream;
     if (shape == FB_SHAPE_LINEAR)
@@ -543,11 +565,12 @@ static int deposit_J_impl(const char *who, int shape, int Nm, long n, const doub
         const double *y, const double *z, const double *w, double q, const double *ux,
         const double *uy, const double *uz, const double *inv_gamma, double c, double invdz,
         double zmin, int Nz, double invdr, double rmin, int Nr, void *const *J, long row_stride,
-        const double *ruyten_m0, const double *ruyten_mh, unsigned long long *nflush,
-        const RankNext *RK, hipStream_t s)
+        long col_stride, const double *ruyten_m0, const double *ruyten_mh,
+        unsigned long long *nflush, const RankNext *RK, hipStream_t s)
 {
     if (Nm < 1 || Nm > FB_MAX_MODES) { set_error(who, "Nm out of range"); return -1; }
     DepGrids G;
+    G.cs = col_stride > 0 ? col_stride : 1;
     for (int i = 0; i < 3 * FB_MAX_MODES; i++) G.g[i] = i < 3 * Nm ? (cplx *)J[i] : nullptr;
     if (shape == FB_SHAPE_LINEAR)
         return launch_modes<FB_SHAPE_LINEAR, 3>(Nm, n, x, y, z, w, q, ux, uy, uz, inv_gamma, c,
@@ -562,21 +585,21 @@ static int deposit_J_impl(const char *who, int shape, int Nm, long n, const doub
 extern "C" int fb_deposit_J(int shape, int Nm, long n, const double *x, const double *y,
         const double *z, const double *w, double q, const double *ux, const double *uy,
         const double *uz, const double *inv_gamma, double c, double invdz, double zmin, int Nz,
-        double invdr, double rmin, int Nr, void *const *J, long row_stride,
+        double invdr, double rmin, int Nr, void *const *J, long row_stride, long col_stride,
         const int *prefix_sum, const double *ruyten_m0, const double *ruyten_mh,
         unsigned long long *nflush, void *stream)
 {
     (void)prefix_sum;
     if (n <= 0) return 0;
     return deposit_J_impl("fb_deposit_J", shape, Nm, n, x, y, z, w, q, ux, uy, uz, inv_gamma, c,
-                          invdz, zmin, Nz, invdr, rmin, Nr, J, row_stride, ruyten_m0, ruyten_mh,
+                          invdz, zmin, Nz, invdr, rmin, Nr, J, row_stride, col_stride, ruyten_m0, ruyten_mh,
                           nflush, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int fb_deposit_J_rank_next(int shape, int Nm, long n, const double *x, const double *y,
         const double *z, const double *w, double q, const double *ux, const double *uy,
         const double *uz, const double *inv_gamma, double c, double invdz, double zmin, int Nz,
-        double invdr, double rmin, int Nr, void *const *J, long row_stride,
+        double invdr, double rmin, int Nr, void *const *J, long row_stride, long col_stride,
         const double *ruyten_m0, const double *ruyten_mh, unsigned long long *nflush,
         double dt_push, double x_push, double y_push, double z_push, int ncell,
         void *sort_workspace, size_t workspace_bytes, void *stream)
@@ -594,6 +617,6 @@ extern "C" int fb_deposit_J_rank_next(int shape, int Nm, long n, const double *x
     // fbpic/particles/push/numba_methods.py:24-30: chdt = c * dt
     const RankNext RK = {c * dt_push, x_push, y_push, z_push, W.cell, W.rank, W.count};
     return deposit_J_impl("fb_deposit_J_rank_next", shape, Nm, n, x, y, z, w, q, ux, uy, uz,
-                          inv_gamma, c, invdz, zmin, Nz, invdr, rmin, Nr, J, row_stride,
+                          inv_gamma, c, invdz, zmin, Nz, invdr, rmin, Nr, J, row_stride, col_stride,
                           ruyten_m0, ruyten_mh, nflush, &RK, s);
 }

@@ -219,7 +219,8 @@ __device__ __forceinline__ void zf_pass(cx *lds, const cx *__restrict__ tw,
 
 template <class Z, bool FWD>
 __global__ __launch_bounds__(Z::NTHR) void k_zfft(long ncols, const cx *in, long in_stride,
-        cx *out, long out_stride, const cx *__restrict__ tw, double scale, int ntiles, int pm_Nr)
+        cx *out, long out_stride, const cx *__restrict__ tw, double scale, int ntiles, int pm_Nr,
+        int aos_Nr, int aos_rec)
 {
     constexpr int C = Z::C;
     extern __shared__ double2 zf_lds[];
@@ -230,9 +231,18 @@ __global__ __launch_bounds__(Z::NTHR) void k_zfft(long ncols, const cx *in, long
     if ((nb & 7) == 0) tile = (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3);
     if (tile >= ntiles) return;
     const int c = threadIdx.x % C, jj0 = threadIdx.x / C;
-    const long col = (long)tile * C + c;
+    long col = (long)tile * C + c;
+    if (aos_Nr > 0 && aos_Nr % C == 0) {
+        // records input: order the tiles node-block major, field minor, so that the tiles that
+        // read the same record lines (one 16-B field each) are neighbours on one XCD and the
+        // line comes from HBM once, not once per field and XCD
+        const int nfld = (int)(ncols / aos_Nr);
+        col = (long)(tile % nfld) * aos_Nr + (long)(tile / nfld) * C + c;
+    }
     const bool col_ok = col < ncols;
-    const cx *gin = in + col;
+    // aos_Nr > 0: the input is node-major, in[iz * in_stride + ir * aos_rec + field] (the
+    // deposition's record-per-node target); column (field, ir) of the transform gathers it
+    const cx *gin = aos_Nr > 0 ? in + (col % aos_Nr) * aos_rec + (col / aos_Nr) : in + col;
     cx *gout = out + col;
     // pm_Nr > 0: the columns are groups of (p, m, z) fields of pm_Nr columns each
     int pm = 0;
@@ -280,7 +290,7 @@ static int get_twiddles(int N, const cx **out)
 
 template <class Z>
 static int zfft_launch(long ncols, const cx *in, long is, cx *out, long os, int direction,
-                       const cx *tw, hipStream_t s, int pm_Nr = 0)
+                       const cx *tw, hipStream_t s, int pm_Nr = 0, int aos_Nr = 0, int aos_rec = 0)
 {
     constexpr int N = Z::N, C = Z::C;
     const int ntiles = (int)((ncols + C - 1) / C);
@@ -298,10 +308,10 @@ static int zfft_launch(long ncols, const cx *in, long is, cx *out, long os, int 
     const int nblocks = (ntiles + 7) & ~7;             // multiple of 8 for the XCD mapping
     if (direction < 0)
         hipLaunchKernelGGL((k_zfft<Z, true>), dim3(nblocks), dim3(Z::NTHR), lds_bytes, s, ncols, in,
-                           is, out, os, tw, 1.0, ntiles, pm_Nr);
+                           is, out, os, tw, 1.0, ntiles, pm_Nr, aos_Nr, aos_rec);
     else
         hipLaunchKernelGGL((k_zfft<Z, false>), dim3(nblocks), dim3(Z::NTHR), lds_bytes, s, ncols, in,
-                           is, out, os, tw, 1.0 / (double)N, ntiles, pm_Nr);
+                           is, out, os, tw, 1.0 / (double)N, ntiles, pm_Nr, aos_Nr, aos_rec);
     return check(hipGetLastError(), "fb_zfft");
 }
 
@@ -536,7 +546,20 @@ extern "C" int fb_zfft_supported(int Nz)
 }
 
 static int zfft_dispatch(const char *who, int Nz, long ncols, const void *in, long in_stride, void *out,
-                         long out_stride, int direction, int pm_Nr, void *stream);
+                         long out_stride, int direction, int pm_Nr, void *stream, int aos_Nr = 0,
+                         int aos_rec = 0);
+
+extern "C" int fb_zfft_from_records(int Nz, int nfields, int Nr, const void *in, long in_stride,
+                                    int record, void *out, long out_stride, void *stream)
+{
+    if (nfields <= 0 || nfields > record || Nr <= 0) {
+        set_error("fb_zfft_from_records", "need 0 < nfields <= record and Nr > 0");
+        return -1;
+    }
+    if (in == out) { set_error("fb_zfft_from_records", "out of place only"); return -1; }
+    return zfft_dispatch("fb_zfft_from_records", Nz, (long)nfields * Nr, in, in_stride, out, out_stride,
+                         -1, 0, stream, Nr, record);
+}
 
 extern "C" int fb_zfft_pm_to_rt(int Nz, long ncols, const void *in, long in_stride, void *out,
                                 long out_stride, int Nr, void *stream)
@@ -556,7 +579,7 @@ extern "C" int fb_zfft(int Nz, long ncols, const void *in, long in_stride, void 
 }
 
 static int zfft_dispatch(const char *who, int Nz, long ncols, const void *in, long in_stride, void *out,
-                         long out_stride, int direction, int pm_Nr, void *stream)
+                         long out_stride, int direction, int pm_Nr, void *stream, int aos_Nr, int aos_rec)
 {
     if (!fb_zfft_supported(Nz)) {
         set_error(who, "unsupported Nz (2^k in [64, 4096] or 9 * 2^k in [576, 2304])");
@@ -570,7 +593,7 @@ static int zfft_dispatch(const char *who, int Nz, long ncols, const void *in, lo
     hipStream_t s = (hipStream_t)stream;
     const cx *a = (const cx *)in;
     cx *b = (cx *)out;
-#define ZF_CASE(n, Z) case n: return zfft_launch<Z>(ncols, a, in_stride, b, out_stride, direction, tw, s, pm_Nr)
+#define ZF_CASE(n, Z) case n: return zfft_launch<Z>(ncols, a, in_stride, b, out_stride, direction, tw, s, pm_Nr, aos_Nr, aos_rec)
     switch (Nz) {
     ZF_CASE(64, ZC64); ZF_CASE(128, ZC128); ZF_CASE(256, ZC256); ZF_CASE(512, ZC512);
     ZF_CASE(1024, ZC1024); ZF_CASE(2048, ZC2048); ZF_CASE(4096, ZC4096);

@@ -80,6 +80,7 @@ class Fields(object):
         self.d_interp = None
         self.d_spect = None
         self.d_scratch = None
+        self.d_src_rec = None
 
     # ---------------------------------------------------------------- slab indexing
     def interp_index(self, name, m):
@@ -243,7 +244,42 @@ class Fields(object):
             _capi.check(lib.fb_hankel(nf, pa(scr_f), self.d_scratch.stride(0), pa(out), self.d_spect.stride(0),
                                       pa(mats), 1.0, Nz, Nr, st), 'fb_hankel')
 
-    def interp2spect_J_and_rho_next(self, fuse_filter=False):
+    # ---------------------------------------------------------------- node-major source records
+    def source_records(self):
+        """complex128[Nz, Nr, 4*Nm] staging array of the in-step deposition: record of node
+        (iz, ir) = (J of mode 0: r, t, z | mode 1: r, t, z | ... | rho of mode 0, 1, ...), i.e.
+        the field order of the J | rho part of the interpolation slab.  With Nm = 2 a record
+        is exactly one 128-B cache line, so the atomics that flush a cell touch 2-4 lines
+        instead of 24-48 (see DepGrids in csrc/deposit.hip)."""
+        if getattr(self, 'd_src_rec', None) is None:
+            t = _capi.torch()
+            rec = 4 * self.Nm
+            rs = self.Nr * rec + SLAB_PAD
+            base = t.zeros(self.Nz * rs, dtype=t.complex128, device=_capi.require_device())
+            self.d_src_rec = base.as_strided((self.Nz, self.Nr, rec), (rs, rec, 1))
+        return self.d_src_rec
+
+    def erase_source_records(self):
+        S = self.source_records()
+        row = _capi.torch().as_strided(S, (self.Nz, self.Nr * S.shape[2]), (S.stride(0), 1))
+        _capi.check(_capi.lib().fb_erase(1, _capi.ptr_array([row]), S.stride(0), self.Nz,
+                                         self.Nr * S.shape[2], _capi.stream()), 'fb_erase')
+
+    def record_views(self, kind):
+        """Per-field (Nz, Nr) views of the record array, in the order the deposition wants:
+        J -> [m0: Jr, Jt, Jz, m1: ...], rho -> [m0, m1, ...]."""
+        S, Nm = self.source_records(), self.Nm
+        if kind == 'J':
+            return [S[:, :, f] for f in range(3 * Nm)]
+        return [S[:, :, 3 * Nm + m] for m in range(Nm)]
+
+    def unpack_source_records(self):
+        """Copy the records into the J | rho fields of the interpolation slab (only needed
+        when something other than interp2spect_J_and_rho_next wants them)."""
+        S, Nm = self.source_records(), self.Nm
+        self.d_interp[:, 6 * Nm:10 * Nm, :].copy_(S.permute(0, 2, 1))
+
+    def interp2spect_J_and_rho_next(self, fuse_filter=False, from_records=False):
         """interp2spect('J') and interp2spect('rho_next') of freshly deposited (un-normalised)
         sources in ONE z-FFT launch and ONE Hankel launch: J and rho are adjacent in the
         interpolation slab, and a Hankel launch takes any list of jobs.  Same arithmetic per
@@ -252,7 +288,16 @@ class Fields(object):
         Nm, Nz, Nr = self.Nm, self.Nz, self.Nr
         lib, pa, st = _capi.lib(), _capi.ptr_array, _capi.stream()
         nJ, nf = 3 * Nm, 4 * Nm
-        fft_exec(self.d_interp[:, 6 * Nm, :], self.d_scratch[:, 0, :], -1, ncols=nf * Nr)
+        if from_records and lib.fb_zfft_supported(Nz):
+            # the z-FFT gathers its columns straight from the deposition's records
+            S = self.source_records()
+            _capi.check(lib.fb_zfft_from_records(Nz, nf, Nr, S.data_ptr(), S.stride(0), S.shape[2],
+                                                 self.d_scratch[:, 0, :].data_ptr(),
+                                                 self.d_scratch.stride(0), st), 'fb_zfft_from_records')
+        else:
+            if from_records:
+                self.unpack_source_records()
+            fft_exec(self.d_interp[:, 6 * Nm, :], self.d_scratch[:, 0, :], -1, ncols=nf * Nr)
         scr_f = self._field_views(self.d_scratch, 0, nf)
         out = self._field_views(self.d_spect, 6 * Nm, nJ) + self._field_views(self.d_spect, 10 * Nm, Nm)
         mats = self._mats['vec_fwd'] + self._mats['scal_fwd']

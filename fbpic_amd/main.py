@@ -263,6 +263,9 @@ class Simulation(object):
         """Transform a J whose interp2spect was deferred (see deposit)."""
         if self._J_transform_pending:
             self._J_transform_pending = False
+            self._rho_already_erased = False
+            if self.particle_shape == 'linear':
+                self.fld.unpack_source_records()  # J was deposited into the record array
             self.fld.interp2spect('J', fuse_divide_by_volume=True, fuse_filter=self.filter_currents)
 
     def shift_galilean_boundaries(self, dt):
@@ -290,17 +293,29 @@ class Simulation(object):
         else:
             raise ValueError('Unknown fieldtype: %s' % fieldtype)
         fused = self._in_step and update_spectral and not (exchange and self.comm.size > 1)
+        records = False
+        # node-major record target (one cache line per node): measured on MI355X, linear shape
+        # deposit J 108 -> 88 us, rho 62 -> 57 us, against +10 us for the z-FFT that then
+        # gathers 16-B pieces; with the cubic shape (16 nodes per cell either way) it loses
+        use_records = self.particle_shape == 'linear'
         if fused and defer_transform and fieldtype == 'J':
-            # deposit('rho_next') follows: zero both source groups in one launch
-            fld.erase('J+rho')
+            # deposit('rho_next') follows: both source groups are zeroed in one launch and
+            # transformed together
             self._rho_already_erased = True
-        elif kind == 'rho' and self._rho_already_erased and fieldtype == 'rho_next':
+            if use_records:
+                fld.erase_source_records()
+                records = True
+            else:
+                fld.erase('J+rho')
+        elif fused and kind == 'rho' and self._rho_already_erased and fieldtype == 'rho_next':
             self._rho_already_erased = False
+            records = use_records
         else:
+            self._flush_J_transform()
             self._rho_already_erased = False
             fld.erase(kind)
         for species in species_list:
-            species.deposit(fld, kind)
+            species.deposit(fld, kind, records=records)
         fld.sum_reduce_deposition_array(kind)
         if self._in_step and update_spectral and not (exchange and self.comm.size > 1):
             # inside step(): divide-by-volume and filter ride along in the Hankel GEMM
@@ -312,7 +327,8 @@ class Simulation(object):
                 return
             if fieldtype == 'rho_next' and self._J_transform_pending:
                 self._J_transform_pending = False
-                fld.interp2spect_J_and_rho_next(fuse_filter=self.filter_currents)
+                fld.interp2spect_J_and_rho_next(fuse_filter=self.filter_currents,
+                                                from_records=records)
             else:
                 self._flush_J_transform()
                 fld.interp2spect(fieldtype, fuse_divide_by_volume=True,

@@ -393,8 +393,10 @@ class Particles(object):
         self._deposits_since_sort += 1
 
     # ---------------------------------------------------------------- deposit
-    def deposit(self, fld, fieldtype):
-        """Deposit rho or J of this species on the interpolation grid (reference :839-1046)."""
+    def deposit(self, fld, fieldtype, records=False):
+        """Deposit rho or J of this species on the interpolation grid (reference :839-1046).
+        `records` (Simulation.step): deposit into the node-major record array of the Fields
+        object instead (Fields.source_records), which the z-FFT reads directly."""
         if self.q == 0:
             return
         assert fieldtype in ['rho', 'J']
@@ -416,17 +418,20 @@ class Particles(object):
         p = _capi.ptr
         adaptive = self.resort_fragmentation > 0
         if fieldtype == 'rho':
-            views = [grid[m].rho for m in range(Nm)]
+            views = fld.record_views('rho') if records else [grid[m].rho for m in range(Nm)]
             rc = lib.fb_deposit_rho(_SHAPE[self.particle_shape], Nm, self.Ntot, p(self.x),
                                     p(self.y), p(self.z), p(weight), self.q, g0.invdz, g0.zmin,
                                     g0.Nz, g0.invdr, g0.rmin, g0.Nr, _capi.ptr_array(views),
-                                    _capi.row_stride(views[0]), p(self.prefix_sum), p(ruy0),
+                                    views[0].stride(0), views[0].stride(1),
+                                    p(self.prefix_sum), p(ruy0),
                                     p(ruyh), None, _capi.stream())
             _capi.check(rc, 'fb_deposit_rho')
         else:
             views = []
             for m in range(Nm):
                 views += [grid[m].Jr, grid[m].Jt, grid[m].Jz]
+            if records:
+                views = fld.record_views('J')
             hint, self.push_after_deposit_J = self.push_after_deposit_J, None
             if hint is not None and self.use_bin_sort and self.Ntot > 0:
                 # the deposition also ranks the particles for the sort that follows `hint`
@@ -434,7 +439,7 @@ class Particles(object):
                     _SHAPE[self.particle_shape], Nm, self.Ntot, p(self.x), p(self.y), p(self.z),
                     p(weight), self.q, p(self.ux), p(self.uy), p(self.uz), p(self.inv_gamma), c,
                     g0.invdz, g0.zmin, g0.Nz, g0.invdr, g0.rmin, g0.Nr, _capi.ptr_array(views),
-                    _capi.row_stride(views[0]), p(ruy0), p(ruyh),
+                    views[0].stride(0), views[0].stride(1), p(ruy0), p(ruyh),
                     p(self._nflush) if adaptive else None, hint[0], hint[1], hint[2], hint[3],
                     self.prefix_sum.shape[0], p(self._sort_ws), self._sort_ws.shape[0],
                     _capi.stream())
@@ -445,8 +450,8 @@ class Particles(object):
                                       p(self.y), p(self.z), p(weight), self.q, p(self.ux),
                                       p(self.uy), p(self.uz), p(self.inv_gamma), c, g0.invdz,
                                       g0.zmin, g0.Nz, g0.invdr, g0.rmin, g0.Nr,
-                                      _capi.ptr_array(views), _capi.row_stride(views[0]),
-                                      p(self.prefix_sum), p(ruy0), p(ruyh),
+                                      _capi.ptr_array(views), views[0].stride(0),
+                                      views[0].stride(1), p(self.prefix_sum), p(ruy0), p(ruyh),
                                       p(self._nflush) if adaptive else None, _capi.stream())
                 _capi.check(rc, 'fb_deposit_J')
             if adaptive:

@@ -151,7 +151,12 @@ int fb_permute(long n, const int *sorted_idx, int nattr,
  * cell-sorted for speed (runs of equal cells are accumulated in registers); the result
  * does not depend on the order.  prefix_sum is accepted for signature compatibility with
  * the reference launch and is not read (may be NULL).
- * rho: HOST array of Nm device pointers.
+ * rho: HOST array of Nm device pointers; element (iz, ir) of each at
+ * base + iz*row_stride + ir*col_stride (complex elements).  col_stride = 1 (or 0) for the
+ * (Nz, Nr) grids of the reference; a record length > 1 selects a node-major target in which
+ * all components and modes of a node share a cache line: global atomics cost one L2 operation
+ * per line an instruction touches, so that layout makes the flush of a cell 6-12x cheaper
+ * (used inside Simulation.step, where the z-FFT then reads the records directly).
  * ruyten_m0 / ruyten_mh: Ruyten coefficients (Nr+1) for mode 0 / modes >= 1.
  * nflush (device uint64[1024], may be NULL): the counters are incremented so that their
  * SUM grows by the number of runs of equal cells met in the particle stream -- n/sum is the
@@ -159,7 +164,7 @@ int fb_permute(long n, const int *sorted_idx, int nattr,
 int fb_deposit_rho(int shape, int Nm, long n,
                    const double *x, const double *y, const double *z, const double *w, double q,
                    double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
-                   void *const *rho, long row_stride,
+                   void *const *rho, long row_stride, long col_stride,
                    const int *prefix_sum, const double *ruyten_m0, const double *ruyten_mh,
                    unsigned long long *nflush, void *stream);
 
@@ -171,7 +176,7 @@ int fb_deposit_J(int shape, int Nm, long n,
                  const double *ux, const double *uy, const double *uz, const double *inv_gamma,
                  double c,
                  double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
-                 void *const *J, long row_stride,
+                 void *const *J, long row_stride, long col_stride,
                  const int *prefix_sum, const double *ruyten_m0, const double *ruyten_mh,
                  unsigned long long *nflush, void *stream);
 
@@ -185,7 +190,7 @@ int fb_deposit_J_rank_next(int shape, int Nm, long n, const double *x, const dou
                            const double *z, const double *w, double q, const double *ux,
                            const double *uy, const double *uz, const double *inv_gamma, double c,
                            double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
-                           void *const *J, long row_stride, const double *ruyten_m0,
+                           void *const *J, long row_stride, long col_stride, const double *ruyten_m0,
                            const double *ruyten_mh, unsigned long long *nflush,
                            double dt_push, double x_push, double y_push, double z_push,
                            int ncell, void *sort_workspace, size_t workspace_bytes,
@@ -294,6 +299,13 @@ int fb_zfft(int Nz, long ncols, const void *in, long in_stride, void *out, long 
  * Out of place only. */
 int fb_zfft_pm_to_rt(int Nz, long ncols, const void *in, long in_stride, void *out,
                      long out_stride, int Nr, void *stream);
+
+/* Forward fb_zfft whose input is the node-major record array the in-step deposition fills
+ * (fb_deposit_* with col_stride = record): in[iz*in_stride + ir*record + f], f < nfields, is
+ * gathered as column (f, ir); the output is the usual z-major slab view of nfields*Nr
+ * columns.  Out of place only; lengths as fb_zfft. */
+int fb_zfft_from_records(int Nz, int nfields, int Nr, const void *in, long in_stride, int record,
+                         void *out, long out_stride, void *stream);
 
 /* Self-contained fallback for every other length whose prime factors are <= 31 (rocFFT of
  * ROCm 7.2 refuses some, e.g. Nz = 4416): one Stockham pass per launch through global

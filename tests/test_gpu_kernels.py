@@ -178,7 +178,11 @@ def _deposit_gpu(hip, g, shape, Nm, what, b0, bh, slab=False, presort=True):
     d = {k: dev(hip, g[k][si]) for k in names}            # (sorted) particle arrays
     dpre = dev(hip, pre)
     ncomp = 1 if what == 'rho' else 3
-    if slab:
+    if slab == 'records':      # node-major target: all fields of a node in one record
+        rec = ncomp * Nm + 1
+        s = t.zeros((Nz, Nr, rec), dtype=t.complex128, device='cuda')
+        views = [s[:, :, j] for j in range(ncomp * Nm)]
+    elif slab:
         s = t.zeros((Nz, ncomp * Nm + 1, Nr), dtype=t.complex128, device='cuda')
         views = [s[:, j, :] for j in range(ncomp * Nm)]
     else:
@@ -189,12 +193,14 @@ def _deposit_gpu(hip, g, shape, Nm, what, b0, bh, slab=False, presort=True):
     if what == 'rho':
         rc = hip.lib().fb_deposit_rho(sh, Nm, g['x'].size, p(d['x']), p(d['y']), p(d['z']), p(d['w']),
                                       float(g['q']), *geom, hip.ptr_array(views),
-                                      hip.row_stride(views[0]), p(dpre), p(db0), p(dbh), None, hip.stream())
+                                      views[0].stride(0), views[0].stride(1), p(dpre), p(db0), p(dbh),
+                                      None, hip.stream())
     else:
         rc = hip.lib().fb_deposit_J(sh, Nm, g['x'].size, p(d['x']), p(d['y']), p(d['z']), p(d['w']),
                                     float(g['q']), p(d['ux']), p(d['uy']), p(d['uz']),
                                     p(d['inv_gamma']), c, *geom, hip.ptr_array(views),
-                                    hip.row_stride(views[0]), p(dpre), p(db0), p(dbh), None, hip.stream())
+                                    views[0].stride(0), views[0].stride(1), p(dpre), p(db0), p(dbh),
+                                    None, hip.stream())
     hip.check(rc, 'fb_deposit')
     return np.array([host(v) for v in views])
 
@@ -219,9 +225,13 @@ def test_deposit_vs_oracle_and_golden(hip, oracle, shape, Nm):
         assert rel_err(got, red) < TOL
         got_u = _deposit_gpu(hip, g, shape, Nm, 'rho', b0, bh, slab=bool(ruy), presort=False)
         assert rel_err(got_u, red) < TOL
+        got_r = _deposit_gpu(hip, g, shape, Nm, 'rho', b0, bh, slab='records')
+        assert rel_err(got_r, red) < TOL
         gl = oracle.deposit_J_global(shape, Nm, g['x'], g['y'], g['z'], g['w'], float(g['q']),
                                      g['ux'], g['uy'], g['uz'], g['inv_gamma'], *geom, b0, bh, 1)
+        gotJr = _deposit_gpu(hip, g, shape, Nm, 'J', b0, bh, slab='records').reshape(Nm, 3, Nz, Nr)
         gotJ = _deposit_gpu(hip, g, shape, Nm, 'J', b0, bh, slab=bool(ruy)).reshape(Nm, 3, Nz, Nr)
+        assert rel_err(gotJr, gotJ) < TOL
         for k in range(3):
             redk = np.zeros((Nm, Nz, Nr), complex)
             for m in range(Nm):
@@ -489,6 +499,22 @@ def test_rt_pm_fused_into_hankel_and_fft(hip):
     assert np.array_equal(host(s4), b)
 
 
+def test_zfft_from_records(hip):
+    """fb_zfft_from_records == fb_zfft forward of the same fields laid out as a slab."""
+    rng = np.random.default_rng(10)
+    Nz, Nr, nf, rec = 256, 24, 5, 8
+    t = hip.torch()
+    a = rng.normal(size=(Nz, Nr, rec)) + 1j * rng.normal(size=(Nz, Nr, rec))
+    S = dev(hip, a)
+    out = t.zeros((Nz, nf + 1, Nr), dtype=t.complex128, device='cuda')
+    hip.check(hip.lib().fb_zfft_from_records(Nz, nf, Nr, S.data_ptr(), Nr * rec, rec,
+                                             out[:, 0, :].data_ptr(), (nf + 1) * Nr, hip.stream()),
+              'zfft records')
+    ref = np.fft.fft(np.transpose(a[:, :, :nf], (0, 2, 1)), axis=0)
+    assert rel_err(host(out[:, :nf, :]), ref) < TOL
+    assert np.all(host(out[:, nf, :]) == 0)
+
+
 def test_psatd_step_fused_equals_separate(hip, oracle):
     """fb_psatd_step_standard == correct_currents -> push_eb -> push_rho (oracle, per mode)."""
     g = golden('spectral')
@@ -720,11 +746,11 @@ def test_push_x_folded_into_sort(hip, oracle, preranked):
             J.zero_(); J2.zero_()
             hip.check(hip.lib().fb_deposit_J_rank_next(
                 shape, Nm, n, p(src[0]), p(src[1]), p(src[2]), p(src[6]), q, p(src[3]), p(src[4]),
-                p(src[5]), p(src[7]), c, *geom, hip.ptr_array(views), 3 * Nm * Nr, p(ruy), p(ruy),
+                p(src[5]), p(src[7]), c, *geom, hip.ptr_array(views), 3 * Nm * Nr, 1, p(ruy), p(ruy),
                 None, dt, 1., 1., 1., ncell, p(ws), nb, hip.stream()), 'deposit_J_rank_next')
             hip.check(hip.lib().fb_deposit_J(
                 shape, Nm, n, p(src[0]), p(src[1]), p(src[2]), p(src[6]), q, p(src[3]), p(src[4]),
-                p(src[5]), p(src[7]), c, *geom, hip.ptr_array(views2), 3 * Nm * Nr, None, p(ruy),
+                p(src[5]), p(src[7]), c, *geom, hip.ptr_array(views2), 3 * Nm * Nr, 1, None, p(ruy),
                 p(ruy), None, hip.stream()), 'deposit_J')
             assert rel_err(host(J), host(J2)) < 1e-13
     hip.check(hip.lib().fb_push_x_bin_sort_particles(

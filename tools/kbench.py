@@ -58,6 +58,8 @@ def main():
         timeit('push_p', lambda: s.push_p(0.), 112)
         timeit('deposit_J', lambda: s.deposit(fld, 'J'), 64)
         timeit('deposit_rho', lambda: s.deposit(fld, 'rho'), 32)
+        timeit('deposit_J_rec', lambda: s.deposit(fld, 'J', records=True), 64)
+        timeit('deposit_rho_rec', lambda: s.deposit(fld, 'rho', records=True), 32)
         timeit('sort', lambda: s.sort_particles(fld))
         timeit('interp2spect_J', lambda: fld.interp2spect('J'))
         timeit('spect2interp_E', lambda: fld.spect2interp('E'))
