@@ -237,6 +237,37 @@ __global__ __launch_bounds__(256) void k_gather(int Nm_arg, long n,
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             // stage node values: lane = (segment, field, jz, jr)
+            if (NMT > 0 && S * S * 6 * NMT <= 64) {
+                // one node value per lane and segment: the loads of up to 4 segments are
+                // issued together (independent L2 round trips) before any is written to LDS
+                const int o = lane;
+                const bool lane_on = o < NV;
+                const int jr = o % S, jz = (o / S) % S, f = lane_on ? o / (S * S) : 0;
+                const int m_ = f / 6, k_ = f - 6 * m_;
+                const double flip = m1pow(m_);
+                const double sgn_below = (k_ % 3 == 2) ? flip : -flip;
+                for (int sg0 = 0; sg0 < ns; sg0 += 4) {
+                    double2 vals[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        vals[u] = make_double2(0., 0.);
+                        if (sg0 + u < ns && lane_on) {
+                            int row = segkz[sg0 + u] + jz, col = segkr[sg0 + u] + jr;
+                            if (row < 0) row += Nz; else if (row > Nz - 1) row -= Nz;
+                            double sgn = 1.;
+                            if (col < 0) { col = -col - 1; sgn = sgn_below; }
+                            else if (col > Nr - 1) col = Nr - 1;
+                            double2 v = ldc(G.g[f] + (long)row * rs + col);
+                            v.x *= sgn; v.y *= sgn;
+                            vals[u] = v;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (sg0 + u < ns && lane_on)
+                            *(double2 *)(panel + (size_t)(sg0 + u) * PSTR + 2 * o) = vals[u];
+                }
+            } else
             for (int sg = 0; sg < ns; sg++)
             for (int o = lane; o < NV; o += 64) {
                 const int jr = o % S, jz = (o / S) % S, f = o / (S * S);

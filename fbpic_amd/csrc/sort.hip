@@ -156,8 +156,8 @@ __global__ __launch_bounds__(256) void k_scatter(long n, const int *__restrict__
             dst.p[6][d] = wt; dst.p[7][d] = g;
         }
         for (int k = PUSH ? 8 : 0; k < nattr; k++) dst.p[k][d] = src.p[k][i];
-        cell_sorted[d] = c;
-        sorted_idx[d] = (int)i;
+        if (cell_sorted) cell_sorted[d] = c;
+        if (sorted_idx) sorted_idx[d] = (int)i;
     }
 }
 

@@ -85,6 +85,9 @@ class Particles(object):
         # counting sort (fb_bin_sort_particles) instead of cell_index + radix sort + permute;
         # False restores the reference-like stable three-stage sort
         self.use_bin_sort = True
+        # the counting sort only materialises `cell_idx` / `sorted_idx` (sorted cell of every
+        # particle, permutation) when asked: nothing on the hot path reads them
+        self.keep_sort_outputs = False
         self.max_deposits_between_sorts = 16
         self._runs_after_sort = None
         self._runs_latest = None
@@ -292,6 +295,8 @@ class Particles(object):
             names = list(_STATE) + (list(_FIELDS) if self.keep_fields_sorted else [])
             src = [getattr(self, k) for k in names]
             dst = self._alt[:len(names)]
+            p_cell = p(self.cell_idx) if self.keep_sort_outputs else None
+            p_sidx = p(self.sorted_idx) if self.keep_sort_outputs else None
             pend, self._pending_push = self._pending_push, None
             preranked = int(pend is not None and self._prerank == pend)
             self._prerank = None
@@ -301,16 +306,16 @@ class Particles(object):
                     self.Ntot, self.prefix_sum.shape[0], p(self.x), p(self.y), p(self.z),
                     p(self.ux), p(self.uy), p(self.uz), p(self.inv_gamma), c, pend[0], pend[1],
                     pend[2], pend[3], g0.invdz, g0.zmin, g0.Nz, g0.invdr, g0.rmin, g0.Nr,
-                    len(names), _capi.ptr_array(src), _capi.ptr_array(dst), p(self.cell_idx),
-                    p(self.sorted_idx), p(self.prefix_sum), p(self._sort_ws),
+                    len(names), _capi.ptr_array(src), _capi.ptr_array(dst), p_cell, p_sidx,
+                    p(self.prefix_sum), p(self._sort_ws),
                     self._sort_ws.shape[0], preranked, st)
                 _capi.check(rc, 'fb_push_x_bin_sort_particles')
             else:
                 rc = lib.fb_bin_sort_particles(
                     self.Ntot, self.prefix_sum.shape[0], p(self.x), p(self.y), p(self.z),
                     g0.invdz, g0.zmin, g0.Nz, g0.invdr, g0.rmin, g0.Nr, len(names),
-                    _capi.ptr_array(src), _capi.ptr_array(dst), p(self.cell_idx),
-                    p(self.sorted_idx), p(self.prefix_sum), p(self._sort_ws),
+                    _capi.ptr_array(src), _capi.ptr_array(dst), p_cell, p_sidx,
+                    p(self.prefix_sum), p(self._sort_ws),
                     self._sort_ws.shape[0], st)
                 _capi.check(rc, 'fb_bin_sort_particles')
             for i, k in enumerate(names):

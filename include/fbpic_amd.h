@@ -112,7 +112,8 @@ int fb_sort_by_cell(long n, int ncell, int *cell_idx, int *sorted_idx,
  * src[k][old]).  Outputs as the reference's sort: cell_idx_sorted[n], sorted_idx[n]
  * (old index of each sorted particle), prefix_sum[ncell] (inclusive).  Unlike Thrust's
  * stable argsort the order INSIDE a cell is unspecified (gather and deposition do not
- * depend on it).  src/dst: HOST arrays of nattr (<= 16) device pointers. */
+ * depend on it).  src/dst: HOST arrays of nattr (<= 16) device pointers.  cell_idx_sorted
+ * and sorted_idx may be NULL when the caller does not need them (8 B per particle less). */
 size_t fb_bin_sort_workspace_bytes(long n, int ncell);
 int fb_bin_sort_particles(long n, int ncell, const double *x, const double *y, const double *z,
                           double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
