@@ -203,6 +203,7 @@ def test_headline_size_properties():
     from fbpic_amd.main import GpuMemoryManager
     sim = helpers.uniform_plasma_sim(1024, 128, 2, (2, 4, 4), 'linear', seed=0)
     s = sim.ptcl[0]
+    s.keep_sort_outputs = True          # materialise cell_idx / sorted_idx for check (a)
     n = s.Ntot
     assert n == 4194304
     w_sorted = np.sort(s.w)
