@@ -232,3 +232,34 @@ def test_headline_size_properties():
         sim.fld.spect2interp('E')
         err = (sim.fld.interp[1].Er - E0).abs().max().item() / max(E0.abs().max().item(), 1e-300)
     assert err < 1e-11
+
+
+def test_empty_and_tiny_species_step():
+    """Edge cases of the particle path: a species with no particle, one with a single particle
+    sitting exactly on the axis, and both together with a normal species; the cycle must run
+    and the normal species must be unaffected by the presence of the empty one."""
+    from scipy.constants import e, m_e
+    ref = helpers.uniform_plasma_sim(32, 16, 2, (2, 2, 4), 'linear', seed=5)
+    sim = helpers.uniform_plasma_sim(32, 16, 2, (2, 2, 4), 'linear', seed=5)
+    empty = sim.add_new_species(q=e, m=1836. * m_e)
+    assert empty.Ntot == 0
+    one = sim.add_new_species(q=0., m=m_e)            # neutral: gathers / deposits nothing
+    for k, v in (('x', 0.), ('y', 0.), ('z', 1.e-6), ('ux', 0.), ('uy', 0.), ('uz', 0.5),
+                 ('inv_gamma', 1. / np.sqrt(1.25)), ('w', 1.)):
+        setattr(one, k, np.array([v]))
+    one.Ntot = 1
+    for k in ('Ex', 'Ey', 'Ez', 'Bx', 'By', 'Bz'):
+        setattr(one, k, np.zeros(1))
+    ref.step(3)
+    sim.step(3)
+    assert sim.ptcl[1].Ntot == 0 and sim.ptcl[2].Ntot == 1
+    # the neutral particle just drifts: z advances by 3 * c dt * uz * inv_gamma (mod the box)
+    from scipy.constants import c
+    L = sim.fld.interp[0].zmax - sim.fld.interp[0].zmin
+    z_exp = (1.e-6 + 3 * c * sim.dt * 0.5 / np.sqrt(1.25)) % L
+    assert abs(float(sim.ptcl[2].z[0]) % L - z_exp) < 1e-12 * L
+    for m in range(2):
+        for k in ('Er', 'Ez', 'Bt', 'Jz', 'rho'):
+            a, b = getattr(sim.fld.interp[m], k), getattr(ref.fld.interp[m], k)
+            # two runs of the same input differ by the order of the deposition atomics only
+            assert np.array_equal(a, b) or np.abs(a - b).max() <= 1e-11 * np.abs(b).max(), (m, k)
