@@ -73,6 +73,13 @@ def parse():
     return ap.parse_args()
 
 
+def config_name(args, ppc):
+    """Which entry of BASELINE.json's `configs` the per-rank workload is (C2 = configs[1], the
+    one the metric is quoted on; C5 = configs[4]); anything else is a custom size."""
+    key = (args.Nz, args.Nr, args.Nm, ppc[0] * ppc[1] * ppc[2], args.shape)
+    return {(1024, 128, 2, 32, 'linear'): 'C2', (2048, 512, 4, 64, 'cubic'): 'C5'}.get(key, 'custom')
+
+
 def main():
     args = parse()
     import numpy as np
@@ -149,9 +156,10 @@ def main():
         'ms_per_step': 1e3 * dt_wall / args.steps, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'ns_per_particle_step': 1e9 * dt_wall / (args.steps * n_total) * world,
-        'config': {'workload': 'C2 uniform plasma %dx%d Nm=%d %d ppc %s shape, z-periodic, '
+        'config': {'workload': '%s uniform plasma %dx%d Nm=%d %d ppc %s shape, z-periodic, '
                                'standard PSATD n_order=%d, curl-free correction, filtered'
-                               % (args.Nz * world, args.Nr, args.Nm, ppc[0] * ppc[1] * ppc[2],
+                               % (config_name(args, ppc), args.Nz * world, args.Nr, args.Nm,
+                                  ppc[0] * ppc[1] * ppc[2],
                                   args.shape, n_order),
                    'particles': n_total, 'parallelism': 'z-slab x%d' % world},
     }

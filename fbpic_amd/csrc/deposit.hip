@@ -223,13 +223,14 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
     int cur_z = DEP_NOKEY, cur_r = DEP_NOKEY, cur_nb = 0;
     unsigned int my_flushes = 0;      // wave-uniform: runs of equal cells seen by this wave
 
-    // With the linear shape, two cells that follow each other along r share one node column.
-    // Its partial sums are not flushed: the accumulator lanes of that column simply become
-    // the lower column of the new cell (`par` swaps which radial weight feeds which lane),
-    // halving the atomics of an r-ordered stream.
-    constexpr bool SLIDE = (SHAPE == FB_SHAPE_LINEAR);
-    int par = 0;                      // linear shape: logical jr of a lane = (kl & 1) ^ par
-    // flush the finished cell; keep_upper: only its lower node column (the upper one carries on)
+    // Two cells that follow each other along r share S-1 of their S node columns.  The
+    // partial sums of those columns are not flushed: their accumulator lanes simply take the
+    // role of the next-lower column of the new cell (`off` rotates which radial weight feeds
+    // which lane), and only the lowest column of the finished cell is written out - 1/S of
+    // the atomics of an r-ordered stream (1/2 for the linear shape, 1/4 for the cubic one).
+    // Logical column of a lane whose physical column index is j: (j - off) mod S.
+    int off = 0;
+    // flush the finished cell; keep_upper: only its lowest node column (the others carry on)
     auto flush = [&](bool keep_upper) {
         if (cur_z == DEP_NOKEY) return;
         my_flushes++;
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
                     v = (bl == b) ? a : v;
                 }
             }
-            const int jr = SLIDE ? (f_jr[qq] ^ par) : f_jr[qq];
+            const int jr = (f_jr[qq] - off) & (S - 1);
             if (!f_ok[qq] || v == 0. || (keep_upper && jr != 0)) continue;
             if (interior) {
                 // all S x S nodes inside the grid (wave-uniform test): no guard folding, no
@@ -399,19 +400,22 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
             if ((starts >> p) & 1ull) {
                 const int nz_ = __builtin_amdgcn_readlane(my_kz, p);
                 const int nr_ = __builtin_amdgcn_readlane(my_kr, p);
-                if (SLIDE && nz_ == cur_z && nr_ == cur_r + 1) {
+                if (nz_ == cur_z && nr_ == cur_r + 1) {
                     flush(true);                     // column cur_r is complete
-                    const bool upper = ((kl & 1) ^ par) != 0;   // carries on as the lower column
+                    // the other columns carry on, one position lower in the new cell
+                    const bool carry = (((kl & (S - 1)) - off) & (S - 1)) != 0;
 #pragma unroll
-                    for (int t = 0; t < NT; t++) acc[0][t] = upper ? acc[0][t] : 0.;
-                    par ^= 1;
+                    for (int rg = 0; rg < RG; rg++)
+#pragma unroll
+                        for (int t = 0; t < NT; t++) acc[rg][t] = carry ? acc[rg][t] : 0.;
+                    off = (off + 1) & (S - 1);
                 } else {
                     flush(false);
 #pragma unroll
                     for (int rg = 0; rg < RG; rg++)
 #pragma unroll
                         for (int t = 0; t < NT; t++) acc[rg][t] = 0.;
-                    par = 0;
+                    off = 0;
                 }
                 cur_z = nz_;
                 cur_r = nr_;
@@ -421,8 +425,9 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
             int e = rest ? p + 1 + __builtin_ctzll(rest) : cnt;
             if (e > cnt) e = cnt;
             const int g1 = (e - 1) >> 4;
-            // weight rows fed by this lane: node rg*4 + jl (linear: its column follows `par`)
-            const int wrow = SLIDE ? (jl ^ par) : jl;
+            // weight rows fed by this lane: node rg*4 + (its logical column); for the linear
+            // shape jl = jz*2 + jr and only the jr bit rotates
+            const int wrow = (S == 2) ? (jl ^ off) : ((jl - off) & 3);
             for (int g = p >> 4; g <= g1; g++) {
                 const int pi = 16 * g + poff;
                 const bool in = (pi >= p) && (pi < e);
