@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
         }
     };
 
-    const long chunk0 = ((long)blockIdx.x * nwaves + wave) * chunks_per_wave;
+    const long chunk0 = (xcd_block_id() * nwaves + wave) * chunks_per_wave;
     // software pipeline: particle data of chunk ch+1 is requested before chunk ch is
     // processed, hiding the HBM latency behind the staging + accumulation work
     double pn[NCOMP == 1 ? 4 : 8];
@@ -488,7 +488,7 @@ static int launch_z(long n, const double *x, const double *y, const double *z, c
     if (cpw < 1) cpw = 1;
     if (cpw > 64) cpw = 64;
     const long total_waves = (nchunks + cpw - 1) / cpw;
-    const long nblocks = (total_waves + nwaves - 1) / nwaves;
+    const long nblocks = xcd_grid((total_waves + nwaves - 1) / nwaves);
     auto kern = k_deposit<SHAPE, NCOMP, NM, Z0, RANK>;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(64 * nwaves),
                        L::wave_bytes() * nwaves, s, n, x, y, z, w, q, ux, uy, uz, ig, c,

@@ -33,6 +33,23 @@ __device__ __forceinline__ double m1pow(int m) { return (m & 1) ? -1. : 1.; }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Workgroups are dealt round-robin to the 8 XCDs (workgroup b runs on XCD b % 8), each with
+// its own L2.  For kernels that walk the cell-sorted particle stream, give every XCD one
+// contiguous eighth of the stream: neighbouring cells (which share grid nodes) then meet in
+// ONE L2 - field nodes are fetched from HBM once instead of once per XCD, and the lines that
+// deposition atomics update stop bouncing between L2s.  Launch with xcd_grid(nb) workgroups;
+// logical ids >= nb are the idle tail.
+constexpr int FB_NXCD = 8;
+inline long xcd_grid(long nblocks) { return (nblocks + FB_NXCD - 1) / FB_NXCD * FB_NXCD; }
+#ifdef __HIPCC__
+__device__ __forceinline__ long xcd_block_id()
+{
+    const long per = gridDim.x / FB_NXCD;
+    return (long)(blockIdx.x % FB_NXCD) * per + blockIdx.x / FB_NXCD;
+}
+#endif
+
+
 // Layout of the counting-sort workspace (fb_bin_sort_workspace_bytes): per-cell counters,
 // per-particle cell and rank, then the rocPRIM scan scratch.  Shared by sort.hip and by the
 // deposition kernel that pre-computes cell + rank for the sort that follows it.

@@ -147,6 +147,7 @@ constexpr int G_NOKEY = -0x40000000;
 
 // NMT > 0: number of modes known at compile time (mode loop unrolled, exptheta_0 = 1 folded
 // away); NMT = 0: run-time Nm.
+// (forcing a higher occupancy with amdgpu_waves_per_eu spills: measured 1.2x-4x slower)
 template <int SHAPE, int NMT>
 __global__ __launch_bounds__(256) void k_gather(int Nm_arg, long n,
         const double *__restrict__ x, const double *__restrict__ y,
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void k_gather(int Nm_arg, long n,
     int *segkz = (int *)(panel + (size_t)maxseg * PSTR);
     int *segkr = segkz + 8;
 
-    const long chunk0 = ((long)blockIdx.x * nwaves + wave) * chunks_per_wave;
+    const long chunk0 = (xcd_block_id() * nwaves + wave) * chunks_per_wave;
     // software pipeline: the particle coordinates of chunk ch+1 are requested before the
     // work on chunk ch starts, so their HBM latency hides behind staging + stencil math
     double xn = 0., yn = 0., zn = 0.;
@@ -436,7 +437,7 @@ static int launch_gather(int shape, int Nm, long n, const double *x, const doubl
     if (cpw < 1) cpw = 1;
     if (cpw > 64) cpw = 64;
     const long total_waves = (nchunks + cpw - 1) / cpw;
-    dim3 grid((unsigned)((total_waves + nwaves - 1) / nwaves)), block(64 * nwaves);
+    dim3 grid((unsigned)xcd_grid((total_waves + nwaves - 1) / nwaves)), block(64 * nwaves);
 #define FB_LAUNCH_GATHER(SH, NMT) \
     hipLaunchKernelGGL((k_gather<SH, NMT>), grid, block, wave_bytes * nwaves, s, Nm, n, x, y, z, \
                        rmax_gather, invdz, zmin, Nz, invdr, rmin, Nr, G, row_stride, Ex, Ey, Ez, \

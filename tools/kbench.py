@@ -55,6 +55,7 @@ def main():
         s.sorted = True
         timeit('gather', lambda: s.gather(fld.interp, sim.comm), 72)
         timeit('gather_push', lambda: s.gather_push(fld.interp, sim.comm, 0.), 136)
+        timeit('gather_push_ns', lambda: s.gather_push(fld.interp, sim.comm, 0., store_fields=False), 112)
         timeit('push_p', lambda: s.push_p(0.), 112)
         timeit('deposit_J', lambda: s.deposit(fld, 'J'), 64)
         timeit('deposit_rho', lambda: s.deposit(fld, 'rho'), 32)
