@@ -45,6 +45,8 @@ _SIGNATURES = {
     'fb_correct_currents_curlfree_standard': (I, [P, P, P, P, P, L, P, P, P, D, I, I, P]),
     'fb_push_eb_standard': (I, [P] * 11 + [L] + [P] * 7 + [D, I, D, D, D, I, I, P]),
     'fb_correct_currents_curlfree_comoving': (I, [P, P, P, P, P, L, P, P, P, P, P, P, I, I, P]),
+    'fb_correct_currents_crossdeposition_standard': (I, [P] * 7 + [L, P, P, D, I, I, P]),
+    'fb_correct_currents_crossdeposition_comoving': (I, [P] * 7 + [L, P, P, P, P, P, I, I, P]),
     'fb_push_eb_comoving': (I, [P, P, P, P, P, P, P, P, P, P, P, L, P, P, P, P, P, P, P, P, P, P, D, D, I, D, D, D,
                                 I, I, P]),
     'fb_push_rho': (I, [P, P, L, I, I, P]),

@@ -253,6 +253,51 @@ __global__ __launch_bounds__(256) void k_correct_currents_comoving(const cplx *_
     }
 }
 
+// fields/numba_methods.py:87-116 (cross-deposition correction, standard PSATD): Dz + Dxy is
+// the error of the continuity equation, split with the help of two extra charge densities
+// deposited at (z[n], x[n+1]) [rho_next_xy] and (z[n+1], x[n]) [rho_next_z].
+// COMOVING: numba_methods.py:243-275, with the complex tables of the Galilean scheme.
+template <bool COMOVING>
+__global__ __launch_bounds__(256) void k_correct_currents_cross(const cplx *__restrict__ rho_prev,
+        const cplx *__restrict__ rho_next, const cplx *__restrict__ rho_next_z,
+        const cplx *__restrict__ rho_next_xy, cplx *__restrict__ Jp, cplx *__restrict__ Jm,
+        cplx *__restrict__ Jz, long rs, const double *__restrict__ kz, const double *__restrict__ kr,
+        double inv_dt, const cplx *__restrict__ j_corr_coef, const cplx *__restrict__ T_eb,
+        const cplx *__restrict__ T_cc, int Nz, int Nr)
+{
+    FB_GRID_LOOP(idx, iz, ir) {
+        const long o = (long)iz * rs + ir;
+        const double kzz = kz[idx], krr = kr[idx];
+        const cplx jp = ld(Jp + o), jm = ld(Jm + o), jz = ld(Jz + o);
+        const cplx rn = ld(rho_next + o), rz = ld(rho_next_z + o), rxy = ld(rho_next_xy + o);
+        cplx rp = ld(rho_prev + o), sz, sxy;
+        if (COMOVING) {
+            const cplx teb = ld(T_eb + idx);
+            const cplx txy = cmul(teb, rxy);
+            rp = cmul(teb, rp);
+            sz = csub(cadd(csub(rn, txy), rz), rp);
+            sxy = csub(csub(cadd(rn, txy), rz), rp);
+            const cplx h = cmul(rmul(0.5, ld(T_cc + idx)), ld(j_corr_coef + idx));
+            sz = cmul(h, sz);
+            sxy = cmul(h, sxy);
+        } else {
+            sz = rmul(0.5 * inv_dt, csub(cadd(csub(rn, rxy), rz), rp));
+            sxy = rmul(0.5 * inv_dt, csub(cadd(csub(rn, rz), rxy), rp));
+        }
+        const cplx Dz = cadd(rmul(kzz, imul(jz)), sz);
+        const cplx Dxy = cadd(rmul(krr, csub(jp, jm)), sxy);
+        if (krr != 0.) {
+            const double inv_kr = 1. / krr;
+            st(Jp + o, cadd(jp, rmul(inv_kr, rmul(-0.5, Dxy))));
+            st(Jm + o, cadd(jm, rmul(inv_kr, rmul(0.5, Dxy))));
+        }
+        if (kzz != 0.) {
+            const double inv_kz = 1. / kzz;
+            st(Jz + o, cadd(jz, rmul(inv_kz, imul(Dz))));
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_push_eb_comoving(cplx *__restrict__ Ep, cplx *__restrict__ Em,
         cplx *__restrict__ Ez, cplx *__restrict__ Bp, cplx *__restrict__ Bm, cplx *__restrict__ Bz,
         const cplx *__restrict__ Jp, const cplx *__restrict__ Jm, const cplx *__restrict__ Jz,
@@ -451,6 +496,32 @@ extern "C" int fb_correct_currents_curlfree_comoving(const void *rho_prev, const
                        (cplx *)Jm, (cplx *)Jz, rs, kz, kr, inv_k2, (const cplx *)j_corr_coef,
                        (const cplx *)T_eb, (const cplx *)T_cc, Nz, Nr);
     FB_CHECK_LAUNCH("fb_correct_currents_curlfree_comoving");
+}
+
+extern "C" int fb_correct_currents_crossdeposition_standard(const void *rho_prev,
+        const void *rho_next, const void *rho_next_z, const void *rho_next_xy,
+        void *Jp, void *Jm, void *Jz, long rs, const double *kz, const double *kr,
+        double inv_dt, int Nz, int Nr, void *stream)
+{
+    hipLaunchKernelGGL(k_correct_currents_cross<false>, dim3(grid_for(Nz, Nr)), dim3(256), 0,
+                       (hipStream_t)stream, (const cplx *)rho_prev, (const cplx *)rho_next,
+                       (const cplx *)rho_next_z, (const cplx *)rho_next_xy, (cplx *)Jp, (cplx *)Jm,
+                       (cplx *)Jz, rs, kz, kr, inv_dt, (const cplx *)nullptr, (const cplx *)nullptr,
+                       (const cplx *)nullptr, Nz, Nr);
+    FB_CHECK_LAUNCH("fb_correct_currents_crossdeposition_standard");
+}
+
+extern "C" int fb_correct_currents_crossdeposition_comoving(const void *rho_prev,
+        const void *rho_next, const void *rho_next_z, const void *rho_next_xy,
+        void *Jp, void *Jm, void *Jz, long rs, const double *kz, const double *kr,
+        const void *j_corr_coef, const void *T_eb, const void *T_cc, int Nz, int Nr, void *stream)
+{
+    hipLaunchKernelGGL(k_correct_currents_cross<true>, dim3(grid_for(Nz, Nr)), dim3(256), 0,
+                       (hipStream_t)stream, (const cplx *)rho_prev, (const cplx *)rho_next,
+                       (const cplx *)rho_next_z, (const cplx *)rho_next_xy, (cplx *)Jp, (cplx *)Jm,
+                       (cplx *)Jz, rs, kz, kr, 0., (const cplx *)j_corr_coef, (const cplx *)T_eb,
+                       (const cplx *)T_cc, Nz, Nr);
+    FB_CHECK_LAUNCH("fb_correct_currents_crossdeposition_comoving");
 }
 
 extern "C" int fb_push_eb_comoving(void *Ep, void *Em, void *Ez, void *Bp, void *Bm, void *Bz,

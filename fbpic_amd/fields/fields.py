@@ -44,8 +44,6 @@ class Fields(object):
         self.n_order = n_order
         self.v_comoving = v_comoving
         self.use_galilean = use_galilean if v_comoving is not None else False
-        if v_comoving is not None and current_correction != 'curl-free':
-            raise NotImplementedError('cross-deposition is outside the fbpic_amd scope')
         self.smoother = smoother if smoother is not None else \
             BinomialSmoother(n_passes=1, compensator=False)
         self.use_cuda = use_cuda
@@ -75,7 +73,8 @@ class Fields(object):
                                  'rho_next_xy': False, 'rho_next_z': False}
         # device state (allocated at the first send_fields_to_gpu)
         self.NFi = 10 * Nm
-        self.NFs = 11 * Nm
+        # + rho_next_z, rho_next_xy of every mode with the cross-deposition correction
+        self.NFs = (13 if current_correction == 'cross-deposition' else 11) * Nm
         self.NFx = 6 * Nm
         self.d_interp = None
         self.d_spect = None
@@ -93,6 +92,10 @@ class Fields(object):
             return 9 * self.Nm + m
         if name == 'rho_next':
             return 10 * self.Nm + m
+        if name == 'rho_next_z':
+            return 11 * self.Nm + m
+        if name == 'rho_next_xy':
+            return 12 * self.Nm + m
         return 3 * self.Nm * _VEC[name[0]] + 3 * m + _S_COMP.index(name[1])
 
     # ---------------------------------------------------------------- host <-> device
@@ -108,7 +111,7 @@ class Fields(object):
         for m in range(Nm):
             for name in INTERP_FIELDS:
                 hi[:, self.interp_index(name, m), :] = getattr(self.interp[m], name)
-            for name in SPECT_FIELDS:
+            for name in self.spect[m].field_names:
                 hs[:, self.spect_index(name, m), :] = getattr(self.spect[m], name)
         if self.d_interp is None:
             self.d_interp = self._alloc_slab(self.NFi)
@@ -120,7 +123,7 @@ class Fields(object):
         for m in range(Nm):
             for name in INTERP_FIELDS:
                 setattr(self.interp[m], name, self.d_interp[:, self.interp_index(name, m), :])
-            for name in SPECT_FIELDS:
+            for name in self.spect[m].field_names:
                 setattr(self.spect[m], name, self.d_spect[:, self.spect_index(name, m), :])
             self.interp[m].upload_tables()
             self.spect[m].upload_tables()
@@ -147,7 +150,7 @@ class Fields(object):
             for name in INTERP_FIELDS:
                 setattr(self.interp[m], name,
                         np.ascontiguousarray(hi[:, self.interp_index(name, m), :]))
-            for name in SPECT_FIELDS:
+            for name in self.spect[m].field_names:
                 setattr(self.spect[m], name,
                         np.ascontiguousarray(hs[:, self.spect_index(name, m), :]))
         self.data_is_on_gpu = False
@@ -188,7 +191,11 @@ class Fields(object):
             return f0, f0, 3 * Nm, True
         if fieldtype in ('rho_prev', 'rho_next'):
             return 9 * Nm, (9 if fieldtype == 'rho_prev' else 10) * Nm, Nm, False
-        if fieldtype in ('E_pml', 'B_pml', 'rho_next_z', 'rho_next_xy'):
+        if fieldtype in ('rho_next_z', 'rho_next_xy'):
+            if self.current_correction != 'cross-deposition':
+                raise ValueError('%s needs current_correction="cross-deposition"' % fieldtype)
+            return 9 * Nm, (11 if fieldtype == 'rho_next_z' else 12) * Nm, Nm, False
+        if fieldtype in ('E_pml', 'B_pml'):
             raise NotImplementedError('%s is outside the fbpic_amd scope' % fieldtype)
         raise ValueError('Invalid string for fieldtype: %s' % fieldtype)
 
@@ -390,6 +397,9 @@ class Fields(object):
             assert self.exchanged_source['rho_prev'] is False
             assert self.exchanged_source['rho_next'] is False
             assert self.exchanged_source['J'] is False
+            if self.current_correction == 'cross-deposition':
+                assert self.exchanged_source['rho_next_xy'] is False
+                assert self.exchanged_source['rho_next_z'] is False
         for m in range(self.Nm):
             self.spect[m].correct_currents(self.dt, self.psatd[m], self.current_correction)
 

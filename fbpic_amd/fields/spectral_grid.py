@@ -1,5 +1,5 @@
 """Spectral grid of one azimuthal mode: wavenumber / filter tables (host, NumPy) and the
-eleven spectral field arrays; device kernels for current correction, PSATD push, rho
+eleven spectral field arrays (thirteen with the cross-deposition correction); device kernels for current correction, PSATD push, rho
 shift and filtering (csrc/fields.hip).
 
 Tables restate fbpic/fields/spectral_grid.py:108-124; the methods replace the CUDA
@@ -11,8 +11,11 @@ from scipy.constants import c, epsilon_0, mu_0
 from .. import _capi
 
 SPECT_FIELDS = ('Ep', 'Em', 'Ez', 'Bp', 'Bm', 'Bz', 'Jp', 'Jm', 'Jz', 'rho_prev', 'rho_next')
+# only allocated with current_correction='cross-deposition' (spectral_grid.py:97-99)
+CROSS_FIELDS = ('rho_next_z', 'rho_next_xy')
 _FILTER_GROUPS = {'E': ('Ep', 'Em', 'Ez'), 'B': ('Bp', 'Bm', 'Bz'), 'J': ('Jp', 'Jm', 'Jz'),
-                  'rho_prev': ('rho_prev',), 'rho_next': ('rho_next',)}
+                  'rho_prev': ('rho_prev',), 'rho_next': ('rho_next',),
+                  'rho_next_z': ('rho_next_z',), 'rho_next_xy': ('rho_next_xy',)}
 
 
 class SpectralGrid(object):
@@ -20,14 +23,14 @@ class SpectralGrid(object):
                  use_pml=False, use_cuda=True):
         if use_pml:
             raise NotImplementedError('PML is outside the fbpic_amd scope')
-        if current_correction != 'curl-free':
-            raise NotImplementedError(
-                "only current_correction='curl-free' is implemented in fbpic_amd")
         Nz, Nr = len(kz_modified), len(kr)
         self.Nz, self.Nr, self.m = Nz, Nr, m
         self.use_pml = False
         self.use_cuda = use_cuda
-        for name in SPECT_FIELDS:
+        self.field_names = SPECT_FIELDS
+        if current_correction == 'cross-deposition':
+            self.field_names = SPECT_FIELDS + CROSS_FIELDS
+        for name in self.field_names:
             setattr(self, name, np.zeros((Nz, Nr), dtype='complex'))
         # field solve uses the (finite-order) modified kz, filtering the true kz
         self.kz, self.kr = np.meshgrid(kz_modified, kr, indexing='ij')
@@ -45,8 +48,24 @@ class SpectralGrid(object):
             self._tables_up = True
 
     def correct_currents(self, dt, ps, current_correction):
+        if current_correction == 'cross-deposition':
+            p = _capi.ptr
+            common = (p(self.rho_prev), p(self.rho_next), p(self.rho_next_z), p(self.rho_next_xy),
+                      p(self.Jp), p(self.Jm), p(self.Jz), _capi.row_stride(self.Jp),
+                      p(self.d_kz), p(self.d_kr))
+            if ps.V is not None:        # spectral_grid.py:250-258
+                t = ps.device_tables()
+                rc = _capi.lib().fb_correct_currents_crossdeposition_comoving(
+                    *common, p(t['j_corr_coef']), p(t['T_eb']), p(t['T_cc']), self.Nz, self.Nr,
+                    _capi.stream())
+                _capi.check(rc, 'fb_correct_currents_crossdeposition_comoving')
+            else:                       # spectral_grid.py:231-238
+                rc = _capi.lib().fb_correct_currents_crossdeposition_standard(
+                    *common, 1. / dt, self.Nz, self.Nr, _capi.stream())
+                _capi.check(rc, 'fb_correct_currents_crossdeposition_standard')
+            return
         if current_correction != 'curl-free':
-            raise NotImplementedError('only the curl-free correction is implemented')
+            raise ValueError('Unknown current correction: %s' % current_correction)
         if ps.V is not None:
             # Galilean / comoving-current scheme (spectral_grid.py:240-247)
             t = ps.device_tables()

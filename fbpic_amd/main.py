@@ -203,14 +203,17 @@ class Simulation(object):
                 species.handle_elementary_processes(self.time + 0.5 * dt)
             for species in ptcl:
                 species.keep_fields_sorted = False
-            if move_positions and not self.use_galilean:
+            cross = bool(correct_currents) and fld.current_correction == 'cross-deposition'
+            if move_positions and not self.use_galilean and not cross:
                 # the J deposition also ranks the particles for the sort after the push below
                 # (not with a Galilean grid: zmin moves between this deposit and that sort)
                 for species in ptcl:
                     species.push_after_deposit_J = (0.5 * dt, 1., 1., 1.)
-            self.deposit('J', exchange=(correct_currents is False), defer_transform=True)
+            self.deposit('J', exchange=(correct_currents is False), defer_transform=not cross)
             for species in ptcl:
                 species.push_after_deposit_J = None
+            if cross:
+                self.cross_deposit(move_positions)
             if move_positions:
                 # deferred: the push is folded into the sort that deposit('rho_next') triggers
                 for species in ptcl:
@@ -232,13 +235,18 @@ class Simulation(object):
                 fld.push(use_true_rho, check_exchanges=(self.comm.size > 1))
             elif self.comm.size == 1:
                 # single domain: correction, push and rho shift are cell-local -> one launch
-                fld.psatd_step(correct_currents, use_true_rho)
+                if cross:
+                    fld.correct_currents()
+                fld.psatd_step(correct_currents and not cross, use_true_rho)
                 if correct_currents:
                     fld.exchanged_source['J'] = True
             else:
                 if correct_currents:
                     assert fld.exchanged_source['J'] is False
-                    fld.psatd_step(use_true_rho=use_true_rho, only_correct=True)
+                    if cross:
+                        fld.correct_currents(check_exchanges=True)
+                    else:
+                        fld.psatd_step(use_true_rho=use_true_rho, only_correct=True)
                     fld.spect2partial_interp('J')
                     self.comm.exchange_fields(fld.interp, 'J', 'add')
                     fld.partial_interp2spect('J')
@@ -258,6 +266,35 @@ class Simulation(object):
         fld.spect2interp('rho_prev')
         if (not fld.exchanged_source['rho_prev']) and (self.comm.size > 1):
             self.comm.exchange_fields(fld.interp, 'rho', 'add')
+
+    def cross_deposit(self, move_positions):
+        """Cross-deposition (main.py:672-716), called with the particles at t = n+1/2:
+        charge density at (z[n], x[n+1]) -> rho_next_xy, at (z[n+1], x[n]) -> rho_next_z,
+        then back to n+1/2.  Each push rides along in the sort of the deposit that follows."""
+        dt = self.dt
+        if self.laser_antennas:
+            raise NotImplementedError('laser antennas are outside the fbpic_amd scope')
+
+        def push(frac, x_push, y_push, z_push, defer):
+            if move_positions:
+                for species in self.ptcl:
+                    species.push_x(frac * dt, x_push=x_push, y_push=y_push, z_push=z_push,
+                                   defer=defer)
+        push(0.5, 1., 1., -1., True)          # z[n+1/2], x[n+1/2] => z[n], x[n+1]
+        if self.use_galilean:
+            self.shift_galilean_boundaries(-0.5 * dt)
+        self.deposit('rho_next_xy')
+        for species in self.ptcl:
+            species.flush_pending_push()
+        push(1., -1., -1., 1., True)          # z[n], x[n+1] => z[n+1], x[n]
+        if self.use_galilean:
+            self.shift_galilean_boundaries(dt)
+        self.deposit('rho_next_z')
+        for species in self.ptcl:
+            species.flush_pending_push()
+        push(0.5, 1., 1., -1., False)         # z[n+1], x[n] => z[n+1/2], x[n+1/2]
+        if self.use_galilean:
+            self.shift_galilean_boundaries(-0.5 * dt)
 
     def _flush_J_transform(self):
         """Transform a J whose interp2spect was deferred (see deposit)."""

@@ -233,6 +233,19 @@ int fb_correct_currents_curlfree_comoving(const void *rho_prev, const void *rho_
         void *Jp, void *Jm, void *Jz, long row_stride, const double *kz, const double *kr,
         const double *inv_k2, const void *j_corr_coef, const void *T_eb, const void *T_cc,
         int Nz, int Nr, void *stream);
+/* Cross-deposition current correction (fields/spectral_grid.py:231-238, 250-258 ->
+ * cuda_correct_currents_crossdeposition_{standard,comoving}; same argument order as
+ * fields/numba_methods.py:87-116, 243-275).  rho_next_z / rho_next_xy: spectral charge
+ * densities deposited at (z[n+1], x[n]) and (z[n], x[n+1]) by Simulation.cross_deposit
+ * (main.py:672-716); same row stride as the other spectral fields. */
+int fb_correct_currents_crossdeposition_standard(const void *rho_prev, const void *rho_next,
+        const void *rho_next_z, const void *rho_next_xy, void *Jp, void *Jm, void *Jz,
+        long row_stride, const double *kz, const double *kr, double inv_dt,
+        int Nz, int Nr, void *stream);
+int fb_correct_currents_crossdeposition_comoving(const void *rho_prev, const void *rho_next,
+        const void *rho_next_z, const void *rho_next_xy, void *Jp, void *Jm, void *Jz,
+        long row_stride, const double *kz, const double *kr, const void *j_corr_coef,
+        const void *T_eb, const void *T_cc, int Nz, int Nr, void *stream);
 int fb_push_eb_comoving(void *Ep, void *Em, void *Ez, void *Bp, void *Bm, void *Bz,
         const void *Jp, const void *Jm, const void *Jz,
         const void *rho_prev, const void *rho_next, long row_stride,

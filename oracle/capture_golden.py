@@ -520,6 +520,92 @@ def cap_galilean():
         save(name, **res)
 
 
+def cap_crossdep():
+    """Cross-deposition current correction: the two spectral kernels on
+    random inputs, and whole-cycle trajectories with current_correction='cross-deposition'
+    (standard PSATD plasma wave, linear + cubic; Galilean drifting plasma, cubic)."""
+    import importlib
+    from fbpic.fields import Fields
+    from fbpic.fields.numba_methods import numba_correct_currents_crossdeposition_standard, \
+        numba_correct_currents_crossdeposition_comoving
+    from fbpic.main import Simulation
+    rng = np.random.default_rng(606)
+    Nz, Nr, Nm = 32, 16, 2
+    dz, dr = 0.25e-6, 0.5e-6
+    dt = dz / c
+    names = ['rho_prev', 'rho_next', 'rho_next_z', 'rho_next_xy', 'Jp', 'Jm', 'Jz']
+    res = dict(Nz=Nz, Nr=Nr, Nm=Nm, dz=dz, dr=dr, dt=dt)
+    for tag, V, gal in (('std', None, False), ('gal', 0.9 * c, True), ('com', -0.5 * c, False)):
+        f = Fields(Nz, Nz * dz, Nr, Nr * dr, Nm, dt, n_order=-1, zmin=0.,
+                   current_correction='cross-deposition', v_comoving=V, use_galilean=gal)
+        res['%s_V' % tag] = np.nan if V is None else V
+        for m in range(Nm):
+            sp, ps = f.spect[m], f.psatd[m]
+            for k in ('kz', 'kr'):
+                res['%s_%s_m%d' % (tag, k, m)] = np.asarray(getattr(sp, k))
+            if V is not None:
+                for k in ('T_eb', 'T_cc', 'j_corr_coef'):
+                    res['%s_%s_m%d' % (tag, k, m)] = np.asarray(getattr(ps, k))
+            scale = dict(J=1e12, r=1e4)
+            arrs = {k: (rng.normal(size=(Nz, Nr)) + 1j * rng.normal(size=(Nz, Nr))) * scale[k[0]]
+                    for k in names}
+            for k in names:
+                res['%s_in_%s_m%d' % (tag, k, m)] = arrs[k].copy()
+            cc = {k: arrs[k].copy() for k in names}
+            if V is None:
+                numba_correct_currents_crossdeposition_standard(
+                    cc['rho_prev'], cc['rho_next'], cc['rho_next_z'], cc['rho_next_xy'],
+                    cc['Jp'], cc['Jm'], cc['Jz'], sp.kz, sp.kr, 1. / dt, Nz, Nr)
+            else:
+                numba_correct_currents_crossdeposition_comoving(
+                    cc['rho_prev'], cc['rho_next'], cc['rho_next_z'], cc['rho_next_xy'],
+                    cc['Jp'], cc['Jm'], cc['Jz'], sp.kz, sp.kr, ps.j_corr_coef, ps.T_eb,
+                    ps.T_cc, 1. / dt, Nz, Nr)
+            for k in ('Jp', 'Jm', 'Jz'):
+                res['%s_cc_%s_m%d' % (tag, k, m)] = cc[k]
+    save('crossdep_kernels', **res)
+
+    sys.path.insert(0, '/root/reference/tests')
+    T = importlib.import_module('test_periodic_plasma_wave')
+    for name, shape, V in (('cycle_cross_lin_16x8', 'linear', None),
+                           ('cycle_cross_cub_16x8', 'cubic', None),
+                           ('cycle_cross_galilean_cub_16x8', 'cubic', 'gal')):
+        Nz, Nr, Nm = 16, 8, 2
+        dz = 0.2e-6
+        zmax, rmax = Nz * dz, Nr * 0.3125e-6
+        dt = dz / c
+        gamma_b = 3.
+        beta_b = -np.sqrt(1. - 1. / gamma_b**2)
+        np.random.seed(13)
+        sim = Simulation(Nz, zmax, Nr, rmax, Nm, dt, 0., zmax, 0., 0.9 * rmax, 2, 2, 4, 2.e24,
+                         n_order=-1, particle_shape=shape, verbose_level=0,
+                         current_correction='cross-deposition',
+                         v_comoving=(beta_b * c if V else None), use_galilean=bool(V))
+        sp0 = sim.ptcl[0]
+        if V:
+            rng2 = np.random.default_rng(3)
+            sp0.uz[:] = gamma_b * beta_b + 0.01 * rng2.normal(size=sp0.Ntot)
+            sp0.ux[:] = 0.01 * rng2.normal(size=sp0.Ntot)
+            sp0.uy[:] = 0.01 * rng2.normal(size=sp0.Ntot)
+            sp0.inv_gamma[:] = 1. / np.sqrt(1. + sp0.ux**2 + sp0.uy**2 + sp0.uz**2)
+        else:
+            k0 = 2 * np.pi / zmax
+            wp = np.sqrt(2.e24 * e**2 / (m_e * epsilon_0))
+            T.impart_momenta(sp0, [0.01, 0.01, 0.01], k0, 0.4 * rmax, wp)
+        res = dict(Nz=Nz, Nr=Nr, Nm=Nm, zmax=zmax, rmax=rmax, dt=dt, n_order=-1, shape=shape,
+                   v_comoving=(beta_b * c if V else np.nan), use_galilean=bool(V), n_species=1,
+                   q=np.array([s.q for s in sim.ptcl]), m=np.array([s.m for s in sim.ptcl]))
+        snapshot(sim, 's0', res, spect=False)
+        res['s0_zmin'] = sim.fld.interp[0].zmin
+        done = 0
+        for upto in (1, 2, 5):
+            sim.step(upto - done, show_progress=False)
+            done = upto
+            snapshot(sim, 's%d' % upto, res)
+            res['s%d_zmin' % upto] = sim.fld.interp[0].zmin
+        save(name, **res)
+
+
 def cap_uniform_rho():
     """Counterpart of tests/test_uniform_rho_deposition.py: only the assertion values."""
     # The assertions are analytic (rho = -n e inside the plasma); no fixture needed.
@@ -527,7 +613,7 @@ def cap_uniform_rho():
 
 ALL = dict(push=cap_push, gather=cap_gather, deposit=cap_deposit, grid_setup=cap_grid_setup,
            spectral=cap_spectral, cycle=cap_cycle, bunch=cap_bunch, lwfa=cap_lwfa,
-           galilean=cap_galilean)
+           galilean=cap_galilean, crossdep=cap_crossdep)
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(ALL)

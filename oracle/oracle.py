@@ -181,6 +181,23 @@ def correct_currents_curlfree_comoving(rho_prev, rho_next, Jp, Jm, Jz, kz, kr, i
         _f64(inv_k2), _c128(j_corr_coef), _c128(T_eb), _c128(T_cc), c_i(Nz), c_i(Nr))
 
 
+def correct_currents_crossdeposition(rho_prev, rho_next, rho_next_z, rho_next_xy, Jp, Jm, Jz,
+                                     kz, kr, inv_dt):
+    Nz, Nr = Jp.shape
+    lib().orc_correct_currents_crossdeposition(
+        _c128(rho_prev), _c128(rho_next), _c128(rho_next_z), _c128(rho_next_xy), _c128(Jp),
+        _c128(Jm), _c128(Jz), _f64(kz), _f64(kr), c_d(inv_dt), c_i(Nz), c_i(Nr))
+
+
+def correct_currents_crossdeposition_comoving(rho_prev, rho_next, rho_next_z, rho_next_xy,
+                                              Jp, Jm, Jz, kz, kr, j_corr_coef, T_eb, T_cc):
+    Nz, Nr = Jp.shape
+    lib().orc_correct_currents_crossdeposition_comoving(
+        _c128(rho_prev), _c128(rho_next), _c128(rho_next_z), _c128(rho_next_xy), _c128(Jp),
+        _c128(Jm), _c128(Jz), _f64(kz), _f64(kr), _c128(j_corr_coef), _c128(T_eb), _c128(T_cc),
+        c_i(Nz), c_i(Nr))
+
+
 def push_eb_comoving(Ep, Em, Ez, Bp, Bm, Bz, Jp, Jm, Jz, rho_prev, rho_next,
                      rho_prev_coef, rho_next_coef, j_coef, C, S_w, T_eb, T_cc, T_rho, kr, kz,
                      dt, V, use_true_rho):
@@ -260,11 +277,13 @@ class OracleSim:
     """
 
     def __init__(self, Nz, Nr, Nm, zmin, zmax, rmax, dt, shape, tables, species,
-                 nthreads=1, filter_currents=True, v_comoving=None, use_galilean=False):
+                 nthreads=1, filter_currents=True, v_comoving=None, use_galilean=False,
+                 current_correction='curl-free'):
         # Galilean / comoving-current PSATD (main.py:269-273, 496-497, 524-525): tables then
         # also hold T_eb, T_cc, T_rho, j_corr_coef and complex source coefficients
         self.v_comoving = v_comoving
         self.use_galilean = bool(use_galilean) if v_comoving is not None else False
+        self.current_correction = current_correction
         self.Nz, self.Nr, self.Nm = Nz, Nr, Nm
         self.zmin, self.zmax, self.rmax = zmin, zmax, rmax
         self.dz = (zmax - zmin) / Nz
@@ -280,6 +299,10 @@ class OracleSim:
         z = lambda: np.zeros((Nz, Nr), dtype=np.complex128)  # noqa: E731
         self.interp = [{k: z() for k in INTERP} for _ in range(Nm)]
         self.spect = [{k: z() for k in SPECT} for _ in range(Nm)]
+        if current_correction == 'cross-deposition':      # spectral_grid.py:97-99
+            for sp in self.spect:
+                sp['rho_next_z'] = z()
+                sp['rho_next_xy'] = z()
         self.species = species
         for s in species:
             n = s['x'].size
@@ -375,6 +398,27 @@ class OracleSim:
         self.zmin += self.v_comoving * dt
         self.zmax += self.v_comoving * dt
 
+    def cross_deposit(self):
+        """main.py:672-716, called with the particles at t = n+1/2: deposit the charge at
+        (z[n], x[n+1]) and at (z[n+1], x[n]), then come back to n+1/2."""
+        dt = self.dt
+
+        def push(frac, px, py, pz):
+            for s in self.species:
+                push_x(s['x'], s['y'], s['z'], s['ux'], s['uy'], s['uz'], s['inv_gamma'],
+                       frac * dt, px, py, pz)
+        push(0.5, 1., 1., -1.)
+        if self.use_galilean:
+            self.shift_galilean_boundaries(-0.5 * dt)
+        self.deposit('rho_next_xy')
+        push(1., -1., -1., 1.)
+        if self.use_galilean:
+            self.shift_galilean_boundaries(dt)
+        self.deposit('rho_next_z')
+        push(0.5, 1., 1., -1.)
+        if self.use_galilean:
+            self.shift_galilean_boundaries(-0.5 * dt)
+
     def step(self, N=1, correct_currents=True, use_true_rho=False):
         dt = self.dt
         self.interp2spect('E')
@@ -396,13 +440,28 @@ class OracleSim:
             if self.use_galilean:
                 self.shift_galilean_boundaries(0.5 * dt)
             self.deposit('J')
+            cross = correct_currents and self.current_correction == 'cross-deposition'
+            if cross:
+                self.cross_deposit()
             for s in self.species:
                 push_x(s['x'], s['y'], s['z'], s['ux'], s['uy'], s['uz'], s['inv_gamma'], 0.5 * dt)
             if self.use_galilean:
                 self.shift_galilean_boundaries(0.5 * dt)
             self.deposit('rho_next')
             V = self.v_comoving
-            if correct_currents:
+            if cross:
+                for m in range(self.Nm):
+                    sp, t = self.spect[m], self.t[m]
+                    if V is None:
+                        correct_currents_crossdeposition(
+                            sp['rho_prev'], sp['rho_next'], sp['rho_next_z'], sp['rho_next_xy'],
+                            sp['Jp'], sp['Jm'], sp['Jz'], t['kz'], t['kr'], 1. / dt)
+                    else:
+                        correct_currents_crossdeposition_comoving(
+                            sp['rho_prev'], sp['rho_next'], sp['rho_next_z'], sp['rho_next_xy'],
+                            sp['Jp'], sp['Jm'], sp['Jz'], t['kz'], t['kr'], t['j_corr_coef'],
+                            t['T_eb'], t['T_cc'])
+            elif correct_currents:
                 for m in range(self.Nm):
                     sp, t = self.spect[m], self.t[m]
                     if V is None:
@@ -478,7 +537,8 @@ def from_sim(sim, nthreads=1):
     o = OracleSim(fld.Nz, fld.Nr, fld.Nm, g0.zmin, g0.zmax, fld.rmax, sim.dt,
                   sim.particle_shape, tables_from_sim(sim), species, nthreads=nthreads,
                   filter_currents=sim.filter_currents, v_comoving=sim.v_comoving,
-                  use_galilean=sim.use_galilean)
+                  use_galilean=sim.use_galilean,
+                  current_correction=fld.current_correction)
     for m in range(fld.Nm):
         for k in INTERP:
             o.interp[m][k][:] = getattr(fld.interp[m], k)

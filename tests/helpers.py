@@ -43,8 +43,11 @@ def build_from_golden(g, name):
     n_order = int(g['n_order']) if 'n_order' in g.files else -1
     shape = str(g['shape']) if 'shape' in g.files else ('linear' if 'linear' in name or 'lin' in name else 'cubic')
     extra = {}
-    if 'v_comoving' in g.files:          # Galilean / comoving-current PSATD
+    if 'v_comoving' in g.files and np.isfinite(float(g['v_comoving'])):
+        # Galilean / comoving-current PSATD
         extra = dict(v_comoving=float(g['v_comoving']), use_galilean=bool(g['use_galilean']))
+    if 'cross' in name:                  # cross-deposition current correction
+        extra['current_correction'] = 'cross-deposition'
     sim = Simulation(Nz, float(g['zmax']), Nr, float(g['rmax']), Nm, float(g['dt']), zmin=zmin,
                      n_order=n_order, particle_shape=shape,
                      n_guard=(None if n_order == -1 else 8), **extra)

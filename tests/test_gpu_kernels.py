@@ -599,6 +599,39 @@ def test_comoving_spectral_kernels_vs_golden(hip, tag):
             assert np.all(host(slab[:, 11, :]) == 0)
 
 
+@pytest.mark.parametrize('tag', ['std', 'gal', 'com'])
+def test_crossdeposition_kernels_vs_golden(hip, tag):
+    """fb_correct_currents_crossdeposition_{standard,comoving} against the reference's numba
+    kernels (numba_methods.py:87-116, 243-275), on slab views."""
+    g = golden('crossdep_kernels')
+    Nz, Nr, Nm = int(g['Nz']), int(g['Nr']), int(g['Nm'])
+    names = ['rho_prev', 'rho_next', 'rho_next_z', 'rho_next_xy', 'Jp', 'Jm', 'Jz']
+    t = hip.torch()
+    p = hip.ptr
+    for m in range(Nm):
+        kz, kr = (dev(hip, np.ascontiguousarray(g['%s_%s_m%d' % (tag, k, m)], dtype=np.float64))
+                  for k in ('kz', 'kr'))
+        slab = t.zeros((Nz, 8, Nr), dtype=t.complex128, device='cuda')
+        for i, k in enumerate(names):
+            slab[:, i, :] = dev(hip, g['%s_in_%s_m%d' % (tag, k, m)])
+        a = {k: slab[:, i, :] for i, k in enumerate(names)}
+        if tag == 'std':
+            hip.check(hip.lib().fb_correct_currents_crossdeposition_standard(
+                *[p(a[k]) for k in names], 8 * Nr, p(kz), p(kr), 1. / float(g['dt']), Nz, Nr,
+                hip.stream()), 'cross std')
+        else:
+            tb = {k: dev(hip, np.ascontiguousarray(g['%s_%s_m%d' % (tag, k, m)], dtype=np.complex128))
+                  for k in ('j_corr_coef', 'T_eb', 'T_cc')}
+            hip.check(hip.lib().fb_correct_currents_crossdeposition_comoving(
+                *[p(a[k]) for k in names], 8 * Nr, p(kz), p(kr), p(tb['j_corr_coef']),
+                p(tb['T_eb']), p(tb['T_cc']), Nz, Nr, hip.stream()), 'cross comoving')
+        for k in ('Jp', 'Jm', 'Jz'):
+            assert rel_err(host(a[k]), g['%s_cc_%s_m%d' % (tag, k, m)]) < TOL, (m, k)
+        for i, k in enumerate(names[:4]):       # the charge densities are read-only
+            assert np.array_equal(host(a[k]), g['%s_in_%s_m%d' % (tag, k, m)]), k
+        assert np.all(host(slab[:, 7, :]) == 0)
+
+
 @pytest.mark.parametrize('shape', ['linear', 'cubic'])
 def test_gather_push_fused_is_bit_identical_to_sequence(hip, shape):
     """fb_gather_push == fb_gather -> fb_push_p -> fb_push_x (same arithmetic, same bits)."""

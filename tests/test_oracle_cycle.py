@@ -78,3 +78,23 @@ def test_oracle_galilean_cycle_vs_reference(oracle, name):
         done = upto
         _check(o, g, 's%d' % upto, tol)
         assert abs(o.zmin - float(g['s%d_zmin' % upto])) <= 1e-15 * abs(float(g['zmax']))
+
+
+CROSS = ['cycle_cross_lin_16x8', 'cycle_cross_cub_16x8', 'cycle_cross_galilean_cub_16x8']
+
+
+@pytest.mark.parametrize('name', CROSS)
+def test_oracle_crossdeposition_cycle_vs_reference(oracle, name):
+    """current_correction='cross-deposition' (main.py:512-514, 672-716):
+    plasma wave with the standard PSATD (linear, cubic) and a Galilean drifting plasma."""
+    g = golden(name)
+    sim = helpers.build_from_golden(g, name)
+    assert sim.fld.current_correction == 'cross-deposition'
+    o = oracle.from_sim(sim, nthreads=1)
+    done = 0
+    # (the correction divides by kz and kr: round-off a few times that of the curl-free runs)
+    for upto, tol in ((1, 5e-13), (2, 2e-12), (5, 2e-11)):
+        o.step(upto - done)
+        done = upto
+        _check(o, g, 's%d' % upto, tol)
+        assert abs(o.zmin - float(g['s%d_zmin' % upto])) <= 1e-15 * abs(float(g['zmax']))
