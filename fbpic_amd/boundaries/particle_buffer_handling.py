@@ -22,11 +22,34 @@ def exchange_particles_between_ranks(comm, species, fld, time):
     zbox_min = g0.zmin + ng * g0.dz
     zbox_max = g0.zmax - ng * g0.dz
     z = species.z
-    sel_l = z < zbox_min
-    sel_r = z > zbox_max
-    stay = ~(sel_l | sel_r)
-    arrs = [getattr(species, k) for k in _STATE]
     dev = z.device
+    cut = (z.is_cuda and comm.left_proc is not None and comm.right_proc is not None
+           and getattr(species, 'use_bin_sort', False) and species.Ntot > 0)
+    if cut:
+        # Device path between two neighbours, as the reference's GPU path
+        # (particle_buffer_handling.py:177-236): the particles are cell-sorted, so the ones in
+        # the guard cells are the two ends of the arrays - cut at two prefix-sum offsets (one
+        # host read) instead of building three boolean selections of every attribute.  (Cell
+        # based: a particle changes owner half a cell later than with the z comparison of the
+        # reference's CPU path, which the ranks next to an open end keep using.)
+        if not species.sorted:
+            species.sort_particles(fld=fld)
+            species.sorted = True
+        Nz, Nr = fld.Nz, fld.Nr
+        iz_min = max(ng + species.prefix_sum_shift, 0)
+        iz_max = min(Nz - ng + species.prefix_sum_shift + 1, Nz)
+        ps = species.prefix_sum
+        ends = t.stack((ps[max(iz_min * (Nr + 1) - 1, 0)], ps[iz_max * (Nr + 1) - 1])).tolist()
+        i_min = int(ends[0]) if iz_min * (Nr + 1) - 1 >= 0 else 0
+        i_max = int(ends[1])
+        sel_l, sel_r, stay = slice(0, i_min), slice(i_max, species.Ntot), slice(i_min, i_max)
+        nothing_leaves = (i_min == 0 and i_max == species.Ntot)
+    else:
+        sel_l = z < zbox_min
+        sel_r = z > zbox_max
+        stay = ~(sel_l | sel_r)
+        nothing_leaves = False
+    arrs = [getattr(species, k) for k in _STATE]
 
     def pack(sel, proc):
         if proc is None:
@@ -57,6 +80,8 @@ def exchange_particles_between_ranks(comm, species, fld, time):
         recv_r[2] += Ltot
     if comm.left_proc == comm.size - 1 and n_rl:
         recv_l[2] -= Ltot
+    if nothing_leaves and n_rl == 0 and n_rr == 0:
+        return                       # nobody crossed a boundary: arrays (and their sort) stay
     for i, k in enumerate(_STATE):
         setattr(species, k, t.cat((recv_l[i], arrs[i][stay], recv_r[i])).contiguous())
     species.Ntot = int(species.x.shape[0])
