@@ -52,6 +52,8 @@ _SIGNATURES = {
     'fb_push_rho': (I, [P, P, L, I, I, P]),
     'fb_rt_to_pm': (I, [I, _PP, _PP, _PP, _PP, L, I, I, P]),
     'fb_pm_to_rt': (I, [I, _PP, _PP, _PP, _PP, L, I, I, P]),
+    'fb_guard_buffers': (I, [I, P, L, L, I, I, I, P, P, P]),
+    'fb_damp_rows': (I, [P, L, L, P, I, P, I, I, P]),
     'fb_shift_spect': (I, [I, _PP, L, P, I, I, I, P]),
     'fb_scale': (I, [I, _PP, L, D, I, I, P]),
     'fb_fft_plan_create': (I, [I, L, L, L, I, _PP]),
@@ -130,7 +132,8 @@ def stream():
 
 
 def ptr(t):
-    return t.data_ptr()
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
 
 
 def ptr_array(tensors):

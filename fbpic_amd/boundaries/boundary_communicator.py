@@ -106,6 +106,7 @@ class BoundaryCommunicator(object):
                 self.right_damp = self.generate_damp_array(self.n_guard, self.nz_damp, self.n_inject)
         self.d_left_damp = None
         self.d_right_damp = None
+        self._guard_bufs = {}
 
     # ---------------------------------------------------------------- decomposition
     def divide_into_domain(self):
@@ -191,6 +192,21 @@ class BoundaryCommunicator(object):
             # E and B of all modes are the first 6*Nm fields of the z-major slab: one
             # multiplication per end instead of 6*Nm
             slab = owner.d_interp[:, 0:6 * owner.Nm, :]
+        if slab is not None:
+            # one launch for both ends (cuda_damp_EB_left / cuda_damp_EB_right)
+            dev = interp[0].Er.device
+            if self.left_proc is None and self.d_left_damp is None:
+                self.d_left_damp = t.as_tensor(self.left_damp, device=dev)
+            if self.right_proc is None and self.d_right_damp is None:
+                self.d_right_damp = t.as_tensor(self.right_damp[::-1].copy(), device=dev)
+            dl = self.d_left_damp if self.left_proc is None else None
+            dr = self.d_right_damp if self.right_proc is None else None
+            rc = _capi.lib().fb_damp_rows(
+                _capi.ptr(slab), owner.d_interp.stride(0), slab.shape[1] * slab.shape[2],
+                _capi.ptr(dl), 0 if dl is None else dl.shape[0],
+                _capi.ptr(dr), 0 if dr is None else dr.shape[0], slab.shape[0], _capi.stream())
+            _capi.check(rc, 'fb_damp_rows')
+            return
         if self.left_proc is None:
             if self.d_left_damp is None:
                 self.d_left_damp = t.as_tensor(self.left_damp, device=interp[0].Er.device)
@@ -236,15 +252,31 @@ class BoundaryCommunicator(object):
         else:
             raise ValueError('Unknown method: %s' % method)
         owner = getattr(interp[0], '_owner', None)
+        has_l, has_r = self.left_proc is not None, self.right_proc is not None
         if owner is not None and owner.data_is_on_gpu and len(interp) == owner.Nm:
-            # z-major slab: the whole group (all modes and components) is one strided
-            # block slab[z0:z1, f0:f0+nf, :] -> one copy to pack, one to unpack
+            # z-major slab: the whole group (all modes and components) is `nf * Nr` adjacent
+            # values of every z row -> ONE launch packs both message buffers, one unpacks them
+            # (the reference's copy_*_to_gpu_buffer / replace_* / add_*_from_gpu_buffer)
             f0, _, nf, _ = owner._group('rho_prev' if fldtype == 'rho' else fldtype)
             region = owner.d_interp[:, f0:f0 + nf, :]
-            targets = [region]
-        else:
-            targets = [getattr(g, k) for g in interp for k in names]
-        has_l, has_r = self.left_proc is not None, self.right_proc is not None
+            nrows, ncontig = s_l.stop - s_l.start, nf * region.shape[2]
+            key = (fldtype, method, nrows, ncontig)
+            bufs = self._guard_bufs.get(key)
+            if bufs is None:        # persistent message buffers: stable addresses for RCCL
+                bufs = [t.empty((nrows, ncontig), dtype=t.complex128, device=region.device)
+                        if side else None for side in (has_l, has_r, has_l, has_r)]
+                self._guard_bufs[key] = bufs
+            send_l, send_r, recv_l, recv_r = bufs
+            lib, p, st = _capi.lib(), _capi.ptr, _capi.stream()
+            rs = owner.d_interp.stride(0)
+            _capi.check(lib.fb_guard_buffers(0, p(region), rs, ncontig, s_l.start, s_r.start, nrows,
+                                             p(send_l), p(send_r), st), 'fb_guard_buffers')
+            self.exchange_domains(send_l, send_r, recv_l, recv_r)
+            _capi.check(lib.fb_guard_buffers(1 if method == 'replace' else 2, p(region), rs, ncontig,
+                                             d_l.start, d_r.start, nrows, p(recv_l), p(recv_r), st),
+                        'fb_guard_buffers')
+            return
+        targets = [getattr(g, k) for g in interp for k in names]
         send_l = t.stack([a[s_l] for a in targets]).contiguous() if has_l else None
         send_r = t.stack([a[s_r] for a in targets]).contiguous() if has_r else None
         recv_l = t.empty_like(send_l) if has_l else None

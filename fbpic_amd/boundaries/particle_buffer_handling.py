@@ -15,8 +15,30 @@ _STATE = ('x', 'y', 'z', 'ux', 'uy', 'uz', 'inv_gamma', 'w')     # reference buf
 _FIELDS = ('Ex', 'Ey', 'Ez', 'Bx', 'By', 'Bz')
 
 
+_PRIMED = set()
+
+
+def _prime_device_ops(t, dev):
+    """Run the tensor operations of the hand-over once on a few dummy values.  The device code
+    of an operation is loaded the first time it runs (tens of ms); without this, that cost
+    lands on the first step in which a particle really crosses a boundary - typically
+    `exchange_period` steps into a run - instead of on the first (warm-up) step."""
+    if dev in _PRIMED or dev.type != 'cuda':
+        return
+    _PRIMED.add(dev)
+    a = t.arange(16, dtype=t.float64, device=dev)
+    b = t.stack([a[2:5], a[3:6]]).contiguous()
+    c = t.cat((b[0], a[1:9], b[1])).contiguous()
+    b[1] += 1.
+    m = a > 3.
+    t.cat((a[m], c[~m[:14]])).sum().item()
+    t.zeros(4, dtype=t.float64, device=dev)
+    t.tensor([3], dtype=t.int64, device=dev).item()
+
+
 def exchange_particles_between_ranks(comm, species, fld, time):
     t = _capi.torch()
+    _prime_device_ops(t, species.z.device)
     g0 = fld.interp[0]
     ng = comm.n_guard
     zbox_min = g0.zmin + ng * g0.dz

@@ -573,3 +573,74 @@ extern "C" int fb_shift_spect(int nf, void *const *ptrs, long rs, const void *sh
                        rs, (const cplx *)shift, n_move, Nz, Nr);
     FB_CHECK_LAUNCH("fb_shift_spect");
 }
+
+// ---- guard-cell buffers of the z-domain decomposition ------------------------------------
+// boundaries/cuda_methods.py:12-195 (copy_*_to_gpu_buffer), :197-372 (replace_*_from_gpu_buffer),
+// :374-484 (add_*_from_gpu_buffer): one launch moves the `nrows` slab rows next to BOTH z ends
+// between the slab and two contiguous message buffers.  A field group (all modes and
+// components) is `ncontig` adjacent complex values of every z row of the z-major slab.
+// MODE 0: slab -> buffers, 1: buffers replace slab, 2: buffers add to slab.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_guard_buffers(cplx *__restrict__ slab, long rs, long ncontig,
+        int z_left, int z_right, int nrows, cplx *__restrict__ buf_l, cplx *__restrict__ buf_r)
+{
+    const long per_side = (long)nrows * ncontig;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * per_side; i += stride) {
+        const bool right = i >= per_side;
+        cplx *buf = right ? buf_r : buf_l;
+        if (buf == nullptr) continue;
+        const long j = right ? i - per_side : i;
+        const long row = j / ncontig, col = j - row * ncontig;
+        cplx *g = slab + ((right ? z_right : z_left) + row) * rs + col;
+        if (MODE == 0) st(buf + j, ld(g));
+        else if (MODE == 1) st(g, ld(buf + j));
+        else st(g, cadd(ld(g), ld(buf + j)));
+    }
+}
+
+// boundaries/cuda_methods.py:486-640 (cuda_damp_EB_left / _right): rows [0, nd_l) of the group
+// are multiplied by damp_l[iz], rows [Nz - nd_r, Nz) by damp_r[iz - (Nz - nd_r)].
+__global__ __launch_bounds__(256) void k_damp_rows(cplx *__restrict__ slab, long rs, long ncontig,
+        const double *__restrict__ damp_l, int nd_l, const double *__restrict__ damp_r, int nd_r,
+        int Nz)
+{
+    const long total = (long)(nd_l + nd_r) * ncontig;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const long row = i / ncontig, col = i - row * ncontig;
+        const bool right = row >= nd_l;
+        const long iz = right ? (Nz - nd_r) + (row - nd_l) : row;
+        const double d = right ? damp_r[row - nd_l] : damp_l[row];
+        cplx *g = slab + iz * rs + col;
+        st(g, rmul(d, ld(g)));
+    }
+}
+
+extern "C" int fb_guard_buffers(int mode, void *slab, long row_stride, long ncontig, int z_left,
+        int z_right, int nrows, void *buf_left, void *buf_right, void *stream)
+{
+    if (mode < 0 || mode > 2) { set_error("fb_guard_buffers", "mode must be 0, 1 or 2"); return -1; }
+    if (nrows <= 0 || ncontig <= 0 || (buf_left == nullptr && buf_right == nullptr)) return 0;
+    const dim3 grid(stream_grid(2L * nrows * ncontig)), block(256);
+#define FB_GUARD_LAUNCH(M)                                                                      \
+    hipLaunchKernelGGL(k_guard_buffers<M>, grid, block, 0, (hipStream_t)stream, (cplx *)slab,      \
+                       row_stride, ncontig, z_left, z_right, nrows, (cplx *)buf_left, (cplx *)buf_right)
+    if (mode == 0) FB_GUARD_LAUNCH(0);
+    else if (mode == 1) FB_GUARD_LAUNCH(1);
+    else FB_GUARD_LAUNCH(2);
+#undef FB_GUARD_LAUNCH
+    FB_CHECK_LAUNCH("fb_guard_buffers");
+}
+
+extern "C" int fb_damp_rows(void *slab, long row_stride, long ncontig, const double *damp_left,
+        int nd_left, const double *damp_right, int nd_right, int Nz, void *stream)
+{
+    if (damp_left == nullptr) nd_left = 0;
+    if (damp_right == nullptr) nd_right = 0;
+    if (nd_left + nd_right <= 0 || ncontig <= 0) return 0;
+    hipLaunchKernelGGL(k_damp_rows, dim3(stream_grid((long)(nd_left + nd_right) * ncontig)), dim3(256),
+                       0, (hipStream_t)stream, (cplx *)slab, row_stride, ncontig, damp_left, nd_left,
+                       damp_right, nd_right, Nz);
+    FB_CHECK_LAUNCH("fb_damp_rows");
+}

@@ -283,6 +283,23 @@ int fb_scale(int nfields, void *const *ptrs, long row_stride, double factor,
 int fb_shift_spect(int nfields, void *const *ptrs, long row_stride, const void *shift,
                    int n_move, int Nz, int Nr, void *stream);
 
+/* ---- guard cells of the z-domain decomposition ------------------------------------- */
+/* boundaries/field_buffer_handling.py:114-470 -> boundaries/cuda_methods.py:12-195
+ * (copy_{vec,scal}_to_gpu_buffer), :197-372 (replace_*_from_gpu_buffer), :374-484
+ * (add_*_from_gpu_buffer), all modes and components and both z ends in ONE launch.
+ * slab: first element of the field group in row 0 of a z-major slab (row_stride complex
+ * elements between z rows; `ncontig` = n_fields * Nr adjacent complex values per row).
+ * Rows [z_left, z_left + nrows) <-> buf_left, rows [z_right, z_right + nrows) <-> buf_right
+ * (contiguous complex128[nrows * ncontig]; NULL = no neighbour on that side).
+ * mode 0: slab -> buffers; 1: buffers replace the slab rows; 2: buffers are added. */
+int fb_guard_buffers(int mode, void *slab, long row_stride, long ncontig, int z_left,
+                     int z_right, int nrows, void *buf_left, void *buf_right, void *stream);
+/* boundaries/boundary_communicator.py:828-907 -> cuda_damp_EB_left / cuda_damp_EB_right
+ * (boundaries/cuda_methods.py:486-640): rows [0, nd_left) *= damp_left[iz], rows
+ * [Nz - nd_right, Nz) *= damp_right[iz - (Nz - nd_right)] (NULL = open end elsewhere). */
+int fb_damp_rows(void *slab, long row_stride, long ncontig, const double *damp_left, int nd_left,
+                 const double *damp_right, int nd_right, int Nz, void *stream);
+
 /* ---- FFT along z (rocFFT) --------------------------------------------------------- */
 /* fields/spectral_transform/fourier.py:78 (cufft Plan1d) and :116-160.
  * One plan transforms `ncols` columns at once: element (iz, col) lives at

@@ -800,3 +800,60 @@ def test_push_x_folded_into_sort(hip, oracle, preranked):
     # the inputs are untouched
     for a, b in zip((x, y, z), src[:3]):
         assert np.array_equal(host(b), a)
+
+
+def test_guard_buffers_and_damping(hip):
+    """fb_guard_buffers (pack / replace / add of the guard rows of a field group, both z ends
+    in one launch; boundaries/cuda_methods.py:12-484) and fb_damp_rows (:486-640) against
+    NumPy slicing on a padded z-major slab."""
+    t = hip.torch()
+    p = hip.ptr
+    rng = np.random.default_rng(77)
+    Nz, NF, Nr, f0, nf, ng = 40, 7, 9, 2, 3, 4
+    rs = NF * Nr + 8
+    base = t.zeros(Nz * rs, dtype=t.complex128, device='cuda')
+    slab = base.as_strided((Nz, NF, Nr), (rs, Nr, 1))
+    h = rng.normal(size=(Nz, NF, Nr)) + 1j * rng.normal(size=(Nz, NF, Nr))
+    slab.copy_(t.from_numpy(h))
+    region = slab[:, f0:f0 + nf, :]
+    ncontig = nf * Nr
+    for nrows, zl, zr in ((ng, ng, Nz - 2 * ng), (2 * ng, 0, Nz - 2 * ng)):
+        bl = t.empty((nrows, ncontig), dtype=t.complex128, device='cuda')
+        br = t.empty_like(bl)
+        hip.check(hip.lib().fb_guard_buffers(0, p(region), rs, ncontig, zl, zr, nrows, p(bl), p(br),
+                                             hip.stream()), 'pack')
+        assert np.array_equal(host(bl), h[zl:zl + nrows, f0:f0 + nf].reshape(nrows, ncontig))
+        assert np.array_equal(host(br), h[zr:zr + nrows, f0:f0 + nf].reshape(nrows, ncontig))
+        # one-sided (open end on the left): only the right buffer is written
+        bl.zero_()
+        hip.check(hip.lib().fb_guard_buffers(0, p(region), rs, ncontig, zl, zr, nrows, None, p(br),
+                                             hip.stream()), 'pack right only')
+        assert np.all(host(bl) == 0)
+    # unpack: replace the outer ng rows, then add onto 2 ng rows
+    inc_l = rng.normal(size=(2 * ng, ncontig)) + 1j * rng.normal(size=(2 * ng, ncontig))
+    inc_r = rng.normal(size=(2 * ng, ncontig)) + 1j * rng.normal(size=(2 * ng, ncontig))
+    dl, dr = dev(hip, inc_l), dev(hip, inc_r)
+    hip.check(hip.lib().fb_guard_buffers(1, p(region), rs, ncontig, 0, Nz - ng, ng, p(dl), p(dr),
+                                         hip.stream()), 'replace')
+    exp = h.copy()
+    exp[:ng, f0:f0 + nf] = inc_l[:ng].reshape(ng, nf, Nr)
+    exp[Nz - ng:, f0:f0 + nf] = inc_r[:ng].reshape(ng, nf, Nr)
+    assert np.array_equal(host(slab), exp)
+    hip.check(hip.lib().fb_guard_buffers(2, p(region), rs, ncontig, 0, Nz - 2 * ng, 2 * ng, p(dl),
+                                         p(dr), hip.stream()), 'add')
+    exp[:2 * ng, f0:f0 + nf] += inc_l.reshape(2 * ng, nf, Nr)
+    exp[Nz - 2 * ng:, f0:f0 + nf] += inc_r.reshape(2 * ng, nf, Nr)
+    assert np.array_equal(host(slab), exp)
+    assert np.all(host(base.as_strided((Nz, 8), (rs, 1), NF * Nr)) == 0)       # row padding untouched
+    # damping of both ends / of one end
+    damp_l, damp_r = rng.uniform(size=6), rng.uniform(size=5)
+    d_damp_l, d_damp_r = dev(hip, damp_l), dev(hip, damp_r)
+    hip.check(hip.lib().fb_damp_rows(p(region), rs, ncontig, p(d_damp_l), 6, p(d_damp_r), 5, Nz,
+                                     hip.stream()), 'damp')
+    exp[:6, f0:f0 + nf] *= damp_l[:, None, None]
+    exp[Nz - 5:, f0:f0 + nf] *= damp_r[:, None, None]
+    assert np.array_equal(host(slab), exp)
+    hip.check(hip.lib().fb_damp_rows(p(region), rs, ncontig, None, 0, p(d_damp_r), 5, Nz,
+                                     hip.stream()), 'damp right')
+    exp[Nz - 5:, f0:f0 + nf] *= damp_r[:, None, None]
+    assert np.array_equal(host(slab), exp)
