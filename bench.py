@@ -140,7 +140,7 @@ def main():
         kern = None
         if not args.no_kernel_timing:
             _capi.enable_timing()
-            sim.step(3)
+            sim.step(10)     # enough launches for a stable mean (durations vary ~15% per step)
             kern = _capi.collect_timing()
     if world > 1:
         tt = torch.tensor([dt_wall], dtype=torch.float64,

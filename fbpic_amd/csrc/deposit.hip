@@ -607,7 +607,7 @@ extern "C" int fb_deposit_J_rank_next(int shape, int Nm, long n, const double *x
         double invdr, double rmin, int Nr, void *const *J, long row_stride, long col_stride,
         const double *ruyten_m0, const double *ruyten_mh, unsigned long long *nflush,
         double dt_push, double x_push, double y_push, double z_push, int ncell,
-        void *sort_workspace, size_t workspace_bytes, void *stream)
+        void *sort_workspace, size_t workspace_bytes, int counts_are_zero, void *stream)
 {
     hipStream_t s = (hipStream_t)stream;
     if (ncell != Nz * (Nr + 1)) { set_error("fb_deposit_J_rank_next", "ncell != Nz*(Nr+1)"); return -1; }
@@ -616,8 +616,10 @@ extern "C" int fb_deposit_J_rank_next(int shape, int Nm, long n, const double *x
         return -1;
     }
     const BinSortWs W = carve_bin_sort_ws(sort_workspace, workspace_bytes, n, ncell);
-    hipError_t e = hipMemsetAsync(W.count, 0, (size_t)ncell * sizeof(int), s);
-    if (e != hipSuccess) return check(e, "fb_deposit_J_rank_next(memset)");
+    if (!counts_are_zero) {
+        hipError_t e = hipMemsetAsync(W.count, 0, (size_t)ncell * sizeof(int), s);
+        if (e != hipSuccess) return check(e, "fb_deposit_J_rank_next(memset)");
+    }
     if (n <= 0) return 0;
     // fbpic/particles/push/numba_methods.py:24-30: chdt = c * dt
     const RankNext RK = {c * dt_push, x_push, y_push, z_push, W.cell, W.rank, W.count};

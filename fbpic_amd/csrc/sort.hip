@@ -138,9 +138,13 @@ __global__ __launch_bounds__(256) void k_bin_rank(long n, const double *__restri
 template <bool PUSH>
 __global__ __launch_bounds__(256) void k_scatter(long n, const int *__restrict__ cell,
         const int *__restrict__ rank, const int *__restrict__ prefix, int nattr, CPtrs16 src,
-        Ptrs16 dst, PushX P, int *__restrict__ cell_sorted, int *__restrict__ sorted_idx)
+        Ptrs16 dst, PushX P, int *__restrict__ cell_sorted, int *__restrict__ sorted_idx,
+        int *__restrict__ count, int ncell)
 {
     long stride = (long)gridDim.x * blockDim.x;
+    // the per-cell counters have been consumed by the scan: leave them zeroed for the next
+    // rank pass (saves its memset launch)
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < ncell; i += stride) count[i] = 0;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const int c = cell[i];
         const int d = (c > 0 ? prefix[c - 1] : 0) + rank[i];
@@ -309,10 +313,10 @@ static int bin_sort_impl(const char *who, bool push, bool preranked, const PushX
         for (int k = 0; k < 16; k++) { a.p[k] = k < nattr ? src[k] : nullptr; b.p[k] = k < nattr ? dst[k] : nullptr; }
         if (push)
             hipLaunchKernelGGL(k_scatter<true>, dim3(stream_grid(n)), dim3(256), 0, s, n, cell, rank,
-                               prefix_sum, nattr, a, b, P, cell_idx_sorted, sorted_idx);
+                               prefix_sum, nattr, a, b, P, cell_idx_sorted, sorted_idx, count, ncell);
         else
             hipLaunchKernelGGL(k_scatter<false>, dim3(stream_grid(n)), dim3(256), 0, s, n, cell, rank,
-                               prefix_sum, nattr, a, b, P, cell_idx_sorted, sorted_idx);
+                               prefix_sum, nattr, a, b, P, cell_idx_sorted, sorted_idx, count, ncell);
     }
     FB_CHECK_LAUNCH(who);
 }

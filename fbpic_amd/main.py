@@ -3,6 +3,7 @@
 `exchange_and_damp_EB`, `add_new_species`, attributes `fld`, `ptcl`, `comm`, `time`,
 `iteration`, `diags`.  The order of operations in `step` follows main.py:346-586
 exactly; every operation is a HIP kernel launch (fbpic_amd has no CPU path)."""
+import os
 import numpy as np
 from scipy.constants import m_e, m_p, e, c
 from . import _capi
@@ -93,6 +94,8 @@ class Simulation(object):
                           use_modified_volume=use_modified_volume)
         self.grid_shape = self.fld.interp[0].Ez.shape
         self.particle_shape = particle_shape
+        # rank the particles for the next sort inside the J deposition (fb_deposit_J_rank_next)
+        self.prerank_in_deposit = os.environ.get('FBPIC_AMD_PRERANK', '1') != '0'
         self.ptcl = []
         if n_e is not None:
             self.add_new_species(q=-e, m=m_e, n=n_e, dens_func=dens_func,
@@ -204,7 +207,7 @@ class Simulation(object):
             for species in ptcl:
                 species.keep_fields_sorted = False
             cross = bool(correct_currents) and fld.current_correction == 'cross-deposition'
-            if move_positions and not self.use_galilean and not cross:
+            if move_positions and not self.use_galilean and not cross and self.prerank_in_deposit:
                 # the J deposition also ranks the particles for the sort after the push below
                 # (not with a Galilean grid: zmin moves between this deposit and that sort)
                 for species in ptcl:

@@ -100,6 +100,7 @@ class Particles(object):
         self.sorting_buffer = None
         self._alt = None
         self._sort_ws = None
+        self._counts_clean = False
         self._cell_size = None
 
     # ---------------------------------------------------------------- host <-> device
@@ -119,6 +120,7 @@ class Particles(object):
         nbytes = max(int(_capi.lib().fb_sort_workspace_bytes(n, ncell)),
                      int(_capi.lib().fb_bin_sort_workspace_bytes(n, ncell)))
         self._sort_ws = t.empty(nbytes, dtype=t.uint8, device=dev)
+        self._counts_clean = False       # per-cell counters of the workspace known to be zero
         self._nflush = t.zeros(1024, dtype=t.int64, device=dev)
         self._nflush_host = t.zeros(1024, dtype=t.int64).pin_memory()
         self._runs_after_sort = None
@@ -318,6 +320,7 @@ class Particles(object):
                     p(self.prefix_sum), p(self._sort_ws),
                     self._sort_ws.shape[0], st)
                 _capi.check(rc, 'fb_bin_sort_particles')
+            self._counts_clean = True    # the scatter pass leaves the counters zeroed
             for i, k in enumerate(names):
                 setattr(self, k, dst[i])
                 self._alt[i] = src[i]
@@ -338,6 +341,7 @@ class Particles(object):
                                  p(self._sorted_idx_alt), ctypes.byref(in_alt),
                                  p(self.prefix_sum), p(self._sort_ws), self._sort_ws.shape[0], st)
         _capi.check(rc, 'fb_sort_by_cell')
+        self._counts_clean = False       # the radix sort used the workspace as scratch
         if in_alt.value:     # the radix sort left its result in the alternate buffers
             self.cell_idx, self._cell_idx_alt = self._cell_idx_alt, self.cell_idx
             self.sorted_idx, self._sorted_idx_alt = self._sorted_idx_alt, self.sorted_idx
@@ -447,7 +451,8 @@ class Particles(object):
                     views[0].stride(0), views[0].stride(1), p(ruy0), p(ruyh),
                     p(self._nflush) if adaptive else None, hint[0], hint[1], hint[2], hint[3],
                     self.prefix_sum.shape[0], p(self._sort_ws), self._sort_ws.shape[0],
-                    _capi.stream())
+                    int(self._counts_clean), _capi.stream())
+                self._counts_clean = False
                 _capi.check(rc, 'fb_deposit_J_rank_next')
                 self._prerank = tuple(hint)
             else:

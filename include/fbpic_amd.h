@@ -129,7 +129,8 @@ int fb_bin_sort_particles(long n, int ncell, const double *x, const double *y, c
  * the reference's particle buffers, particle_buffer_handling.py:150-160).
  * preranked != 0: the cell / rank / per-cell counts in `workspace` were already produced by
  * fb_deposit_J_rank_next for exactly this push (same dt and push factors, particle arrays
- * untouched since); the sort then only scans the counts and scatters. */
+ * untouched since); the sort then only scans the counts and scatters.
+ * On return (n > 0) the per-cell counters at the head of `workspace` are zero again. */
 int fb_push_x_bin_sort_particles(long n, int ncell, const double *x, const double *y,
                                  const double *z, const double *ux, const double *uy,
                                  const double *uz, const double *inv_gamma, double c, double dt,
@@ -186,7 +187,10 @@ int fb_deposit_J(int shape, int Nm, long n,
  * every particle, the cell of the position pushed by (dt_push, x_push, y_push, z_push) and
  * its rank in that cell go to `sort_workspace` (layout of fb_bin_sort_workspace_bytes).
  * Follow with fb_push_x_bin_sort_particles(..., preranked = 1).  J itself is deposited
- * exactly as by fb_deposit_J. */
+ * exactly as by fb_deposit_J.
+ * counts_are_zero != 0: the caller guarantees that the per-cell counters at the head of
+ * `sort_workspace` are all zero - true after any completed fb_*bin_sort_particles call on this
+ * workspace (the scatter pass leaves them zeroed) - and the memset launch is skipped. */
 int fb_deposit_J_rank_next(int shape, int Nm, long n, const double *x, const double *y,
                            const double *z, const double *w, double q, const double *ux,
                            const double *uy, const double *uz, const double *inv_gamma, double c,
@@ -195,7 +199,7 @@ int fb_deposit_J_rank_next(int shape, int Nm, long n, const double *x, const dou
                            const double *ruyten_mh, unsigned long long *nflush,
                            double dt_push, double x_push, double y_push, double z_push,
                            int ncell, void *sort_workspace, size_t workspace_bytes,
-                           void *stream);
+                           int counts_are_zero, void *stream);
 
 /* ---- interpolation-grid kernels ------------------------------------------------ */
 /* fields/interpolation_grid.py:236-250 -> cuda_erase_scalar/vector (fields/cuda_methods.py:18,40).

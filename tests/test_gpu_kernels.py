@@ -780,7 +780,7 @@ def test_push_x_folded_into_sort(hip, oracle, preranked):
             hip.check(hip.lib().fb_deposit_J_rank_next(
                 shape, Nm, n, p(src[0]), p(src[1]), p(src[2]), p(src[6]), q, p(src[3]), p(src[4]),
                 p(src[5]), p(src[7]), c, *geom, hip.ptr_array(views), 3 * Nm * Nr, 1, p(ruy), p(ruy),
-                None, dt, 1., 1., 1., ncell, p(ws), nb, hip.stream()), 'deposit_J_rank_next')
+                None, dt, 1., 1., 1., ncell, p(ws), nb, 0, hip.stream()), 'deposit_J_rank_next')
             hip.check(hip.lib().fb_deposit_J(
                 shape, Nm, n, p(src[0]), p(src[1]), p(src[2]), p(src[6]), q, p(src[3]), p(src[4]),
                 p(src[5]), p(src[7]), c, *geom, hip.ptr_array(views2), 3 * Nm * Nr, 1, None, p(ruy),
@@ -797,6 +797,23 @@ def test_push_x_folded_into_sort(hip, oracle, preranked):
     assert np.array_equal(prefix, np.cumsum(np.bincount(ref, minlength=ncell)).astype(np.int32))
     for a, b in zip((xr, yr, zr, ux, uy, uz, w, ig), dst):
         assert np.array_equal(host(b), a[sidx])
+    # the scatter pass leaves the per-cell counters of the workspace zeroed ...
+    assert np.all(host(ws[:4 * ncell].view(t.int32)) == 0)
+    if preranked:
+        # ... so that the next rank pass may skip its memset (counts_are_zero = 1)
+        hip.check(hip.lib().fb_deposit_J_rank_next(
+            1, Nm, n, p(src[0]), p(src[1]), p(src[2]), p(src[6]), q, p(src[3]), p(src[4]),
+            p(src[5]), p(src[7]), c, *geom, hip.ptr_array(views), 3 * Nm * Nr, 1, p(ruy), p(ruy),
+            None, dt, 1., 1., 1., ncell, p(ws), nb, 1, hip.stream()), 'deposit_J_rank_next')
+        dst2 = [t.empty_like(b) for b in dst]
+        hip.check(hip.lib().fb_push_x_bin_sort_particles(
+            n, ncell, p(src[0]), p(src[1]), p(src[2]), p(src[3]), p(src[4]), p(src[5]), p(src[7]),
+            c, dt, 1., 1., 1., *geom, 8, hip.ptr_array(src), hip.ptr_array(dst2), p(ci), p(si), p(pre),
+            p(ws), nb, 1, hip.stream()), 'push_x_bin_sort')
+        assert np.array_equal(host(pre), prefix) and np.array_equal(host(ci), cis)
+        sidx2 = host(si)
+        for a, b in zip((xr, yr, zr, ux, uy, uz, w, ig), dst2):
+            assert np.array_equal(host(b), a[sidx2])
     # the inputs are untouched
     for a, b in zip((x, y, z), src[:3]):
         assert np.array_equal(host(b), a)
