@@ -91,6 +91,22 @@ template <bool FWD> struct Dft<3, FWD> {
         v[2] = csub(t2, t3);
     }
 };
+template <bool FWD> struct Dft<6, FWD> {
+    // 6 = 2 x 3: X[k] = E[k mod 3] + W6^k O[k mod 3], E / O = 3-point DFTs of the even / odd
+    // inputs, W6 = exp(-+ 2 pi i / 6) = (1/2, -+ h); W6^(k+3) = -W6^k
+    __device__ __forceinline__ static void run(cx *v)
+    {
+        constexpr double h = 0.86602540378443864676;
+        cx e[3] = {v[0], v[2], v[4]}, o[3] = {v[1], v[3], v[5]};
+        Dft<3, FWD>::run(e);
+        Dft<3, FWD>::run(o);
+        const cx w1 = make_double2(0.5, FWD ? -h : h), w2 = make_double2(-0.5, FWD ? -h : h);
+        const cx o1 = cmul(o[1], w1), o2 = cmul(o[2], w2);
+        v[0] = cadd(e[0], o[0]); v[3] = csub(e[0], o[0]);
+        v[1] = cadd(e[1], o1);   v[4] = csub(e[1], o1);
+        v[2] = cadd(e[2], o2);   v[5] = csub(e[2], o2);
+    }
+};
 template <bool FWD> struct Dft<9, FWD> {
     // 9 = 3 x 3 Cooley-Tukey: X[k1 + 3 k2] = sum_n2 W3^(n2 k2) W9^(n2 k1) sum_n1 W3^(n1 k1) x[3 n1 + n2]
     __device__ __forceinline__ static void run(cx *v)
@@ -143,10 +159,11 @@ typedef ZCfg<1024, 4, 256, 8, 8, 4, 4, 1> ZC1024;
 typedef ZCfg<2048, 2, 256, 8, 8, 8, 4, 1> ZC2048;
 typedef ZCfg<4096, 1, 256, 8, 8, 8, 8, 1> ZC4096;
 // 9 x 2^k (a power-of-two slab plus 2 x 64 guard cells, e.g. 1024 + 128): 4608 points per
-// 128-lane workgroup (36 per lane), radix 9 then 4 / 2
-typedef ZCfg<576, 8, 128, 9, 4, 4, 4, 1> ZC576;
-typedef ZCfg<1152, 4, 128, 9, 4, 4, 4, 2> ZC1152;
-typedef ZCfg<2304, 2, 128, 9, 4, 4, 4, 4> ZC2304;
+// 192-lane workgroup (24 per lane), radix 6, 6 then 8 / 4: four passes (measured against the
+// 128-lane radix 9, 4, 4, 4, 2 plan with 36 points per lane and five passes)
+typedef ZCfg<576, 8, 192, 6, 6, 4, 4, 1> ZC576;
+typedef ZCfg<1152, 4, 192, 6, 6, 8, 4, 1> ZC1152;
+typedef ZCfg<2304, 2, 192, 6, 6, 8, 8, 1> ZC2304;
 
 // One Stockham pass of radix R over the tile (NS = product of the previous radices):
 //   butterfly jj in [0, N/R): inputs rows jj + t N/R, twiddled by W_{NS R}^{t (jj mod NS)},
