@@ -2,6 +2,7 @@
 (tests/golden/grid_setup.npz): Hankel matrices, cell volumes, Ruyten coefficients,
 modified kz, stencil reach, PSATD coefficients, filters, inv_k2.  CPU-only."""
 import numpy as np
+import pytest
 from scipy.constants import c
 from conftest import golden, rel_err
 
@@ -75,3 +76,28 @@ def test_slab_indexing_is_a_bijection():
     for m in range(3):
         for a, b in (('Er', 'Ep'), ('Et', 'Em'), ('Ez', 'Ez'), ('Jr', 'Jp'), ('Bt', 'Bm')):
             assert f.interp_index(a, m) == f.spect_index(b, m)
+
+
+def test_slab_indexing_with_cross_deposition():
+    """current_correction='cross-deposition' adds rho_next_z / rho_next_xy of every mode to the
+    spectral slab (spectral_grid.py:97-99); the first 11 Nm slots keep their meaning."""
+    from fbpic_amd.fields.spectral_grid import SPECT_FIELDS, CROSS_FIELDS
+    Nm = 2
+    f = Fields(8, 8e-6, 4, 4e-6, Nm, 1e-15, current_correction='cross-deposition')
+    g = Fields(8, 8e-6, 4, 4e-6, Nm, 1e-15)
+    assert f.NFs == 13 * Nm and g.NFs == 11 * Nm
+    names = f.spect[0].field_names
+    assert names == SPECT_FIELDS + CROSS_FIELDS and g.spect[0].field_names == SPECT_FIELDS
+    ss = sorted(f.spect_index(k, m) for m in range(Nm) for k in names)
+    assert ss == list(range(f.NFs))
+    for m in range(Nm):
+        for k in SPECT_FIELDS:
+            assert f.spect_index(k, m) == g.spect_index(k, m)
+        assert f.spect[m].rho_next_z.shape == (8, 4) and not hasattr(g.spect[m], 'rho_next_z')
+    # transform groups: both extra densities come from the interpolation-grid rho
+    assert f._group('rho_next_z') == (9 * Nm, 11 * Nm, Nm, False)
+    assert f._group('rho_next_xy') == (9 * Nm, 12 * Nm, Nm, False)
+    with pytest.raises(ValueError):
+        g._group('rho_next_z')
+    with pytest.raises(ValueError):
+        Fields(8, 8e-6, 4, 4e-6, Nm, 1e-15, current_correction='nonsense')
