@@ -1,0 +1,137 @@
+"""Restatements of the reference's OWN physics tests for the hot path, run through the same
+public API (`Simulation`, `GpuMemoryManager`, `Particles.deposit`, `Fields.erase / ...`,
+`add_laser_pulse`, `set_moving_window`) with the reference's parameters and assertions:
+
+* tests/test_uniform_rho_deposition.py - the deposited density of a uniform plasma is uniform
+  (linear and cubic shapes, Ruyten-corrected weights), also after a small radial shift of the
+  electrons of a neutral plasma;
+* tests/test_laser.py (mode-1 case, the Gaussian pulse) - vacuum diffraction of a laser against
+  the paraxial theory in a periodic box with a time step 60x the Courant limit, in a moving
+  window with open boundaries, and on a Galilean grid at 0.999 c.
+
+(test_periodic_plasma_wave.py and test_cpu_gpu_deposition.py are restated in test_gpu_cycle.py.)
+"""
+import numpy as np
+import pytest
+from scipy.constants import c, e, m_e
+from scipy.optimize import curve_fit
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------ test_uniform_rho_deposition.py
+U = dict(Nz=250, zmax=20.e-6, Nr=50, rmax=20.e-6, Nm=2, p_nr=8, p_nz=1, p_nt=4, p_rmax=10.e-6,
+         n=9.e24, frac_shift=0.01)
+
+
+def _deposit_rho(sim):
+    from fbpic_amd.main import GpuMemoryManager
+    with GpuMemoryManager(sim):
+        sim.fld.erase('rho')
+        for species in sim.ptcl:
+            species.deposit(sim.fld, 'rho')
+        sim.fld.sum_reduce_deposition_array('rho')
+        sim.fld.divide_by_volume('rho')
+
+
+@pytest.mark.parametrize('shape', ['linear', 'cubic'])
+def test_uniform_electron_plasma(shape):
+    """test_uniform_rho_deposition.py:49-79."""
+    from fbpic_amd.main import Simulation
+    p = U
+    sim = Simulation(p['Nz'], p['zmax'], p['Nr'], p['rmax'], p['Nm'], p['zmax'] / p['Nz'] / c,
+                     0, p['zmax'], 0, p['p_rmax'], p['p_nz'], p['p_nr'], p['p_nt'], p['n'],
+                     initialize_ions=False, particle_shape=shape)
+    _deposit_rho(sim)
+    n = p['n']
+    Nrmax = int(p['Nr'] * p['p_rmax'] * 1. / p['rmax'])
+    assert np.allclose(-n * e, sim.fld.interp[0].rho[:, :Nrmax - 2], 2.e-3)
+    assert np.allclose(0, sim.fld.interp[0].rho[:, Nrmax + 2:], 1.e-10)
+    assert np.allclose(0, sim.fld.interp[1].rho[:, :], 1.e-10)
+
+
+@pytest.mark.parametrize('shape', ['linear', 'cubic'])
+def test_neutral_plasma_shifted(shape):
+    """test_uniform_rho_deposition.py:100-134."""
+    from fbpic_amd.main import Simulation
+    p = U
+    sim = Simulation(p['Nz'], p['zmax'], p['Nr'], p['rmax'], p['Nm'], p['zmax'] / p['Nz'] / c,
+                     0, p['zmax'], 0, p['p_rmax'], p['p_nz'], p['p_nr'], p['p_nt'], p['n'],
+                     initialize_ions=True, particle_shape=shape)
+    dr = p['rmax'] / p['Nr']
+    sim.ptcl[0].x += p['frac_shift'] * dr
+    _deposit_rho(sim)
+    n = p['n']
+    Nrmax = int(p['Nr'] * p['p_rmax'] * 1. / p['rmax'])
+    assert np.allclose(0, sim.fld.interp[0].rho[:, :Nrmax - 2], atol=n * e * 1.e-3)
+    assert np.allclose(0, sim.fld.interp[1].rho[:, :Nrmax - 2], atol=n * e * 1.e-3)
+    assert np.allclose(0, sim.fld.interp[0].rho[:, Nrmax + 2:], 1.e-10)
+    assert np.allclose(0, sim.fld.interp[1].rho[:, Nrmax + 2:], atol=n * e * 1.e-10)
+
+
+# ------------------------------------------------------------------------------ test_laser.py
+L = dict(Nz=400, zmin=-10.e-6, zmax=10.e-6, Nr=25, Lr=20.e-6, n_order=-1, w0=4.e-6, ctau=5.e-6,
+         k0=2 * np.pi / 0.8e-6, E0=1., L_prop=30.e-6, zf=25.e-6, N_diag=10, rtol=1.e-4)
+
+
+def _gaussian_transverse_profile(r, w, E):
+    return E * np.exp(-r**2 / w**2)
+
+
+def _fit_fields(fld, m):
+    """test_laser.py:420-452 (mode 1: Gaussian fit of the z-integrated |Er|)."""
+    dz = fld.interp[0].dz
+    laser_profile = np.sqrt(dz * (abs(fld.interp[m].Er)**2).sum(axis=0))
+    laser_profile *= 2.**(3. / 4) / (np.pi**(1. / 4) * L['ctau']**(1. / 2))
+    fit = curve_fit(_gaussian_transverse_profile, fld.interp[m].r, laser_profile,
+                    p0=np.array([L['w0'], L['E0']]))
+    fit[0][1] = 2 * fit[0][1]       # factor 2 of the modes m > 0
+    return fit[0]
+
+
+def _propagate_pulse(dt, boundaries, v_window=0, use_galilean=False, v_comoving=0):
+    """test_laser.py:130-286 for m = 1 (Nm = 2, linearly polarised Gaussian pulse)."""
+    from fbpic_amd.main import Simulation
+    from fbpic_amd.lpa_utils.laser import add_laser_pulse, GaussianLaser
+    p = L
+    m = 1
+    sim = Simulation(p['Nz'], p['zmax'], p['Nr'], p['Lr'], m + 1, dt, n_order=p['n_order'],
+                     zmin=p['zmin'], boundaries=boundaries, v_comoving=v_comoving,
+                     exchange_period=1, use_galilean=use_galilean)
+    sim.ptcl = []
+    if v_window != 0:
+        sim.set_moving_window(v=v_window)
+    z0 = (p['zmax'] + p['zmin']) / 2
+    a0 = p['E0'] * e / (m_e * c**2 * p['k0'])
+    add_laser_pulse(sim, GaussianLaser(a0=a0, waist=p['w0'], tau=p['ctau'] / c,
+                                       lambda0=2 * np.pi / p['k0'], z0=z0, zf=p['zf']))
+    N_diag = p['N_diag']
+    w, E = np.zeros(N_diag), np.zeros(N_diag)
+    Ntot_step = int(round(p['L_prop'] / (c * dt)))
+    N_step = int(round(Ntot_step / N_diag))
+    for it in range(N_diag):
+        w[it], E[it] = _fit_fields(sim.fld, m)
+        sim.step(N_step, show_progress=False)
+    z_prop = c * dt * N_step * np.arange(N_diag)
+    ZR = 0.5 * p['k0'] * p['w0']**2
+    w_analytic = p['w0'] * np.sqrt(1 + (z_prop - p['zf'])**2 / ZR**2)
+    E_analytic = p['E0'] / (1 + (z_prop - p['zf'])**2 / ZR**2)**(1. / 2)
+    assert np.allclose(w, w_analytic, rtol=p['rtol'])
+    assert np.allclose(E, E_analytic, rtol=5.e-3)
+
+
+def test_laser_periodic():
+    """test_laser.py:72-89: a very long time step checks the absence of a Courant limit."""
+    _propagate_pulse(L['L_prop'] * 1. / c / L['N_diag'], {'z': 'periodic', 'r': 'reflective'})
+
+
+def test_laser_moving_window():
+    """test_laser.py:91-108."""
+    _propagate_pulse((L['zmax'] - L['zmin']) * 1. / c / L['Nz'], {'z': 'open', 'r': 'reflective'},
+                     v_window=c)
+
+
+def test_laser_galilean():
+    """test_laser.py:110-128."""
+    _propagate_pulse(L['L_prop'] * 1. / c / L['N_diag'], {'z': 'open', 'r': 'reflective'},
+                     use_galilean=True, v_comoving=0.999 * c)
