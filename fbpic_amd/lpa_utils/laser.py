@@ -3,7 +3,9 @@ the device transforms, SURVEY.md 8f row 2.
 
 `GaussianLaser` restates the paraxial Gaussian pulse of
 fbpic/lpa_utils/laser/laser_profiles.py:179-294 (longitudinal_laser_profiles.py:156-181,
-transverse_laser_profiles.py:135-160); `add_laser_pulse(sim, profile)` restates
+transverse_laser_profiles.py:135-160), `LaguerreGaussLaser` / `DonutLikeLaguerreGaussLaser`
+the Laguerre-Gauss pulses of :296-585 (what the reference's tests/test_laser.py uses to
+exercise the modes m = 0 and m = 2); profiles add up with `+`; `add_laser_pulse(sim, profile)` restates
 fbpic/lpa_utils/laser/direct_injection.py:12-217: the transverse field is evaluated on the
 global grid and decomposed in azimuthal modes, Ez follows from div E = 0 and B from
 d_t B = -curl E in spectral space, and the result is ADDED to the local grids.
@@ -15,6 +17,8 @@ from ..fields import Fields
 
 
 class LaserProfile(object):
+    """Base class (laser_profiles.py:20-74): profiles can be summed with `+`."""
+
     def __init__(self, propagation_direction, gpu_capable=False):
         assert propagation_direction in [-1, 1]
         self.propag_direction = float(propagation_direction)
@@ -22,6 +26,23 @@ class LaserProfile(object):
 
     def E_field(self, x, y, z, t):
         raise NotImplementedError
+
+    def __add__(self, other):
+        return SummedLaserProfile(self, other)
+
+
+class SummedLaserProfile(LaserProfile):
+    """Sum of two profiles that propagate in the same direction (laser_profiles.py:77-102)."""
+
+    def __init__(self, profile1, profile2):
+        assert profile1.propag_direction == profile2.propag_direction
+        LaserProfile.__init__(self, int(profile1.propag_direction))
+        self.profile1, self.profile2 = profile1, profile2
+
+    def E_field(self, x, y, z, t):
+        Ex1, Ey1 = self.profile1.E_field(x, y, z, t)
+        Ex2, Ey2 = self.profile2.E_field(x, y, z, t)
+        return Ex1 + Ex2, Ey1 + Ey2
 
 
 class GaussianLaser(LaserProfile):
@@ -56,6 +77,78 @@ class GaussianLaser(LaserProfile):
         trans = np.exp(- (x ** 2 + y ** 2) / (self.w0 ** 2 * diffract)) / diffract
         profile = longi * trans
         return (self.E0x * profile).real, (self.E0y * profile).real
+
+
+class _LaguerreGaussPulse(LaserProfile):
+    """Paraxial Laguerre-Gauss mode (p, m) under an unchirped Gaussian temporal envelope:
+    u = A (sqrt(2) r / w(z))^|m| L_p^|m|(2 r^2 / w(z)^2) exp(-r^2 / (w0^2 q)) / q
+        x exp(-i (2p + |m|) psi) x azimuthal factor,   q = 1 + i (z - zf) / zR, psi = arg q,
+    A = sqrt(p! / (|m| + p)!) (so that the pulse energy does not depend on p and m)."""
+
+    def __init__(self, p, m, a0, waist, tau, z0, zf, theta_pol, lambda0, cep_phase,
+                 propagation_direction):
+        from scipy.special import genlaguerre, factorial
+        LaserProfile.__init__(self, propagation_direction)
+        k0 = 2 * np.pi / lambda0
+        E0 = a0 * m_e * c ** 2 * k0 / e
+        self.E0x, self.E0y = E0 * np.cos(theta_pol), E0 * np.sin(theta_pol)
+        self.p, self.m, self.k0, self.z0 = p, m, k0, z0
+        self.zf = z0 if zf is None else zf
+        self.cep_phase = cep_phase
+        self.inv_ctau2 = 1. / (c * tau) ** 2
+        self.inv_zr = 1. / (0.5 * k0 * waist ** 2)
+        self.w0 = waist
+        self.amplitude = np.sqrt(factorial(p) / factorial(abs(m) + p))
+        self.laguerre = genlaguerre(p, abs(m))
+
+    def _azimuthal(self, theta):
+        raise NotImplementedError
+
+    def E_field(self, x, y, z, t):
+        pd = self.propag_direction
+        xi = pd * (z - self.z0) - c * t
+        longi = np.exp(-1j * self.cep_phase + 1j * self.k0 * xi - self.inv_ctau2 * xi ** 2)
+        q = 1. + 1j * pd * (z - self.zf) * self.inv_zr
+        r2 = x ** 2 + y ** 2
+        s2 = 2 * r2 / (self.w0 * abs(q)) ** 2
+        am = abs(self.m)
+        trans = np.exp(-r2 / (self.w0 ** 2 * q) - 1j * (2 * self.p + am) * np.angle(q)) / q \
+            * np.sqrt(s2) ** am * self.laguerre(s2) * self._azimuthal(np.angle(x + 1j * y))
+        profile = self.amplitude * longi * trans
+        return (self.E0x * profile).real, (self.E0y * profile).real
+
+
+class LaguerreGaussLaser(_LaguerreGaussPulse):
+    """Linearly polarised Laguerre-Gauss pulse whose field varies as cos[m (theta - theta0)]
+    (phase independent of theta; laser_profiles.py:296-446, transverse_laser_profiles.py:
+    169-310).  Needs the azimuthal modes 0 .. m+1."""
+
+    def __init__(self, p, m, a0, waist, tau, z0, zf=None, theta_pol=0., lambda0=0.8e-6,
+                 cep_phase=0., theta0=0., propagation_direction=1):
+        if m < 0 or type(m) is not int:
+            raise ValueError("m should be an integer positive number.")
+        _LaguerreGaussPulse.__init__(self, p, m, a0, waist, tau, z0, zf, theta_pol, lambda0,
+                                     cep_phase, propagation_direction)
+        if m != 0:
+            self.amplitude *= 2 ** .5       # <cos^2> = 1/2: same energy as the m = 0 pulse
+        self.theta0 = theta0
+
+    def _azimuthal(self, theta):
+        return np.cos(self.m * (theta - self.theta0))
+
+
+class DonutLikeLaguerreGaussLaser(_LaguerreGaussPulse):
+    """Linearly polarised Laguerre-Gauss pulse with the cork-screw phase exp(-i m theta) and a
+    theta-independent (donut) intensity (laser_profiles.py:448-585,
+    transverse_laser_profiles.py:312-432).  m may be negative; needs modes 0 .. |m|+1."""
+
+    def __init__(self, p, m, a0, waist, tau, z0, zf=None, theta_pol=0., lambda0=0.8e-6,
+                 cep_phase=0., propagation_direction=1):
+        _LaguerreGaussPulse.__init__(self, p, m, a0, waist, tau, z0, zf, theta_pol, lambda0,
+                                     cep_phase, propagation_direction)
+
+    def _azimuthal(self, theta):
+        return np.exp(-1j * self.m * theta)
 
 
 def add_laser_pulse(sim, laser_profile, gamma_boost=None, method='direct', z0_antenna=None,

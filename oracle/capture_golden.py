@@ -606,6 +606,39 @@ def cap_crossdep():
         save(name, **res)
 
 
+LASER_CASES = [
+    ('lg', (0, 1), dict()),
+    ('lg', (1, 2), dict(theta0=0.3, theta_pol=0.7)),
+    ('lg', (2, 0), dict(cep_phase=0.4)),
+    ('lg', (0, 3), dict(propagation_direction=-1)),
+    ('donut', (0, -1), dict()),
+    ('donut', (1, 2), dict(theta_pol=0.7)),
+    ('donut', (2, 0), dict(cep_phase=0.4)),
+    ('donut', (0, -3), dict(propagation_direction=-1)),
+    ('gauss', (), dict(theta_pol=0.2, cep_phase=0.1)),
+]
+
+
+def cap_laser_profiles():
+    """E_field of the reference's Gaussian / Laguerre-Gauss / donut-like profiles (and of a sum
+    of two) at random points (fbpic/lpa_utils/laser/laser_profiles.py:179-585)."""
+    from fbpic.lpa_utils.laser import GaussianLaser, LaguerreGaussLaser, DonutLikeLaguerreGaussLaser
+    rng = np.random.default_rng(0)
+    x, y = rng.normal(size=(2, 2000)) * 5e-6
+    z = rng.uniform(-20e-6, 40e-6, 2000)
+    t = 3e-15
+    res = dict(x=x, y=y, z=z, t=t)
+    cls = dict(lg=LaguerreGaussLaser, donut=DonutLikeLaguerreGaussLaser, gauss=GaussianLaser)
+    for i, (kind, pm, kw) in enumerate(LASER_CASES):
+        prof = cls[kind](*pm, 1.3, 4e-6, 8e-15, 1e-6, zf=12e-6, **kw)
+        res['case%d' % i] = np.array(prof.E_field(x, y, z, t))
+    s = LaguerreGaussLaser(0, 1, 0.5, 4e-6, 8e-15, 0., zf=5e-6, theta_pol=0., theta0=0.) \
+        + LaguerreGaussLaser(0, 1, 0.5, 4e-6, 8e-15, 0., zf=5e-6, theta_pol=np.pi / 2,
+                             theta0=np.pi / 2)
+    res['sum'] = np.array(s.E_field(x, y, z, t))
+    save('laser_profiles', **res)
+
+
 def cap_uniform_rho():
     """Counterpart of tests/test_uniform_rho_deposition.py: only the assertion values."""
     # The assertions are analytic (rho = -n e inside the plasma); no fixture needed.
@@ -613,7 +646,8 @@ def cap_uniform_rho():
 
 ALL = dict(push=cap_push, gather=cap_gather, deposit=cap_deposit, grid_setup=cap_grid_setup,
            spectral=cap_spectral, cycle=cap_cycle, bunch=cap_bunch, lwfa=cap_lwfa,
-           galilean=cap_galilean, crossdep=cap_crossdep)
+           galilean=cap_galilean, crossdep=cap_crossdep,
+           laser_profiles=cap_laser_profiles)
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(ALL)

@@ -5,8 +5,8 @@ public API (`Simulation`, `GpuMemoryManager`, `Particles.deposit`, `Fields.erase
 * tests/test_uniform_rho_deposition.py - the deposited density of a uniform plasma is uniform
   (linear and cubic shapes, Ruyten-corrected weights), also after a small radial shift of the
   electrons of a neutral plasma;
-* tests/test_laser.py (mode-1 case, the Gaussian pulse) - vacuum diffraction of a laser against
-  the paraxial theory in a periodic box with a time step 60x the Courant limit, in a moving
+* tests/test_laser.py - vacuum diffraction of a laser in mode 0 (radially polarised annular
+  beam), mode 1 (Gaussian) and mode 2 (donut-like Laguerre-Gauss) against the paraxial theory in a periodic box with a time step 60x the Courant limit, in a moving
   window with open boundaries, and on a Galilean grid at 0.999 c.
 
 (test_periodic_plasma_wave.py and test_cpu_gpu_deposition.py are restated in test_gpu_cycle.py.)
@@ -78,33 +78,56 @@ def _gaussian_transverse_profile(r, w, E):
     return E * np.exp(-r**2 / w**2)
 
 
+def _annular_transverse_profile(r, w, E):
+    return E * (r / w) * np.exp(-r**2 / w**2)
+
+
 def _fit_fields(fld, m):
-    """test_laser.py:420-452 (mode 1: Gaussian fit of the z-integrated |Er|)."""
+    """test_laser.py:420-452: Gaussian (m = 1) or annular (m = 0, 2) fit of the z-integrated
+    |Er| of mode m."""
     dz = fld.interp[0].dz
     laser_profile = np.sqrt(dz * (abs(fld.interp[m].Er)**2).sum(axis=0))
     laser_profile *= 2.**(3. / 4) / (np.pi**(1. / 4) * L['ctau']**(1. / 2))
-    fit = curve_fit(_gaussian_transverse_profile, fld.interp[m].r, laser_profile,
-                    p0=np.array([L['w0'], L['E0']]))
-    fit[0][1] = 2 * fit[0][1]       # factor 2 of the modes m > 0
+    shape = _gaussian_transverse_profile if m == 1 else _annular_transverse_profile
+    fit = curve_fit(shape, fld.interp[m].r, laser_profile, p0=np.array([L['w0'], L['E0']]))
+    if m > 0:
+        fit[0][1] = 2 * fit[0][1]       # factor 2 of the modes m > 0
     return fit[0]
 
 
-def _propagate_pulse(dt, boundaries, v_window=0, use_galilean=False, v_comoving=0):
-    """test_laser.py:130-286 for m = 1 (Nm = 2, linearly polarised Gaussian pulse)."""
-    from fbpic_amd.main import Simulation
-    from fbpic_amd.lpa_utils.laser import add_laser_pulse, GaussianLaser
+def _init_fields(sim, m):
+    """test_laser.py:289-338: mode 0 <- radially polarised pulse (two Laguerre-Gauss profiles),
+    mode 1 <- linearly polarised Gaussian pulse, mode 2 <- donut-like Laguerre-Gauss pulse."""
+    from fbpic_amd.lpa_utils.laser import add_laser_pulse, GaussianLaser, LaguerreGaussLaser, \
+        DonutLikeLaguerreGaussLaser
     p = L
-    m = 1
+    z0 = (p['zmax'] + p['zmin']) / 2
+    a0 = p['E0'] * e / (m_e * c**2 * p['k0'])
+    tau, lambda0, w, zf = p['ctau'] / c, 2 * np.pi / p['k0'], p['w0'], p['zf']
+    if m == 0:
+        profile = LaguerreGaussLaser(0, 1, 0.5 * a0, w, tau, z0, zf=zf, lambda0=lambda0,
+                                     theta_pol=0., theta0=0.) \
+            + LaguerreGaussLaser(0, 1, 0.5 * a0, w, tau, z0, zf=zf, lambda0=lambda0,
+                                 theta_pol=np.pi / 2, theta0=np.pi / 2)
+    elif m == 1:
+        profile = GaussianLaser(a0=a0, waist=w, tau=tau, lambda0=lambda0, z0=z0, zf=zf)
+    else:
+        profile = DonutLikeLaguerreGaussLaser(0, -1, a0=a0, waist=w, tau=tau, lambda0=lambda0,
+                                              z0=z0, zf=zf)
+    add_laser_pulse(sim, profile)
+
+
+def _propagate_pulse(m, dt, boundaries, v_window=0, use_galilean=False, v_comoving=0):
+    """test_laser.py:130-286 for the pulse that lives in mode m (Nm = m + 1)."""
+    from fbpic_amd.main import Simulation
+    p = L
     sim = Simulation(p['Nz'], p['zmax'], p['Nr'], p['Lr'], m + 1, dt, n_order=p['n_order'],
                      zmin=p['zmin'], boundaries=boundaries, v_comoving=v_comoving,
                      exchange_period=1, use_galilean=use_galilean)
     sim.ptcl = []
     if v_window != 0:
         sim.set_moving_window(v=v_window)
-    z0 = (p['zmax'] + p['zmin']) / 2
-    a0 = p['E0'] * e / (m_e * c**2 * p['k0'])
-    add_laser_pulse(sim, GaussianLaser(a0=a0, waist=p['w0'], tau=p['ctau'] / c,
-                                       lambda0=2 * np.pi / p['k0'], z0=z0, zf=p['zf']))
+    _init_fields(sim, m)
     N_diag = p['N_diag']
     w, E = np.zeros(N_diag), np.zeros(N_diag)
     Ntot_step = int(round(p['L_prop'] / (c * dt)))
@@ -120,18 +143,21 @@ def _propagate_pulse(dt, boundaries, v_window=0, use_galilean=False, v_comoving=
     assert np.allclose(E, E_analytic, rtol=5.e-3)
 
 
-def test_laser_periodic():
+@pytest.mark.parametrize('m', [0, 1, 2])
+def test_laser_periodic(m):
     """test_laser.py:72-89: a very long time step checks the absence of a Courant limit."""
-    _propagate_pulse(L['L_prop'] * 1. / c / L['N_diag'], {'z': 'periodic', 'r': 'reflective'})
+    _propagate_pulse(m, L['L_prop'] * 1. / c / L['N_diag'], {'z': 'periodic', 'r': 'reflective'})
 
 
-def test_laser_moving_window():
+@pytest.mark.parametrize('m', [0, 1, 2])
+def test_laser_moving_window(m):
     """test_laser.py:91-108."""
-    _propagate_pulse((L['zmax'] - L['zmin']) * 1. / c / L['Nz'], {'z': 'open', 'r': 'reflective'},
-                     v_window=c)
+    _propagate_pulse(m, (L['zmax'] - L['zmin']) * 1. / c / L['Nz'],
+                     {'z': 'open', 'r': 'reflective'}, v_window=c)
 
 
-def test_laser_galilean():
+@pytest.mark.parametrize('m', [0, 1, 2])
+def test_laser_galilean(m):
     """test_laser.py:110-128."""
-    _propagate_pulse(L['L_prop'] * 1. / c / L['N_diag'], {'z': 'open', 'r': 'reflective'},
+    _propagate_pulse(m, L['L_prop'] * 1. / c / L['N_diag'], {'z': 'open', 'r': 'reflective'},
                      use_galilean=True, v_comoving=0.999 * c)

@@ -3,6 +3,7 @@ profile against its closed form at focus, continuous-injection book-keeping, dam
 (The full open-boundary / moving-window cycle is checked on the GPU against the reference
 trajectory in tests/test_gpu_lwfa.py.)"""
 import numpy as np
+import pytest
 from scipy.constants import c, m_e, e
 
 
@@ -59,3 +60,35 @@ def test_damp_profile_matches_reference_formula():
     ref = np.where(i < 24 + 8, np.sin((i - 24) * np.pi / 16.)**2, 1.)
     ref = np.where(i < 24, 0., ref)
     assert np.array_equal(d, ref)
+
+
+def test_laser_profiles_vs_reference():
+    """Gaussian, Laguerre-Gauss and donut-like Laguerre-Gauss pulses and the sum of two
+    profiles against the reference's E_field at 2000 random points
+    (tests/golden/laser_profiles.npz, oracle/capture_golden.py:cap_laser_profiles)."""
+    from conftest import golden
+    from fbpic_amd.lpa_utils.laser import GaussianLaser, LaguerreGaussLaser, \
+        DonutLikeLaguerreGaussLaser
+    g = golden('laser_profiles')
+    x, y, z, t = g['x'], g['y'], g['z'], float(g['t'])
+    cases = [('lg', (0, 1), dict()),
+             ('lg', (1, 2), dict(theta0=0.3, theta_pol=0.7)),
+             ('lg', (2, 0), dict(cep_phase=0.4)),
+             ('lg', (0, 3), dict(propagation_direction=-1)),
+             ('donut', (0, -1), dict()),
+             ('donut', (1, 2), dict(theta_pol=0.7)),
+             ('donut', (2, 0), dict(cep_phase=0.4)),
+             ('donut', (0, -3), dict(propagation_direction=-1)),
+             ('gauss', (), dict(theta_pol=0.2, cep_phase=0.1))]
+    cls = dict(lg=LaguerreGaussLaser, donut=DonutLikeLaguerreGaussLaser, gauss=GaussianLaser)
+    for i, (kind, pm, kw) in enumerate(cases):
+        got = np.array(cls[kind](*pm, 1.3, 4e-6, 8e-15, 1e-6, zf=12e-6, **kw).E_field(x, y, z, t))
+        ref = g['case%d' % i]
+        assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max(), (i, kind, pm)
+    s = LaguerreGaussLaser(0, 1, 0.5, 4e-6, 8e-15, 0., zf=5e-6, theta_pol=0., theta0=0.) \
+        + LaguerreGaussLaser(0, 1, 0.5, 4e-6, 8e-15, 0., zf=5e-6, theta_pol=np.pi / 2,
+                             theta0=np.pi / 2)
+    got = np.array(s.E_field(x, y, z, t))
+    assert np.abs(got - g['sum']).max() <= 1e-13 * np.abs(g['sum']).max()
+    with pytest.raises(ValueError):
+        LaguerreGaussLaser(0, -1, 1., 4e-6, 8e-15, 0.)
