@@ -342,6 +342,54 @@ class BoundaryCommunicator(object):
         for dev_t, host_t in staged:
             dev_t.copy_(host_t)
 
+    # ---------------------------------------------------------------- gathering (diagnostics)
+    def gather_grid_array(self, array, root=0, with_damp=False):
+        """Global array (physical cells of all ranks, z ascending; optionally with the damp
+        cells of the two ends) on rank `root`, None elsewhere
+        (boundary_communicator.py:1011-1072).  `array`: local (Nz_local, Nr) array or tensor
+        including guard and damp cells.  Not on the hot path: host arrays, object gather."""
+        Nz_global, iz_start_global = self.get_Nz_and_iz(local=False, with_damp=with_damp,
+                                                        with_guard=False)
+        Nr = self.get_Nr(with_damp=with_damp)
+        Nz_local, iz_start_local_domain = self.get_Nz_and_iz(
+            local=True, with_damp=with_damp, with_guard=False, rank=self.rank)
+        _, iz_start_local_array = self.get_Nz_and_iz(local=True, with_damp=True, with_guard=True,
+                                                     rank=self.rank)
+        iz_in_array = iz_start_local_domain - iz_start_local_array
+        if hasattr(array, 'detach'):
+            array = array.detach().cpu().numpy()
+        local_array = np.ascontiguousarray(array[iz_in_array:iz_in_array + Nz_local, :Nr])
+        if self.size == 1:
+            return local_array
+        dist = _dist()
+        pieces = [None] * self.size
+        dist.all_gather_object(pieces, local_array)
+        if self.rank != root:
+            return None
+        gathered_array = np.zeros((Nz_global, Nr), dtype=local_array.dtype)
+        for k, piece in enumerate(pieces):
+            _, iz_k = self.get_Nz_and_iz(local=True, with_damp=with_damp, with_guard=False, rank=k)
+            gathered_array[iz_k - iz_start_global: iz_k - iz_start_global + piece.shape[0]] = piece
+        return gathered_array
+
+    def gather_grid(self, grid, root=0):
+        """InterpolationGrid of the global physical domain (no guard, no damp cells) holding
+        the gathered fields, on rank `root` (boundary_communicator.py:964-1009)."""
+        from ..fields.interpolation_grid import InterpolationGrid, INTERP_FIELDS
+        gathered_grid = None
+        if self.rank == root:
+            Nz_global, _ = self.get_Nz_and_iz(local=False, with_guard=False, with_damp=False)
+            zmin_global, zmax_global = self.get_zmin_zmax(local=False, with_guard=False,
+                                                          with_damp=False)
+            gathered_grid = InterpolationGrid(Nz_global, self.get_Nr(with_damp=False), grid.m,
+                                              zmin_global, zmax_global,
+                                              self.get_rmax(with_damp=False))
+        for field in INTERP_FIELDS:
+            gathered_array = self.gather_grid_array(getattr(grid, field), root)
+            if self.rank == root:
+                setattr(gathered_grid, field, gathered_array)
+        return gathered_grid
+
     # ---------------------------------------------------------------- particle exchange
     def exchange_particles(self, species, fld, time):
         """Single periodic domain: wrap z into [zmin, zmax) (particle_buffer_handling.py:

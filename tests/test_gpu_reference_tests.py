@@ -161,3 +161,50 @@ def test_laser_galilean(m):
     """test_laser.py:110-128."""
     _propagate_pulse(m, L['L_prop'] * 1. / c / L['N_diag'], {'z': 'open', 'r': 'reflective'},
                      use_galilean=True, v_comoving=0.999 * c)
+
+
+# --------------------------------------------------------------- test_continuous_injection.py
+CI = dict(Nz=100, Nr=50, Nm=2, zmin=-10.e-6, zmax=5.e-6, rmax=20.e-6, p_nr=2, p_nz=2, p_nt=4,
+          p_zmax=1e6, n=1.e24, ramp0=7.e-6)
+
+
+@pytest.mark.parametrize('preexisting', [True, False])
+def test_continuous_injection_labframe(preexisting):
+    """test_continuous_injection.py:52-71, 73-171 (lab frame): plasma partly initialised in
+    the box and partly injected by the moving window, two species with different particles
+    per cell and a small temperature; after each batch of steps the deposited density (physical
+    cells, gathered grid) equals the analytic profile within 1 % - no discontinuity between
+    initial and injected plasma."""
+    from fbpic_amd.main import Simulation
+    p = CI
+    Nz, Nr, zmin, zmax, rmax, n = p['Nz'], p['Nr'], p['zmin'], p['zmax'], p['rmax'], p['n']
+    dz = (zmax - zmin) / Nz
+    p_zmin = 0.e-6 if preexisting else zmax + 2 * dz
+    ramp, smooth_r = p['ramp0'], rmax * 0.5
+    dt = (zmax - zmin) / Nz / c
+
+    def dens_func(z, r):
+        dens = np.ones_like(z)
+        dens = np.where(r > rmax - smooth_r, np.cos(0.5 * np.pi * (r - smooth_r) / smooth_r)**2, dens)
+        dens = np.where(z < p_zmin, 0., dens)
+        dens = np.where((z >= p_zmin) & (z < p_zmin + ramp), (z - p_zmin) / ramp * dens, dens)
+        return dens
+
+    np.random.seed(0)
+    sim = Simulation(Nz, zmax, Nr, rmax, p['Nm'], dt, p_zmin, p['p_zmax'], 0, rmax, p['p_nz'],
+                     p['p_nr'], p['p_nt'], 0.5 * n, dens_func=dens_func, initialize_ions=False,
+                     zmin=zmin, boundaries={'z': 'open', 'r': 'reflective'})
+    uth = 0.0001
+    sim.add_new_species(-e, m_e, 0.5 * n, dens_func, 2 * p['p_nz'], 2 * p['p_nr'], 2 * p['p_nt'],
+                        p_zmin, p['p_zmax'], 0, rmax, ux_th=uth, uy_th=uth, uz_th=uth)
+    sim.set_moving_window(v=c)
+    N_check = 2
+    N_step = int(Nz / N_check / 2)
+    for _ in range(N_check):
+        sim.step(N_step, move_momenta=False)
+        grid = sim.comm.gather_grid(sim.fld.interp[0])
+        z, r = np.meshgrid(grid.z, grid.r, indexing='ij')
+        rho_expected = -n * e * dens_func(z, r)
+        assert grid.rho.shape == (Nz, Nr)
+        assert np.allclose(grid.rho.real, rho_expected, atol=1.e-2 * abs(rho_expected).max())
+        assert np.allclose(grid.rho.imag, 0., atol=1.e-2 * abs(rho_expected).max())

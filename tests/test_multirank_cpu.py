@@ -105,6 +105,20 @@ def _worker(rank, world, port, boundary, q):
                 if comm.right_proc is not None:
                     exp[-2 * NG:] += local_J(comm.right_proc, m, i, Nz_of[comm.right_proc])[:2 * NG]
                 assert np.allclose(getattr(interp[m], k).numpy(), exp, rtol=0, atol=1e-14), k
+        # ---------------- gather of the physical cells on rank 0 (diagnostics)
+        for with_damp in (False, True):
+            Nz_g, iz_g = comm.get_Nz_and_iz(local=False, with_damp=with_damp, with_guard=False)
+            G = _global_field(4242, Nz_g)
+            idx = np.arange(Nz_l) + iz0 - iz_g          # my rows in the global array
+            ok = (idx >= 0) & (idx < Nz_g)
+            loc = np.full((Nz_l, NR), 1e30 + 0j)
+            loc[ok] = G[idx[ok]]                        # guard rows that wrap: garbage
+            got = comm.gather_grid_array(torch.from_numpy(loc) if with_damp else loc,
+                                         with_damp=with_damp)
+            if rank == 0:
+                assert got.shape == (Nz_g, NR) and np.array_equal(got, G), with_damp
+            else:
+                assert got is None
         # ---------------- particle hand-over
         from fbpic_amd.boundaries.particle_buffer_handling import exchange_particles_between_ranks
 
