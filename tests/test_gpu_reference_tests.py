@@ -208,3 +208,40 @@ def test_continuous_injection_labframe(preexisting):
         assert grid.rho.shape == (Nz, Nr)
         assert np.allclose(grid.rho.real, rho_expected, atol=1.e-2 * abs(rho_expected).max())
         assert np.allclose(grid.rho.imag, 0., atol=1.e-2 * abs(rho_expected).max())
+
+
+# --------------------------------------------------------------------- test_external_fields.py
+def _laser_func(F, x, y, z, t, amplitude, length_scale):
+    import math
+    return F + amplitude * math.cos(2 * np.pi * (z - c * t) / length_scale)
+
+
+def test_external_fields_lab():
+    """test_external_fields.py:41-151 (lab frame): the Vay pusher moves particles in a plane
+    wave given as external Ex, By; ux = a0 sin(k0 (z - ct)) and uz = ux^2 / 2 to 5e-2."""
+    from fbpic_amd.main import Simulation
+    from fbpic_amd.lpa_utils.external_fields import ExternalField
+    Nz, Nr, Nm, zmin, zmax, rmax = 5, 10, 2, 0.e-6, 0.8e-6, 2.e-6
+    a0, lambda0 = 1., 0.8e-6
+    k0 = 2 * np.pi / lambda0
+    dt = lambda0 / c / 200
+    N_step = 400
+    sim = Simulation(Nz, zmax, Nr, rmax, Nm, dt, initialize_ions=False, zmin=zmin,
+                     boundaries={'z': 'periodic', 'r': 'reflective'})
+    sim.ptcl = []
+    sim.add_new_species(-e, m_e, n=1., p_rmax=rmax / Nr, p_nz=1, p_nr=1, p_nt=1)
+    sim.external_fields = [ExternalField(_laser_func, 'Ex', a0 * m_e * c**2 * k0 / e, lambda0),
+                           ExternalField(_laser_func, 'By', a0 * m_e * c * k0 / e, lambda0)]
+    s = sim.ptcl[0]
+    Nptcl = s.Ntot
+    z, ux, uz = (np.zeros((N_step, Nptcl)) for _ in range(3))
+    s.ux = a0 * np.sin(k0 * s.z)
+    s.uz[:] = 0.5 * s.ux**2
+    for i in range(N_step):
+        z[i, :], ux[i, :], uz[i, :] = s.z[:], s.ux[:], s.uz[:]
+        sim.step(1)
+    t = sim.dt * np.arange(N_step)
+    ux_analytical = a0 * np.sin(k0 * (z - c * t[:, None]))
+    uz_analytical = 0.5 * ux_analytical**2
+    assert np.allclose(ux, ux_analytical, atol=5.e-2)
+    assert np.allclose(uz, uz_analytical, atol=5.e-2)

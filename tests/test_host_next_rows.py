@@ -92,3 +92,38 @@ def test_laser_profiles_vs_reference():
     assert np.abs(got - g['sum']).max() <= 1e-13 * np.abs(g['sum']).max()
     with pytest.raises(ValueError):
         LaguerreGaussLaser(0, -1, 1., 4e-6, 8e-15, 0.)
+
+
+def test_external_field_hook_on_host_arrays():
+    """ExternalField.apply_expression (lpa_utils/external_fields.py:174-213) with a `math`-style
+    scalar function and with a NumPy-aware one; species filter; argument checks."""
+    import math
+    from fbpic_amd.lpa_utils.external_fields import ExternalField
+
+    class Sp:
+        pass
+    rng = np.random.default_rng(5)
+    sp, other = Sp(), Sp()
+    for s in (sp, other):
+        s.Ntot = 50
+        for k in ('x', 'y', 'z', 'Ex', 'By'):
+            setattr(s, k, rng.normal(size=50))
+    ex0, by0, z = sp.Ex.copy(), sp.By.copy(), sp.z.copy()
+    o0 = other.Ex.copy()
+
+    def f_scalar(F, x, y, z, t, amplitude, length_scale):
+        return F + amplitude * math.cos(2 * np.pi * (z - c * t) / length_scale)
+
+    def f_array(F, x, y, z, t, amplitude, length_scale):
+        return F + amplitude * np.cos(2 * np.pi * (z - c * t) / length_scale)
+    t = 1e-15
+    ExternalField(f_scalar, 'Ex', 3., 0.8e-6, species=sp).apply_expression([sp, other], t)
+    ExternalField(f_array, 'By', 2., 0.8e-6).apply_expression([sp], t)
+    wave = np.cos(2 * np.pi * (z - c * t) / 0.8e-6)
+    assert np.allclose(sp.Ex, ex0 + 3. * wave, rtol=0, atol=1e-14)
+    assert np.allclose(sp.By, by0 + 2. * wave, rtol=0, atol=1e-14)
+    assert np.array_equal(other.Ex, o0)                 # filtered out by `species`
+    with pytest.raises(ValueError):
+        ExternalField(f_scalar, 'Er', 1., 1.)
+    with pytest.raises(NotImplementedError):
+        ExternalField(f_scalar, 'Ex', 1., 1., gamma_boost=10.)
