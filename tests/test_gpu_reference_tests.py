@@ -9,6 +9,9 @@ public API (`Simulation`, `GpuMemoryManager`, `Particles.deposit`, `Fields.erase
   beam), mode 1 (Gaussian) and mode 2 (donut-like Laguerre-Gauss) against the paraxial theory in a periodic box with a time step 60x the Courant limit, in a moving
   window with open boundaries, and on a Galilean grid at 0.999 c.
 
+* tests/test_continuous_injection.py (lab frame), tests/test_external_fields.py (lab frame),
+  tests/test_linear_wakefield.py (Nm = 1, 2, 3).
+
 (test_periodic_plasma_wave.py and test_cpu_gpu_deposition.py are restated in test_gpu_cycle.py.)
 """
 import numpy as np
@@ -245,3 +248,72 @@ def test_external_fields_lab():
     uz_analytical = 0.5 * ux_analytical**2
     assert np.allclose(ux, ux_analytical, atol=5.e-2)
     assert np.allclose(uz, uz_analytical, atol=5.e-2)
+
+
+# -------------------------------------------------------------------- test_linear_wakefield.py
+W = dict(Nz=800, zmax=40.e-6, Nr=120, rmax=60.e-6, N_step=1500, p_zmin=39.e-6, p_zmax=41.e-6,
+         p_rmin=0., p_rmax=55.e-6, n_e=8.e24, p_nz=2, p_nr=2, a0=0.01, w0=20.e-6, ctau=6.e-6,
+         z0=22.e-6)
+
+
+@pytest.mark.parametrize('Nm', [1, 2, 3])
+def test_linear_wakefield(Nm):
+    """test_linear_wakefield.py:62-166, 168-232: the WHOLE PIC cycle (laser on the grid, moving
+    window, continuous injection, gather, push, deposition, current correction, PSATD) -
+    a laser-driven linear plasma wake after 1500 steps against the analytic Ez, Er of linear
+    theory, to the reference's 8 % / 11 % of the peak.  Nm = 1: azimuthally polarised annular
+    pulse (mode 0), Nm = 2: Gaussian pulse (laser in mode 1, wake in mode 0), Nm = 3:
+    Laguerre-Gauss pulse (laser in modes 0 and 2, wake in modes 0 and 2)."""
+    from scipy.constants import epsilon_0
+    from scipy.integrate import quad
+    from fbpic_amd.main import Simulation
+    from fbpic_amd.lpa_utils.laser import add_laser_pulse, GaussianLaser, LaguerreGaussLaser
+    p = W
+    a0, w0, ctau, z0 = p['a0'], p['w0'], p['ctau'], p['z0']
+    tau = ctau / c
+    kp = 1. / c * np.sqrt(p['n_e'] * e**2 / (m_e * epsilon_0))
+    dt = p['zmax'] / p['Nz'] / c
+    np.random.seed(0)
+    sim = Simulation(p['Nz'], p['zmax'], p['Nr'], p['rmax'], Nm, dt, p['p_zmin'], p['p_zmax'],
+                     p['p_rmin'], p['p_rmax'], p['p_nz'], p['p_nr'], 2 * Nm, p['n_e'],
+                     boundaries={'z': 'open', 'r': 'reflective'})
+    if Nm == 1:
+        profile = LaguerreGaussLaser(0, 1, a0=a0, waist=w0, tau=tau, z0=z0, theta_pol=np.pi / 2,
+                                     theta0=0.) \
+            + LaguerreGaussLaser(0, 1, a0=a0, waist=w0, tau=tau, z0=z0, theta_pol=0.,
+                                 theta0=-np.pi / 2)
+    elif Nm == 2:
+        profile = GaussianLaser(a0=a0, waist=w0, tau=tau, z0=z0, theta_pol=np.pi / 2)
+    else:
+        profile = LaguerreGaussLaser(0, 1, a0=a0, waist=w0, tau=tau, z0=z0, theta_pol=np.pi / 2)
+    add_laser_pulse(sim, profile)
+    sim.set_moving_window(v=c)
+    sim.step(p['N_step'], correct_currents=True)
+
+    grids = [sim.comm.gather_grid(sim.fld.interp[m]) for m in range(Nm)]
+    z, r, t = grids[0].z, grids[0].r, sim.time
+    window_zmax = z.max()
+
+    def long_profile(kernel, limit):
+        return np.array([quad(lambda xi0, xi: kernel(kp * (xi - xi0))
+                              * np.exp(-2 * (xi0 - z0)**2 / ctau**2),
+                              zi - c * t, window_zmax - c * t, args=(zi - c * t,), limit=limit)[0]
+                         for zi in z])
+    if Nm in (1, 3):
+        trans_Ez = 4 * (r / w0)**2 * np.exp(-2 * r**2 / w0**2)
+        trans_Er = 8 * (r / w0**2) * (1 - 2 * r**2 / w0**2) * np.exp(-2 * r**2 / w0**2)
+    else:
+        trans_Ez = np.exp(-2 * r**2 / w0**2)
+        trans_Er = -4 * r / w0**2 * np.exp(-2 * r**2 / w0**2)
+    Ez_analytical = m_e * c**2 * kp**2 * a0**2 / (4. * e) * trans_Ez[None, :] \
+        * long_profile(np.cos, 30)[:, None]
+    Er_analytical = m_e * c**2 * kp * a0**2 / (4. * e) * trans_Er[None, :] \
+        * long_profile(np.sin, 200)[:, None]
+    # sum of the modes in the theta = 0 plane (factor 2 of the modes m > 0)
+    Ez_sim = grids[0].Ez.real.copy()
+    Er_sim = grids[0].Er.real.copy()
+    for m in range(1, Nm):
+        Ez_sim += 2 * grids[m].Ez.real
+        Er_sim += 2 * grids[m].Er.real
+    assert np.allclose(Ez_sim, Ez_analytical, atol=0.08 * abs(Ez_analytical).max())
+    assert np.allclose(Er_sim, Er_analytical, atol=0.11 * abs(Er_analytical).max())
