@@ -148,7 +148,7 @@ def _worker(rank, world, port, boundary, q):
         assert sp.Ntot == znew.size == sp.Ex.shape[0] and sp.changed
         assert np.all(znew >= zlo - 1e-12) and np.all(znew <= zhi + 1e-12)
         # global conservation: every particle that had a neighbour to go to still exists once
-        mine = torch.zeros(2 * 10000, dtype=torch.float64)
+        mine = torch.zeros(world * 10000, dtype=torch.float64)
         mine[sp.w.numpy().astype(int)] = 1.
         dist.all_reduce(mine)
         expected_lost = 0
@@ -174,9 +174,11 @@ def _worker(rank, world, port, boundary, q):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('boundary', ['periodic', 'open'])
-def test_two_rank_exchange_gloo(boundary):
-    world = 2
+@pytest.mark.parametrize('boundary,world', [('periodic', 2), ('open', 2), ('periodic', 3),
+                                            ('open', 3)])
+def test_two_rank_exchange_gloo(boundary, world):
+    """world = 2: both neighbours of a periodic ring are the same peer (message order matters);
+    world = 3: distinct neighbours, and for an open chain one interior rank."""
     port = _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
