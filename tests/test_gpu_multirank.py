@@ -76,10 +76,13 @@ def _worker(rank, world, port, shape, outdir, correct, q):
         q.put((rank, traceback.format_exc()))
 
 
-@pytest.mark.parametrize('shape,correct,tol', [('linear', False, 1e-9), ('cubic', False, 1e-9),
-                                               ('linear', True, 3e-2)])
-def test_two_ranks_reproduce_single_domain(shape, correct, tol):
-    """Without current correction every operation is local within the stencil reach, so
+@pytest.mark.parametrize('shape,correct,tol,nranks', [('linear', False, 1e-9, 2),
+                                                      ('cubic', False, 1e-9, 2),
+                                                      ('linear', True, 3e-2, 2),
+                                                      ('linear', False, 1e-9, 4)])
+def test_two_ranks_reproduce_single_domain(shape, correct, tol, nranks):
+    """(nranks = 4: every rank has two distinct neighbours, as on the 4- and 8-GPU runs.)
+    Without current correction every operation is local within the stencil reach, so
     the decomposed run must agree with the single domain to rounding.  The curl-free
     correction inverts a Laplacian on each rank's own (periodic, guard-padded) box before
     the J guard exchange (reference main.py:530-538), which is only approximately equal to
@@ -88,7 +91,7 @@ def test_two_ranks_reproduce_single_domain(shape, correct, tol):
     import helpers
     outdir = tempfile.mkdtemp()
     ctx = mp.get_context('spawn')
-    for world in (1, 2):
+    for world in (1, nranks):
         port = _free_port()
         q = ctx.Queue()
         procs = [ctx.Process(target=_worker, args=(r, world, port, shape, outdir, correct, q))
@@ -101,12 +104,12 @@ def test_two_ranks_reproduce_single_domain(shape, correct, tol):
         for rank, msg in res:
             assert msg == 'ok', 'world %d rank %d:\n%s' % (world, rank, msg)
     one = np.load(os.path.join(outdir, 'w1_r0.npz'))
-    two = [np.load(os.path.join(outdir, 'w2_r%d.npz' % r)) for r in range(2)]
+    two = [np.load(os.path.join(outdir, 'w%d_r%d.npz' % (nranks, r))) for r in range(nranks)]
     for m in range(NM):
         for k in helpers.INTERP:
             key = '%s_%d' % (k, m)
             ref = one[key]
-            got = np.concatenate([two[0][key], two[1][key]], axis=0)
+            got = np.concatenate([t[key] for t in two], axis=0)
             assert got.shape == ref.shape
             grp = [kk for kk in helpers.INTERP if kk[0] == k[0]]
             scale = max(np.abs(one['%s_%d' % (kk, mm)]).max() for kk in grp for mm in range(NM))
