@@ -66,7 +66,7 @@ def parse():
     ap.add_argument('--shape', default='linear')
     ap.add_argument('--ppc', default='2,4,4')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-steps', type=int, default=3)
+    ap.add_argument('--cpu-steps', type=int, default=10)   # ~10 s of CPU work on 16 cores
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--resort-fragmentation', type=float, default=None,
                     help='override Particles.resort_fragmentation (adaptive sort policy)')
