@@ -179,7 +179,7 @@ class BoundaryCommunicator(object):
         damp = np.where(i_cell < i0 + nz_damp / 2., rise, 1.)
         return np.where(i_cell < i0, 0., damp)
 
-    def damp_EB_open_boundary(self, interp):
+    def damp_EB_open_boundary(self, interp, slab=None):
         """Multiply E and B by the damping profile in the damp cells of the end ranks
         (boundary_communicator.py:828-907).  No-op for periodic z."""
         if self.nz_damp == 0:
@@ -187,11 +187,14 @@ class BoundaryCommunicator(object):
         t = _capi.torch()
         names = ('Er', 'Et', 'Ez', 'Br', 'Bt', 'Bz')
         owner = getattr(interp[0], '_owner', None)
+        base = slab
         slab = None
         if owner is not None and owner.data_is_on_gpu and len(interp) == owner.Nm:
             # E and B of all modes are the first 6*Nm fields of the z-major slab: one
             # multiplication per end instead of 6*Nm
-            slab = owner.d_interp[:, 0:6 * owner.Nm, :]
+            if base is None:
+                base = owner.d_interp
+            slab = base[:, 0:6 * owner.Nm, :]
         if slab is not None:
             # one launch for both ends (cuda_damp_EB_left / cuda_damp_EB_right)
             dev = interp[0].Er.device
@@ -202,7 +205,7 @@ class BoundaryCommunicator(object):
             dl = self.d_left_damp if self.left_proc is None else None
             dr = self.d_right_damp if self.right_proc is None else None
             rc = _capi.lib().fb_damp_rows(
-                _capi.ptr(slab), owner.d_interp.stride(0), slab.shape[1] * slab.shape[2],
+                _capi.ptr(slab), base.stride(0), slab.shape[1] * slab.shape[2],
                 _capi.ptr(dl), 0 if dl is None else dl.shape[0],
                 _capi.ptr(dr), 0 if dr is None else dr.shape[0], slab.shape[0], _capi.stream())
             _capi.check(rc, 'fb_damp_rows')
@@ -230,7 +233,7 @@ class BoundaryCommunicator(object):
                         getattr(g, k)[-nd:, :] *= self.d_right_damp[:, None]
 
     # ---------------------------------------------------------------- field exchange
-    def exchange_fields(self, interp, fldtype, method):
+    def exchange_fields(self, interp, fldtype, method, slab=None):
         """Guard-cell exchange with the two z neighbours (boundary_communicator.py:556-671):
         'replace': my guard cells [0,ng) / [Nz-ng,Nz) <- neighbour's valid [Nz-2ng,Nz-ng) /
         [ng,2ng);  'add': my [0,2ng) / [Nz-2ng,Nz) += neighbour's [Nz-2ng,Nz) / [0,2ng)."""
@@ -258,7 +261,10 @@ class BoundaryCommunicator(object):
             # values of every z row -> ONE launch packs both message buffers, one unpacks them
             # (the reference's copy_*_to_gpu_buffer / replace_* / add_*_from_gpu_buffer)
             f0, _, nf, _ = owner._group('rho_prev' if fldtype == 'rho' else fldtype)
-            region = owner.d_interp[:, f0:f0 + nf, :]
+            base = owner.d_interp
+            if slab is not None:            # the group sits at fields 0 .. nf-1 of `slab`
+                base, f0 = slab, 0
+            region = base[:, f0:f0 + nf, :]
             nrows, ncontig = s_l.stop - s_l.start, nf * region.shape[2]
             key = (fldtype, method, nrows, ncontig)
             bufs = self._guard_bufs.get(key)
@@ -268,7 +274,7 @@ class BoundaryCommunicator(object):
                 self._guard_bufs[key] = bufs
             send_l, send_r, recv_l, recv_r = bufs
             lib, p, st = _capi.lib(), _capi.ptr, _capi.stream()
-            rs = owner.d_interp.stride(0)
+            rs = base.stride(0)
             _capi.check(lib.fb_guard_buffers(0, p(region), rs, ncontig, s_l.start, s_r.start, nrows,
                                              p(send_l), p(send_r), st), 'fb_guard_buffers')
             self.exchange_domains(send_l, send_r, recv_l, recv_r)

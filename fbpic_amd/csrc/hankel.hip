@@ -77,15 +77,23 @@ constexpr size_t HK_LDS_BYTES = (size_t)2 * (HK_ABUF + HK_BBUF) * 8;
 //   written to the other LDS buffer; one barrier per chunk.  MFMA operands come from LDS
 //   (padded panels, conflict-free ds_read_b128 / ds_read_b64), so the vector-memory path
 //   only sees coalesced traffic and each matrix element is fetched once per workgroup.
-template <bool SCALED, bool PAIRED>
+// DUAL (backward transform of a vector field, (p, m) -> (r, t) folded into the GEMM,
+// spectral_transformer.py:89-155): out = in . mat + sgn (in2 . mat2), K walked over both
+// products with one accumulator, then multiplied by i when sgn < 0:
+//   r = p' + m'      (in = p, in2 = m, sgn = +1)
+//   t = i (p' - m')  (in = p, in2 = m, sgn = -1)
+// in2 comes from Pr.in2, sgn from Pr.sgn, mat2 travels in Sc.sk; jobs with in2 == 0 are
+// plain transforms (the z components).
+template <bool SCALED, bool PAIRED, bool DUAL = false>
 __global__ __launch_bounds__(256) void k_hankel(HankelJobs J, HankelScales Sc, HankelPairs Pr, long irs,
                                                 long ors, double alpha, int Nz, int Nr)
 {
     extern __shared__ double hk_lds[];
     const int job = blockIdx.z;
     const cplx *__restrict__ in = J.in[job];
-    const cplx *__restrict__ in2 = PAIRED ? Pr.in2[job] : nullptr;
-    const double psgn = PAIRED ? Pr.sgn[job] : 0.;
+    const cplx *__restrict__ in2 = (PAIRED || DUAL) ? Pr.in2[job] : nullptr;
+    const double psgn = (PAIRED || DUAL) ? Pr.sgn[job] : 0.;
+    const double *__restrict__ mat2 = DUAL ? Sc.sk[job] : nullptr;
     cplx *__restrict__ out = J.out[job];
     const double *__restrict__ mat = J.mat[job];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -104,7 +112,13 @@ __global__ __launch_bounds__(256) void k_hankel(HankelJobs J, HankelScales Sc, H
     // doubles (8 per thread)
     double2 ra[4];
     double rb[8];
-    auto gload = [&](int k0) {
+    const int nchunks = (Nr + HK_KC - 1) / HK_KC;
+    // chunk index -> which of the two products it belongs to (DUAL), and its k offset
+    auto gload = [&](int c) {
+        const bool second = DUAL && c >= nchunks;
+        const int k0 = (second ? c - nchunks : c) * HK_KC;
+        const cplx *__restrict__ src = second ? in2 : in;
+        const double *__restrict__ mm = second ? mat2 : mat;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int idx = j * 256 + tid;
@@ -112,7 +126,8 @@ __global__ __launch_bounds__(256) void k_hankel(HankelJobs J, HankelScales Sc, H
             const int zz = zb + row, k = k0 + kk;
             double2 v = make_double2(0., 0.);
             if (zz < Nz && k < Nr) {
-                v = *(const double2 *)(in + (long)zz * irs + k);
+                v = *(const double2 *)(src + (long)zz * irs + k);
+                if (second) { v.x *= psgn; v.y *= psgn; }
                 if (PAIRED && in2) {
                     // numba_rt_to_pm: p = 0.5 (r - i t), m = 0.5 (r + i t)
                     const double2 w_ = *(const double2 *)(in2 + (long)zz * irs + k);
@@ -128,7 +143,7 @@ __global__ __launch_bounds__(256) void k_hankel(HankelJobs J, HankelScales Sc, H
             const int idx = j * 256 + tid;
             const int kr = idx >> 6, nn = idx & 63;
             const int k = k0 + kr, n = n0 + nn;
-            rb[j] = (k < Nr && n < Nr) ? mat[(long)k * Nr + n] : 0.;
+            rb[j] = (k < Nr && n < Nr) ? mm[(long)k * Nr + n] : 0.;
         }
     };
     auto lstore = [&](int buf) {
@@ -145,13 +160,13 @@ __global__ __launch_bounds__(256) void k_hankel(HankelJobs J, HankelScales Sc, H
             B[(idx >> 6) * HK_RSB + (idx & 63)] = rb[j];
         }
     };
-    const int nchunks = (Nr + HK_KC - 1) / HK_KC;
+    const int ntot = (DUAL && in2) ? 2 * nchunks : nchunks;
     gload(0);
     lstore(0);
     __syncthreads();
-    for (int c = 0; c < nchunks; c++) {
+    for (int c = 0; c < ntot; c++) {
         const int cur = c & 1;
-        if (c + 1 < nchunks) gload((c + 1) * HK_KC);
+        if (c + 1 < ntot) gload(c + 1);
         const double *A = hk_lds + cur * (HK_ABUF + HK_BBUF) + (wz * 16 + li) * HK_RSA;
         const double *B = hk_lds + cur * (HK_ABUF + HK_BBUF) + HK_ABUF + 32 * wn;
 #pragma unroll
@@ -167,9 +182,10 @@ __global__ __launch_bounds__(256) void k_hankel(HankelJobs J, HankelScales Sc, H
                 acc_im[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b[t], acc_im[t], 0, 0, 0);
             }
         }
-        if (c + 1 < nchunks) lstore(cur ^ 1);
+        if (c + 1 < ntot) lstore(cur ^ 1);
         __syncthreads();
     }
+    const bool times_i = DUAL && in2 && psgn < 0.;
     const int z0 = zb + wz * 16;
     const double *fz = SCALED ? Sc.fz[job] : nullptr;
     const double *fr = SCALED ? Sc.fr[job] : nullptr;
@@ -185,8 +201,8 @@ __global__ __launch_bounds__(256) void k_hankel(HankelJobs J, HankelScales Sc, H
             if (zz < Nz) {
                 double cz = cn;
                 if (SCALED && fz) cz = fz[zz] * cn;     // fz[iz]*fr[ir]*F as in numba_filter_*
-                *(double2 *)(out + (long)zz * ors + n) =
-                    make_double2(cz * acc_re[t][r], cz * acc_im[t][r]);
+                const double2 val = make_double2(cz * acc_re[t][r], cz * acc_im[t][r]);
+                *(double2 *)(out + (long)zz * ors + n) = times_i ? make_double2(-val.y, val.x) : val;
             }
         }
     }
@@ -195,10 +211,12 @@ __global__ __launch_bounds__(256) void k_hankel(HankelJobs J, HankelScales Sc, H
 static int launch(int njobs, const void *const *in, long irs, void *const *out, long ors,
                   const double *const *mat, const double *const *sk, const double *const *fz,
                   const double *const *fr, double alpha, int Nz, int Nr, hipStream_t s,
-                  const void *const *in2 = nullptr, const double *pair_sign = nullptr)
+                  const void *const *in2 = nullptr, const double *pair_sign = nullptr,
+                  const double *const *mat2 = nullptr)
 {
-    const bool scaled = sk || fz || fr || in2;
-    const bool paired = in2 != nullptr;
+    const bool dual = mat2 != nullptr;             // (p, m) -> (r, t) on the output side
+    const bool scaled = !dual && (sk || fz || fr || in2);
+    const bool paired = !dual && in2 != nullptr;
     for (int j0 = 0; j0 < njobs; j0 += HK_MAXJOBS) {
         const int nj = njobs - j0 < HK_MAXJOBS ? njobs - j0 : HK_MAXJOBS;
         HankelJobs J;
@@ -206,28 +224,32 @@ static int launch(int njobs, const void *const *in, long irs, void *const *out, 
         HankelPairs Pr;
         for (int j = 0; j < HK_MAXJOBS; j++) {
             const bool v = j < nj;
-            Pr.in2[j] = (v && paired) ? (const cplx *)in2[j0 + j] : nullptr;
-            Pr.sgn[j] = (v && paired && pair_sign) ? pair_sign[j0 + j] : 0.;
+            Pr.in2[j] = (v && (paired || dual)) ? (const cplx *)in2[j0 + j] : nullptr;
+            Pr.sgn[j] = (v && (paired || dual) && pair_sign) ? pair_sign[j0 + j] : 0.;
             J.in[j] = v ? (const cplx *)in[j0 + j] : nullptr;
             J.out[j] = v ? (cplx *)out[j0 + j] : nullptr;
             J.mat[j] = v ? mat[j0 + j] : nullptr;
-            Sc.sk[j] = (v && sk) ? sk[j0 + j] : nullptr;
+            Sc.sk[j] = (v && dual) ? mat2[j0 + j] : ((v && sk) ? sk[j0 + j] : nullptr);
             Sc.fz[j] = (v && fz) ? fz[j0 + j] : nullptr;
             Sc.fr[j] = (v && fr) ? fr[j0 + j] : nullptr;
         }
         dim3 grid((Nz + HK_TZ - 1) / HK_TZ, (Nr + 63) / 64, nj);
         static bool attr_done = false;
         if (!attr_done) {
-            const void *ks[3] = {(const void *)k_hankel<true, true>, (const void *)k_hankel<true, false>,
-                                 (const void *)k_hankel<false, false>};
-            for (int i = 0; i < 3; i++) {
+            const void *ks[4] = {(const void *)k_hankel<true, true>, (const void *)k_hankel<true, false>,
+                                 (const void *)k_hankel<false, false>,
+                                 (const void *)k_hankel<false, false, true>};
+            for (int i = 0; i < 4; i++) {
                 hipError_t e1 = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize,
                                                     (int)HK_LDS_BYTES);
                 if (e1 != hipSuccess) return check(e1, "fb_hankel(attr)");
             }
             attr_done = true;
         }
-        if (paired)
+        if (dual)
+            hipLaunchKernelGGL((k_hankel<false, false, true>), grid, dim3(256), HK_LDS_BYTES, s, J, Sc, Pr,
+                               irs, ors, alpha, Nz, Nr);
+        else if (paired)
             hipLaunchKernelGGL((k_hankel<true, true>), grid, dim3(256), HK_LDS_BYTES, s, J, Sc, Pr, irs, ors,
                                alpha, Nz, Nr);
         else if (scaled)
@@ -278,4 +300,21 @@ extern "C" int fb_hankel_rt_to_pm_scaled(int njobs, const void *const *in, const
     if (!in2 || !pair_sign) { set_error("fb_hankel_rt_to_pm_scaled", "in2 and pair_sign are required"); return -1; }
     return launch(njobs, in, in_row_stride, out, out_row_stride, mat, in_col_scale, out_row_scale,
                   out_col_scale, alpha, Nz, Nr, (hipStream_t)stream, in2, pair_sign);
+}
+
+extern "C" int fb_hankel_pm_to_rt(int njobs, const void *const *in, const void *const *in2,
+                                  const double *pair_sign, long in_row_stride, void *const *out,
+                                  long out_row_stride, const double *const *mat,
+                                  const double *const *mat2, double alpha, int Nz, int Nr,
+                                  void *stream)
+{
+    if (njobs <= 0) return 0;
+    if (!in2 || !pair_sign || !mat2) {
+        set_error("fb_hankel_pm_to_rt", "in2, pair_sign and mat2 are required");
+        return -1;
+    }
+    for (int j = 0; j < njobs; j++)
+        if (in2[j] && !mat2[j]) { set_error("fb_hankel_pm_to_rt", "job with in2 but no mat2"); return -1; }
+    return launch(njobs, in, in_row_stride, out, out_row_stride, mat, nullptr, nullptr, nullptr,
+                  alpha, Nz, Nr, (hipStream_t)stream, in2, pair_sign, mat2);
 }

@@ -344,18 +344,50 @@ class Fields(object):
                         'fb_pm_to_rt')
         fft_exec(self.d_scratch[:, 0, :], self.d_interp[:, fi, :], +1, ncols=nf * Nr)
 
-    def spect2partial_interp(self, fieldtype):
+    def spect2partial_interp(self, fieldtype, to_scratch=False):
         """inverse FFT only: spectral (p,m,z) -> interpolation-grid storage (r,t,z slots),
-        reference fields.py:431-483."""
+        reference fields.py:431-483.  `to_scratch`: the z-real / r-spectral fields go to the
+        scratch slab instead (fields 0 .. nf-1), for `partial2interp`."""
         self._need_gpu()
         fi, fs, nf, _ = self._group(fieldtype)
-        fft_exec(self.d_spect[:, fs, :], self.d_interp[:, fi, :], +1, ncols=nf * self.Nr)
+        dst = self.d_scratch[:, 0, :] if to_scratch else self.d_interp[:, fi, :]
+        fft_exec(self.d_spect[:, fs, :], dst, +1, ncols=nf * self.Nr)
 
-    def partial_interp2spect(self, fieldtype):
+    def partial_interp2spect(self, fieldtype, from_scratch=False):
         """forward FFT only, reference fields.py:485-536."""
         self._need_gpu()
         fi, fs, nf, _ = self._group(fieldtype)
-        fft_exec(self.d_interp[:, fi, :], self.d_spect[:, fs, :], -1, ncols=nf * self.Nr)
+        src = self.d_scratch[:, 0, :] if from_scratch else self.d_interp[:, fi, :]
+        fft_exec(src, self.d_spect[:, fs, :], -1, ncols=nf * self.Nr)
+
+    def partial2interp(self, fieldtype):
+        """z-real / r-spectral (p, m, z) fields in the scratch slab -> interpolation grid:
+        inverse Hankel transform with (p, m) -> (r, t) folded into the GEMM, one launch.
+        Equals partial_interp2spect followed by spect2interp (the z-FFT round trip is the
+        identity, main.py:741-766) without the two FFTs."""
+        self._need_gpu()
+        fi, _, nf, vec = self._group(fieldtype)
+        assert vec and nf <= self.NFx
+        import ctypes
+        lib, pa, st = _capi.lib(), _capi.ptr_array, _capi.stream()
+        scr_f = self._field_views(self.d_scratch, 0, nf)
+        out = self._field_views(self.d_interp, fi, nf)
+        mats = self._mats['vec_inv']
+        if fieldtype == 'EB':
+            mats = mats + mats
+        ins, in2, m1, m2, sgn = [], [], [], [], []
+        for j in range(nf):
+            if j % 3 == 2:                       # z component: plain transform
+                ins.append(scr_f[j]); in2.append(None); m1.append(mats[j]); m2.append(None)
+                sgn.append(0.)
+            else:                                # r = p' + m' ; t = i (p' - m')
+                jp = j - (j % 3)
+                ins.append(scr_f[jp]); in2.append(scr_f[jp + 1])
+                m1.append(mats[jp]); m2.append(mats[jp + 1])
+                sgn.append(1. if j % 3 == 0 else -1.)
+        _capi.check(lib.fb_hankel_pm_to_rt(
+            nf, pa(ins), pa(in2), (ctypes.c_double * nf)(*sgn), self.d_scratch.stride(0), pa(out),
+            self.d_interp.stride(0), pa(m1), pa(m2), 1.0, self.Nz, self.Nr, st), 'fb_hankel_pm_to_rt')
 
     # ---------------------------------------------------------------- solver steps
     def push(self, use_true_rho=False, check_exchanges=False):

@@ -392,6 +392,17 @@ class Simulation(object):
         partial-interp fields) and is skipped (difference ~1e-16 relative)."""
         fld = self.fld
         needs_partial = (self.comm.size > 1) or (self.comm.nz_damp != 0) or len(self.mirrors) > 0
+        if needs_partial and not self.mirrors:
+            # the (z-real, r-spectral) fields live in the scratch slab; after the exchange and
+            # the damping, the interpolation grid follows from them by the inverse Hankel
+            # transform alone: one 6*Nm-field FFT launch less than via the spectral fields
+            scr = fld.d_scratch
+            fld.spect2partial_interp('EB', to_scratch=True)
+            self.comm.exchange_fields(fld.interp, 'EB', 'replace', slab=scr)
+            self.comm.damp_EB_open_boundary(fld.interp, slab=scr)
+            fld.partial_interp2spect('EB', from_scratch=True)
+            fld.partial2interp('EB')
+            return
         if needs_partial:
             fld.spect2partial_interp('EB')
             self.comm.exchange_fields(fld.interp, 'EB', 'replace')

@@ -385,6 +385,17 @@ int fb_hankel_rt_to_pm_scaled(int njobs, const void *const *in, const void *cons
                               const double *const *out_row_scale,
                               const double *const *out_col_scale, double alpha, int Nz, int Nr,
                               void *stream);
+/* Backward counterpart: the Hankel transform of a vector field with (p, m) -> (r, t)
+ * (spectral_transformer.py:89-155 numba_pm_to_rt) folded into the GEMM.  Per job:
+ *   out = in . mat + sign (in2 . mat2), times i when sign < 0
+ * i.e. r = p . invM_p + m . invM_m (sign +1) and t = i (p . invM_p - m . invM_m) (sign -1);
+ * jobs with in2[j] == NULL are plain transforms (z components).  Used where the input is
+ * already in z-real space (after the guard-cell exchange, main.py:741-766), so that no
+ * further FFT is needed to reach the interpolation grid. */
+int fb_hankel_pm_to_rt(int njobs, const void *const *in, const void *const *in2,
+                       const double *pair_sign, long in_row_stride, void *const *out,
+                       long out_row_stride, const double *const *mat, const double *const *mat2,
+                       double alpha, int Nz, int Nr, void *stream);
 
 #ifdef __cplusplus
 }

@@ -874,3 +874,38 @@ def test_guard_buffers_and_damping(hip):
                                      hip.stream()), 'damp right')
     exp[Nz - 5:, f0:f0 + nf] *= damp_r[:, None, None]
     assert np.array_equal(host(slab), exp)
+
+
+@pytest.mark.parametrize('Nz,Nr', [(40, 24), (64, 128), (33, 70)])
+def test_hankel_pm_to_rt(hip, Nz, Nr):
+    """fb_hankel_pm_to_rt: r = p.Mp + m.Mm, t = i (p.Mp - m.Mm), z = z.M0 in one launch, on
+    slab views (inverse transform of a vector field taken from z-real space)."""
+    t = hip.torch()
+    rng = np.random.default_rng(12)
+    nf = 6
+    src = rng.normal(size=(Nz, nf, Nr)) + 1j * rng.normal(size=(Nz, nf, Nr))
+    mats = [rng.normal(size=(Nr, Nr)) for _ in range(nf)]
+    d_src = dev(hip, src)
+    d_out = t.zeros((Nz, nf + 1, Nr), dtype=t.complex128, device='cuda')
+    d_mats = [dev(hip, M) for M in mats]
+    ins, in2, m1, m2, sgn = [], [], [], [], []
+    for j in range(nf):
+        if j % 3 == 2:
+            ins.append(d_src[:, j, :]); in2.append(None); m1.append(d_mats[j]); m2.append(None); sgn.append(0.)
+        else:
+            jp = j - j % 3
+            ins.append(d_src[:, jp, :]); in2.append(d_src[:, jp + 1, :])
+            m1.append(d_mats[jp]); m2.append(d_mats[jp + 1]); sgn.append(1. if j % 3 == 0 else -1.)
+    outs = [d_out[:, j, :] for j in range(nf)]
+    import ctypes
+    hip.check(hip.lib().fb_hankel_pm_to_rt(
+        nf, hip.ptr_array(ins), hip.ptr_array(in2), (ctypes.c_double * nf)(*sgn), nf * Nr,
+        hip.ptr_array(outs), (nf + 1) * Nr, hip.ptr_array(m1), hip.ptr_array(m2), 1.0, Nz, Nr,
+        hip.stream()), 'fb_hankel_pm_to_rt')
+    got = host(d_out)
+    for g in range(nf // 3):
+        p_, m_, z_ = (src[:, 3 * g + k, :] @ mats[3 * g + k] for k in range(3))
+        assert rel_err(got[:, 3 * g, :], p_ + m_) < TOL
+        assert rel_err(got[:, 3 * g + 1, :], 1j * (p_ - m_)) < TOL
+        assert rel_err(got[:, 3 * g + 2, :], z_) < TOL
+    assert np.all(got[:, nf, :] == 0)
