@@ -78,11 +78,11 @@ constexpr size_t HK_LDS_BYTES = (size_t)2 * (HK_ABUF + HK_BBUF) * 8;
 //   (padded panels, conflict-free ds_read_b128 / ds_read_b64), so the vector-memory path
 //   only sees coalesced traffic and each matrix element is fetched once per workgroup.
 // DUAL (backward transform of a vector field, (p, m) -> (r, t) folded into the GEMM,
-// spectral_transformer.py:89-155): out = in . mat + sgn (in2 . mat2), K walked over both
-// products with one accumulator, then multiplied by i when sgn < 0:
-//   r = p' + m'      (in = p, in2 = m, sgn = +1)
-//   t = i (p' - m')  (in = p, in2 = m, sgn = -1)
-// in2 comes from Pr.in2, sgn from Pr.sgn, mat2 travels in Sc.sk; jobs with in2 == 0 are
+// spectral_transformer.py:89-155): a job with in2 != 0 computes BOTH p' = in . mat and
+// m' = in2 . mat2 (K walked over the first product, then over the second, two accumulator
+// sets - the same MFMA work as two plain jobs) and writes
+//   out = p' + m' (the r slot)  and  out2 = i (p' - m') (the t slot).
+// in2 comes from Pr.in2, mat2 travels in Sc.sk and out2 in Sc.fz; jobs with in2 == 0 are
 // plain transforms (the z components).
 template <bool SCALED, bool PAIRED, bool DUAL = false>
 __global__ __launch_bounds__(256) void k_hankel(HankelJobs J, HankelScales Sc, HankelPairs Pr, long irs,
@@ -92,8 +92,9 @@ __global__ __launch_bounds__(256) void k_hankel(HankelJobs J, HankelScales Sc, H
     const int job = blockIdx.z;
     const cplx *__restrict__ in = J.in[job];
     const cplx *__restrict__ in2 = (PAIRED || DUAL) ? Pr.in2[job] : nullptr;
-    const double psgn = (PAIRED || DUAL) ? Pr.sgn[job] : 0.;
+    const double psgn = PAIRED ? Pr.sgn[job] : 0.;
     const double *__restrict__ mat2 = DUAL ? Sc.sk[job] : nullptr;
+    cplx *__restrict__ out2 = DUAL ? (cplx *)const_cast<double *>(Sc.fz[job]) : nullptr;
     cplx *__restrict__ out = J.out[job];
     const double *__restrict__ mat = J.mat[job];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -102,11 +103,13 @@ __global__ __launch_bounds__(256) void k_hankel(HankelJobs J, HankelScales Sc, H
     const int zb = blockIdx.x * HK_TZ, n0 = blockIdx.y * 64;
     const double *sk = SCALED ? Sc.sk[job] : nullptr;
 
-    double4_t acc_re[2], acc_im[2];
+    double4_t acc_re[2], acc_im[2], acc2_re[2], acc2_im[2];
 #pragma unroll
     for (int t = 0; t < 2; t++) {
         acc_re[t] = (double4_t){0., 0., 0., 0.};
         acc_im[t] = (double4_t){0., 0., 0., 0.};
+        acc2_re[t] = (double4_t){0., 0., 0., 0.};
+        acc2_im[t] = (double4_t){0., 0., 0., 0.};
     }
     // staging registers: A chunk = 32 rows x 32 complex (4 per thread), B chunk = 32 x 64
     // doubles (8 per thread)
@@ -127,7 +130,6 @@ __global__ __launch_bounds__(256) void k_hankel(HankelJobs J, HankelScales Sc, H
             double2 v = make_double2(0., 0.);
             if (zz < Nz && k < Nr) {
                 v = *(const double2 *)(src + (long)zz * irs + k);
-                if (second) { v.x *= psgn; v.y *= psgn; }
                 if (PAIRED && in2) {
                     // numba_rt_to_pm: p = 0.5 (r - i t), m = 0.5 (r + i t)
                     const double2 w_ = *(const double2 *)(in2 + (long)zz * irs + k);
@@ -169,23 +171,27 @@ __global__ __launch_bounds__(256) void k_hankel(HankelJobs J, HankelScales Sc, H
         if (c + 1 < ntot) gload(c + 1);
         const double *A = hk_lds + cur * (HK_ABUF + HK_BBUF) + (wz * 16 + li) * HK_RSA;
         const double *B = hk_lds + cur * (HK_ABUF + HK_BBUF) + HK_ABUF + 32 * wn;
+        auto mma_chunk = [&](double4_t *are, double4_t *aim) {
 #pragma unroll
-        for (int s = 0; s < HK_KC / 4; s++) {
-            const double2 a = *(const double2 *)(A + 2 * (4 * s + lk));
-            const double *brow = B + (4 * s + lk) * HK_RSB + li;
-            double b[2];
+            for (int s = 0; s < HK_KC / 4; s++) {
+                const double2 a = *(const double2 *)(A + 2 * (4 * s + lk));
+                const double *brow = B + (4 * s + lk) * HK_RSB + li;
+                double b[2];
 #pragma unroll
-            for (int t = 0; t < 2; t++) b[t] = brow[16 * t];
+                for (int t = 0; t < 2; t++) b[t] = brow[16 * t];
 #pragma unroll
-            for (int t = 0; t < 2; t++) {
-                acc_re[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b[t], acc_re[t], 0, 0, 0);
-                acc_im[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b[t], acc_im[t], 0, 0, 0);
+                for (int t = 0; t < 2; t++) {
+                    are[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b[t], are[t], 0, 0, 0);
+                    aim[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b[t], aim[t], 0, 0, 0);
+                }
             }
-        }
+        };
+        if (DUAL && c >= nchunks) mma_chunk(acc2_re, acc2_im);
+        else mma_chunk(acc_re, acc_im);
         if (c + 1 < ntot) lstore(cur ^ 1);
         __syncthreads();
     }
-    const bool times_i = DUAL && in2 && psgn < 0.;
+    const bool pair = DUAL && in2;
     const int z0 = zb + wz * 16;
     const double *fz = SCALED ? Sc.fz[job] : nullptr;
     const double *fr = SCALED ? Sc.fr[job] : nullptr;
@@ -201,8 +207,15 @@ __global__ __launch_bounds__(256) void k_hankel(HankelJobs J, HankelScales Sc, H
             if (zz < Nz) {
                 double cz = cn;
                 if (SCALED && fz) cz = fz[zz] * cn;     // fz[iz]*fr[ir]*F as in numba_filter_*
-                const double2 val = make_double2(cz * acc_re[t][r], cz * acc_im[t][r]);
-                *(double2 *)(out + (long)zz * ors + n) = times_i ? make_double2(-val.y, val.x) : val;
+                if (pair) {
+                    const double pr = cz * acc_re[t][r], pi = cz * acc_im[t][r];
+                    const double mr = cz * acc2_re[t][r], mi = cz * acc2_im[t][r];
+                    *(double2 *)(out + (long)zz * ors + n) = make_double2(pr + mr, pi + mi);
+                    *(double2 *)(out2 + (long)zz * ors + n) = make_double2(-(pi - mi), pr - mr);
+                } else {
+                    *(double2 *)(out + (long)zz * ors + n) =
+                        make_double2(cz * acc_re[t][r], cz * acc_im[t][r]);
+                }
             }
         }
     }
@@ -212,7 +225,7 @@ static int launch(int njobs, const void *const *in, long irs, void *const *out, 
                   const double *const *mat, const double *const *sk, const double *const *fz,
                   const double *const *fr, double alpha, int Nz, int Nr, hipStream_t s,
                   const void *const *in2 = nullptr, const double *pair_sign = nullptr,
-                  const double *const *mat2 = nullptr)
+                  const double *const *mat2 = nullptr, void *const *out2 = nullptr)
 {
     const bool dual = mat2 != nullptr;             // (p, m) -> (r, t) on the output side
     const bool scaled = !dual && (sk || fz || fr || in2);
@@ -230,7 +243,7 @@ static int launch(int njobs, const void *const *in, long irs, void *const *out, 
             J.out[j] = v ? (cplx *)out[j0 + j] : nullptr;
             J.mat[j] = v ? mat[j0 + j] : nullptr;
             Sc.sk[j] = (v && dual) ? mat2[j0 + j] : ((v && sk) ? sk[j0 + j] : nullptr);
-            Sc.fz[j] = (v && fz) ? fz[j0 + j] : nullptr;
+            Sc.fz[j] = (v && dual) ? (const double *)out2[j0 + j] : ((v && fz) ? fz[j0 + j] : nullptr);
             Sc.fr[j] = (v && fr) ? fr[j0 + j] : nullptr;
         }
         dim3 grid((Nz + HK_TZ - 1) / HK_TZ, (Nr + 63) / 64, nj);
@@ -303,18 +316,21 @@ extern "C" int fb_hankel_rt_to_pm_scaled(int njobs, const void *const *in, const
 }
 
 extern "C" int fb_hankel_pm_to_rt(int njobs, const void *const *in, const void *const *in2,
-                                  const double *pair_sign, long in_row_stride, void *const *out,
+                                  long in_row_stride, void *const *out, void *const *out2,
                                   long out_row_stride, const double *const *mat,
                                   const double *const *mat2, double alpha, int Nz, int Nr,
                                   void *stream)
 {
     if (njobs <= 0) return 0;
-    if (!in2 || !pair_sign || !mat2) {
-        set_error("fb_hankel_pm_to_rt", "in2, pair_sign and mat2 are required");
+    if (!in2 || !out2 || !mat2) {
+        set_error("fb_hankel_pm_to_rt", "in2, out2 and mat2 are required");
         return -1;
     }
     for (int j = 0; j < njobs; j++)
-        if (in2[j] && !mat2[j]) { set_error("fb_hankel_pm_to_rt", "job with in2 but no mat2"); return -1; }
+        if (in2[j] && (!mat2[j] || !out2[j])) {
+            set_error("fb_hankel_pm_to_rt", "pair job without mat2 / out2");
+            return -1;
+        }
     return launch(njobs, in, in_row_stride, out, out_row_stride, mat, nullptr, nullptr, nullptr,
-                  alpha, Nz, Nr, (hipStream_t)stream, in2, pair_sign, mat2);
+                  alpha, Nz, Nr, (hipStream_t)stream, in2, nullptr, mat2, out2);
 }

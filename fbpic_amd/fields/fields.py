@@ -368,25 +368,23 @@ class Fields(object):
         self._need_gpu()
         fi, _, nf, vec = self._group(fieldtype)
         assert vec and nf <= self.NFx
-        import ctypes
         lib, pa, st = _capi.lib(), _capi.ptr_array, _capi.stream()
         scr_f = self._field_views(self.d_scratch, 0, nf)
         out = self._field_views(self.d_interp, fi, nf)
         mats = self._mats['vec_inv']
         if fieldtype == 'EB':
             mats = mats + mats
-        ins, in2, m1, m2, sgn = [], [], [], [], []
-        for j in range(nf):
-            if j % 3 == 2:                       # z component: plain transform
-                ins.append(scr_f[j]); in2.append(None); m1.append(mats[j]); m2.append(None)
-                sgn.append(0.)
-            else:                                # r = p' + m' ; t = i (p' - m')
-                jp = j - (j % 3)
-                ins.append(scr_f[jp]); in2.append(scr_f[jp + 1])
-                m1.append(mats[jp]); m2.append(mats[jp + 1])
-                sgn.append(1. if j % 3 == 0 else -1.)
+        ins, in2, o1, o2, m1, m2 = [], [], [], [], [], []
+        for g in range(0, nf, 3):
+            # pair job: (p, m) -> (r, t); then the z component as a plain job
+            ins += [scr_f[g], scr_f[g + 2]]
+            in2 += [scr_f[g + 1], None]
+            o1 += [out[g], out[g + 2]]
+            o2 += [out[g + 1], None]
+            m1 += [mats[g], mats[g + 2]]
+            m2 += [mats[g + 1], None]
         _capi.check(lib.fb_hankel_pm_to_rt(
-            nf, pa(ins), pa(in2), (ctypes.c_double * nf)(*sgn), self.d_scratch.stride(0), pa(out),
+            len(ins), pa(ins), pa(in2), self.d_scratch.stride(0), pa(o1), pa(o2),
             self.d_interp.stride(0), pa(m1), pa(m2), 1.0, self.Nz, self.Nr, st), 'fb_hankel_pm_to_rt')
 
     # ---------------------------------------------------------------- solver steps

@@ -386,14 +386,15 @@ int fb_hankel_rt_to_pm_scaled(int njobs, const void *const *in, const void *cons
                               const double *const *out_col_scale, double alpha, int Nz, int Nr,
                               void *stream);
 /* Backward counterpart: the Hankel transform of a vector field with (p, m) -> (r, t)
- * (spectral_transformer.py:89-155 numba_pm_to_rt) folded into the GEMM.  Per job:
- *   out = in . mat + sign (in2 . mat2), times i when sign < 0
- * i.e. r = p . invM_p + m . invM_m (sign +1) and t = i (p . invM_p - m . invM_m) (sign -1);
- * jobs with in2[j] == NULL are plain transforms (z components).  Used where the input is
- * already in z-real space (after the guard-cell exchange, main.py:741-766), so that no
- * further FFT is needed to reach the interpolation grid. */
+ * (spectral_transformer.py:89-155 numba_pm_to_rt) folded into the GEMM.  A job with
+ * in2[j] != NULL transforms a (p, m) pair, p' = in . mat and m' = in2 . mat2, and writes
+ *   out = p' + m'  (r)   and   out2 = i (p' - m')  (t);
+ * jobs with in2[j] == NULL are plain transforms (z components, out2 unused).  Same MFMA
+ * work as the plain transforms.  Used where the input is already in z-real space (after
+ * the guard-cell exchange, main.py:741-766), so that no further FFT is needed to reach the
+ * interpolation grid. */
 int fb_hankel_pm_to_rt(int njobs, const void *const *in, const void *const *in2,
-                       const double *pair_sign, long in_row_stride, void *const *out,
+                       long in_row_stride, void *const *out, void *const *out2,
                        long out_row_stride, const double *const *mat, const double *const *mat2,
                        double alpha, int Nz, int Nr, void *stream);
 

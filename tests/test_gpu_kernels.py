@@ -888,19 +888,18 @@ def test_hankel_pm_to_rt(hip, Nz, Nr):
     d_src = dev(hip, src)
     d_out = t.zeros((Nz, nf + 1, Nr), dtype=t.complex128, device='cuda')
     d_mats = [dev(hip, M) for M in mats]
-    ins, in2, m1, m2, sgn = [], [], [], [], []
-    for j in range(nf):
-        if j % 3 == 2:
-            ins.append(d_src[:, j, :]); in2.append(None); m1.append(d_mats[j]); m2.append(None); sgn.append(0.)
-        else:
-            jp = j - j % 3
-            ins.append(d_src[:, jp, :]); in2.append(d_src[:, jp + 1, :])
-            m1.append(d_mats[jp]); m2.append(d_mats[jp + 1]); sgn.append(1. if j % 3 == 0 else -1.)
     outs = [d_out[:, j, :] for j in range(nf)]
-    import ctypes
+    ins, in2, o1, o2, m1, m2 = [], [], [], [], [], []
+    for g in range(0, nf, 3):
+        ins += [d_src[:, g, :], d_src[:, g + 2, :]]
+        in2 += [d_src[:, g + 1, :], None]
+        o1 += [outs[g], outs[g + 2]]
+        o2 += [outs[g + 1], None]
+        m1 += [d_mats[g], d_mats[g + 2]]
+        m2 += [d_mats[g + 1], None]
     hip.check(hip.lib().fb_hankel_pm_to_rt(
-        nf, hip.ptr_array(ins), hip.ptr_array(in2), (ctypes.c_double * nf)(*sgn), nf * Nr,
-        hip.ptr_array(outs), (nf + 1) * Nr, hip.ptr_array(m1), hip.ptr_array(m2), 1.0, Nz, Nr,
+        len(ins), hip.ptr_array(ins), hip.ptr_array(in2), nf * Nr, hip.ptr_array(o1),
+        hip.ptr_array(o2), (nf + 1) * Nr, hip.ptr_array(m1), hip.ptr_array(m2), 1.0, Nz, Nr,
         hip.stream()), 'fb_hankel_pm_to_rt')
     got = host(d_out)
     for g in range(nf // 3):
