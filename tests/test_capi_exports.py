@@ -79,3 +79,26 @@ def test_cpu_baseline_uses_the_cores_it_is_given():
     import bench
     n = bench.available_cores()
     assert 1 <= n <= len(__import__('os').sched_getaffinity(0))
+
+
+def test_bench_roofline_object_is_stable_between_tied_kernels():
+    """bench.roofline(): per-entry-point table + the entry point the `roofline` object
+    describes.  gather+push, the J deposition and the sort take the same time within noise;
+    the object names gather+push whenever it is within 5 % of the longest, else the longest.
+    The PMC traffic comes from the newest profiles/r*_pmc_* pair."""
+    import bench
+    a = [0, 0, 4194304] + [None] * 30          # args of a launch: a[2] = number of particles
+    for g, d, s, expect in ((0.127, 0.1276, 0.101, 'fb_gather_push'),
+                            (0.127, 0.120, 0.1271, 'fb_gather_push'),
+                            (0.110, 0.130, 0.100, 'fb_deposit_J_rank_next')):
+        kern = {'fb_gather_push': [(g, a)] * 10, 'fb_deposit_J_rank_next': [(d, a)] * 10,
+                'fb_push_x_bin_sort_particles': [(s, a)] * 10, 'fb_erase': [(0.005, a)] * 10}
+        roof, table = bench.roofline(kern)
+        assert roof['kernel'] == expect
+        assert roof['bound'] == 'hbm' and roof['peak'] == 8000.0 and roof['unit'] == 'GB/s'
+        assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-12
+        assert set(table) == set(kern) and 'frac' not in table['fb_erase']
+    roof, _ = bench.roofline({'fb_gather_push': [(0.127, a)] * 3})
+    # 112 B per particle when E, B stay in registers (a[19] is None)
+    assert abs(roof['achieved'] - 112 * 4194304 / 0.127e-3 / 1e9) < 1e-6
+    assert roof['traffic'] is None or roof['traffic'] > 4e8
