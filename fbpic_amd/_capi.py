@@ -10,7 +10,8 @@ import os
 from ctypes import c_double as D, c_int as I, c_long as L, c_void_p as P, c_size_t as Z
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libfbpic_amd.so')
+# FBPIC_AMD_LIB: developer override (A/B timing of two builds of the library)
+LIB_PATH = os.environ.get('FBPIC_AMD_LIB') or os.path.join(_HERE, 'csrc', 'libfbpic_amd.so')
 _lib = None
 
 _PP = ctypes.POINTER(P)   # host array of device pointers

@@ -147,7 +147,18 @@ constexpr int G_NOKEY = -0x40000000;
 
 // NMT > 0: number of modes known at compile time (mode loop unrolled, exptheta_0 = 1 folded
 // away); NMT = 0: run-time Nm.
-// (forcing a higher occupancy with amdgpu_waves_per_eu spills: measured 1.2x-4x slower)
+//
+// The kernel is bound by latency and instruction issue, not by HBM (rocprofv3 + ISA census,
+// DESIGN.md section 6), so the staging of a chunk is arranged as ONE round trip to L2:
+//   * the keys of the segments are wave-uniform scalars (v_readlane of the start lanes found
+//     by the ballot): no LDS exchange, row/column arithmetic partly on the scalar unit;
+//   * a lane's role in the staging (which field / node it fetches, its pointer and its
+//     below-axis sign) does not depend on the chunk and is set up once per wave;
+//   * the loads of all segments of a round are issued back to back, and the work that does
+//     not need them (1/r, cos, sin, the products of the shape factors) sits between the
+//     issue and the first use.
+// (forcing 5 / 6 waves per SIMD with amdgpu_waves_per_eu: 107 VGPRs -> spills, measured
+// 94 / 147 us against 96 us for the fused Nm = 2 kernel)
 template <int SHAPE, int NMT>
 __global__ __launch_bounds__(256) void k_gather(int Nm_arg, long n,
         const double *__restrict__ x, const double *__restrict__ y,
@@ -156,7 +167,7 @@ __global__ __launch_bounds__(256) void k_gather(int Nm_arg, long n,
         GatherGrids G, long rs,
         double *__restrict__ Ex, double *__restrict__ Ey, double *__restrict__ Ez,
         double *__restrict__ Bx, double *__restrict__ By, double *__restrict__ Bz,
-        int maxseg, int chunks_per_wave, PushArgs PA)
+        int maxseg_arg, int chunks_per_wave, PushArgs PA)
 {
     constexpr int S = GShape<SHAPE>::S, OFF = GShape<SHAPE>::OFF;
     const int Nm = NMT ? NMT : Nm_arg;
@@ -165,9 +176,29 @@ __global__ __launch_bounds__(256) void k_gather(int Nm_arg, long n,
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar loop bounds
     const int NV = S * S * 6 * Nm;                 // complex node values of one segment
     const int PSTR = 2 * NV + 2;                   // panel stride in doubles (16-B pad)
-    double *panel = lds + (size_t)wave * ((size_t)maxseg * PSTR + 2 * 8);
-    int *segkz = (int *)(panel + (size_t)maxseg * PSTR);
-    int *segkr = segkz + 8;
+    // FAST: one node value per lane and segment (linear shape, Nm <= 2)
+    constexpr bool FAST = NMT > 0 && S * S * 6 * NMT <= 64;
+    constexpr int NVL = NMT ? (S * S * 6 * NMT + 63) / 64 : 1;   // node values per lane
+    const int maxseg = FAST ? 4 : maxseg_arg;
+    double *panel = lds + (size_t)wave * ((size_t)maxseg * PSTR);
+
+    // staging role of this lane, FAST path: node value o = lane of every segment
+    bool st_on = false;
+    int st_jr = 0, st_jz = 0;
+    const cplx *st_ptr = nullptr;
+    double st_sgn = 1.;
+    if constexpr (FAST) {
+        st_on = lane < S * S * 6 * NMT;
+        const int o = st_on ? lane : 0;
+        st_jr = o % S; st_jz = (o / S) % S;
+        const int f = o / (S * S);
+        st_ptr = G.g[f];
+        // mirror below the axis: -(-1)^m for r,t components, +(-1)^m for z
+        // (inline_functions.py:70-79, 151-158)
+        const int m_ = f / 6, k_ = f - 6 * m_;
+        const double flip = m1pow(m_);
+        st_sgn = (k_ % 3 == 2) ? flip : -flip;
+    }
 
     const long chunk0 = (xcd_block_id() * nwaves + wave) * chunks_per_wave;
     // software pipeline: the particle coordinates of chunk ch+1 are requested before the
@@ -190,11 +221,9 @@ __global__ __launch_bounds__(256) void k_gather(int Nm_arg, long n,
             while (zj < PA.wzmin) zj += l_box;
         }
         if (ch + 1 < chunks_per_wave && i + 64 < n) { xn = x[i + 64]; yn = y[i + 64]; zn = z[i + 64]; }
-        double pux = 0., puy = 0., puz = 0., pig = 0.;
-        if (PA.ux && act) { pux = PA.ux[i]; puy = PA.uy[i]; puz = PA.uz[i]; pig = PA.ig[i]; }
+        double rj = 0.;
         if (act) {
-            const double rj = sqrt(xj * xj + yj * yj);
-            if (rj != 0.) { double invr = 1. / rj; cs = xj * invr; sn = yj * invr; }
+            rj = sqrt(xj * xj + yj * yj);
             const double r_cell = invdr * (rj - rmin) - 0.5;
             const double z_cell = invdz * (zj - zmin) - 0.5;
             inside = rj < rmax_gather;
@@ -227,68 +256,92 @@ __global__ __launch_bounds__(256) void k_gather(int Nm_arg, long n,
         const unsigned long long starts = __ballot(is_start);
         const int nseg = __popcll(starts);
         const int myseg = __popcll(starts & ((2ull << lane) - 1ull)) - 1;   // valid if inside
+        unsigned long long rem = starts;          // start lanes of the segments not yet staged
         double F[6] = {0., 0., 0., 0., 0., 0.};
-        for (int s0 = 0; s0 < nseg; s0 += maxseg) {
-            const int ns = min(maxseg, nseg - s0);
-            // publish the keys of this round's segments
-            if (is_start && myseg >= s0 && myseg < s0 + ns) {
-                segkz[myseg - s0] = kz;
-                segkr[myseg - s0] = kr;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // stage node values: lane = (segment, field, jz, jr)
-            if (NMT > 0 && S * S * 6 * NMT <= 64) {
-                // one node value per lane and segment: the loads of up to 4 segments are
-                // issued together (independent L2 round trips) before any is written to LDS
-                const int o = lane;
-                const bool lane_on = o < NV;
-                const int jr = o % S, jz = (o / S) % S, f = lane_on ? o / (S * S) : 0;
-                const int m_ = f / 6, k_ = f - 6 * m_;
-                const double flip = m1pow(m_);
-                const double sgn_below = (k_ % 3 == 2) ? flip : -flip;
-                for (int sg0 = 0; sg0 < ns; sg0 += 4) {
-                    double2 vals[4];
+
+        // ---- staging of one round of segments: issue (loads in flight) / commit (to LDS)
+        double2 vals[FAST ? 4 : NVL];
+        double vsgn[FAST ? 4 : NVL];
+        auto node_addr = [&](const cplx *fp, int skz, int skr, int jz, int jr, double sgn_below,
+                             double &sgn) -> const cplx * {
+            int row = skz + jz, col = skr + jr;
+            if (row < 0) row += Nz; else if (row > Nz - 1) row -= Nz;
+            sgn = 1.;
+            if (col < 0) { col = -col - 1; sgn = sgn_below; }
+            else if (col > Nr - 1) col = Nr - 1;
+            return fp + (long)row * rs + col;
+        };
+        auto next_key = [&](int &skz, int &skr) {
+            const int l = __builtin_ctzll(rem);
+            rem &= rem - 1ull;
+            skz = __builtin_amdgcn_readlane(kz, l);
+            skr = __builtin_amdgcn_readlane(kr, l);
+        };
+        auto issue_fast = [&](int ns) {
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        vals[u] = make_double2(0., 0.);
-                        if (sg0 + u < ns && lane_on) {
-                            int row = segkz[sg0 + u] + jz, col = segkr[sg0 + u] + jr;
-                            if (row < 0) row += Nz; else if (row > Nz - 1) row -= Nz;
-                            double sgn = 1.;
-                            if (col < 0) { col = -col - 1; sgn = sgn_below; }
-                            else if (col > Nr - 1) col = Nr - 1;
-                            double2 v = ldc(G.g[f] + (long)row * rs + col);
-                            v.x *= sgn; v.y *= sgn;
-                            vals[u] = v;
+            for (int u = 0; u < 4; u++) {
+                vals[u] = make_double2(0., 0.);
+                vsgn[u] = 1.;
+                if (u < ns) {
+                    int skz, skr;
+                    next_key(skz, skr);
+                    if (st_on) vals[u] = ldc(node_addr(st_ptr, skz, skr, st_jz, st_jr, st_sgn, vsgn[u]));
+                }
+            }
+        };
+        auto commit_fast = [&](int ns) {
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (u < ns && st_on) {
+                    double2 v = vals[u];
+                    v.x *= vsgn[u]; v.y *= vsgn[u];
+                    *(double2 *)(panel + (size_t)u * PSTR + 2 * lane) = v;
+                }
+        };
+        // general path: NV > 64 node values per segment, one segment at a time
+        auto stage_general = [&](int ns) {
+            for (int sg = 0; sg < ns; sg++) {
+                int skz, skr;
+                next_key(skz, skr);
+                if constexpr (NMT > 0) {
+#pragma unroll
+                    for (int j = 0; j < NVL; j++) {
+                        const int o = lane + 64 * j;
+                        vals[j] = make_double2(0., 0.);
+                        vsgn[j] = 1.;
+                        if (o < NV) {
+                            const int jr = o % S, jz = (o / S) % S, f = o / (S * S);
+                            const int m_ = f / 6, k_ = f - 6 * m_;
+                            const double flip = m1pow(m_);
+                            vals[j] = ldc(node_addr(G.g[f], skz, skr, jz, jr,
+                                                    (k_ % 3 == 2) ? flip : -flip, vsgn[j]));
                         }
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; u++)
-                        if (sg0 + u < ns && lane_on)
-                            *(double2 *)(panel + (size_t)(sg0 + u) * PSTR + 2 * o) = vals[u];
+                    for (int j = 0; j < NVL; j++) {
+                        const int o = lane + 64 * j;
+                        if (o < NV) {
+                            double2 v = vals[j];
+                            v.x *= vsgn[j]; v.y *= vsgn[j];
+                            *(double2 *)(panel + (size_t)sg * PSTR + 2 * o) = v;
+                        }
+                    }
+                } else {
+                    for (int o = lane; o < NV; o += 64) {
+                        const int jr = o % S, jz = (o / S) % S, f = o / (S * S);
+                        const int m_ = f / 6, k_ = f - 6 * m_;
+                        const double flip = m1pow(m_);
+                        double sgn;
+                        double2 v = ldc(node_addr(G.g[f], skz, skr, jz, jr,
+                                                  (k_ % 3 == 2) ? flip : -flip, sgn));
+                        v.x *= sgn; v.y *= sgn;
+                        *(double2 *)(panel + (size_t)sg * PSTR + 2 * o) = v;
+                    }
                 }
-            } else
-            for (int sg = 0; sg < ns; sg++)
-            for (int o = lane; o < NV; o += 64) {
-                const int jr = o % S, jz = (o / S) % S, f = o / (S * S);
-                int row = segkz[sg] + jz, col = segkr[sg] + jr;
-                if (row < 0) row += Nz; else if (row > Nz - 1) row -= Nz;
-                double sgn = 1.;
-                if (col < 0) {
-                    // mirror below the axis: -(-1)^m for r,t components, +(-1)^m for z
-                    // (inline_functions.py:70-79, 151-158)
-                    col = -col - 1;
-                    const int m = f / 6, k = f - 6 * m;
-                    const double flip = m1pow(m);
-                    sgn = (k % 3 == 2) ? flip : -flip;
-                } else if (col > Nr - 1) col = Nr - 1;
-                double2 v = ldc(G.g[f] + (long)row * rs + col);
-                v.x *= sgn; v.y *= sgn;
-                *(double2 *)(panel + (size_t)sg * PSTR + 2 * o) = v;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+        };
+        // ---- stencil evaluation of the lanes whose segment is in the staged round
+        auto evaluate = [&](int s0, int ns) {
             if (inside && myseg >= s0 && myseg < s0 + ns) {
                 const double *P = panel + (size_t)(myseg - s0) * PSTR;
                 double er = 1., ei = 0.;            // exptheta_m = (cos - i sin)^m
@@ -329,6 +382,24 @@ __global__ __launch_bounds__(256) void k_gather(int Nm_arg, long n,
                     er = nr_; ei = ni_;
                 }
             }
+        };
+
+        const int ns0 = min(maxseg, nseg);
+        if constexpr (FAST) issue_fast(ns0);
+        // independent of the staged values: overlaps the L2 round trip of the loads above
+        if (act && rj != 0.) { const double invr = 1. / rj; cs = xj * invr; sn = yj * invr; }
+        if constexpr (FAST) commit_fast(ns0); else stage_general(ns0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        evaluate(0, ns0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int s0 = maxseg; s0 < nseg; s0 += maxseg) {     // more segments than one round holds
+            const int ns = min(maxseg, nseg - s0);
+            if constexpr (FAST) { issue_fast(ns); commit_fast(ns); } else stage_general(ns);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            evaluate(s0, ns);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
@@ -337,6 +408,9 @@ __global__ __launch_bounds__(256) void k_gather(int Nm_arg, long n,
             const double bx = cs * F[3] - sn * F[4], by = sn * F[3] + cs * F[4], bz = F[5];
             if (Ex) { Ex[i] = ex; Ey[i] = ey; Ez[i] = ez; Bx[i] = bx; By[i] = by; Bz[i] = bz; }
             if (PA.ux) {
+                // momenta are loaded here, not at the top of the chunk: 8 VGPRs less across the
+                // stencil phase; the other waves of the SIMD cover the latency (measured: -3 %)
+                double pux = PA.ux[i], puy = PA.uy[i], puz = PA.uz[i], pig = PA.ig[i];
                 vay(pux, puy, puz, pig, ex, ey, ez, bx, by, bz, PA.econst, PA.bconst);
                 PA.ux[i] = pux; PA.uy[i] = puy; PA.uz[i] = puz; PA.ig[i] = pig;
                 if (PA.chdt != 0.) {
@@ -427,7 +501,8 @@ static int launch_gather(int shape, int Nm, long n, const double *x, const doubl
     int maxseg = (int)((16 * 1024) / panel_bytes);
     if (maxseg > 8) maxseg = 8;
     if (maxseg < 1) maxseg = 1;
-    const size_t wave_bytes = maxseg * panel_bytes + 2 * 8 * 8;
+    if (S * S * 6 * Nm <= 64) maxseg = 4;      // FAST path of k_gather: rounds of 4 segments
+    const size_t wave_bytes = maxseg * panel_bytes;
     int nwaves = 4;
     while (nwaves > 1 && wave_bytes * nwaves > 64 * 1024) nwaves >>= 1;
     const long nchunks = (n + 63) / 64;
