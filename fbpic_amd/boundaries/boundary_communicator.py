@@ -22,6 +22,12 @@ def _dist():
     return dist
 
 
+# (rank, size) or None.  Host-side construction of the grids and tables of ONE slab of a
+# decomposed run without torch.distributed: used by the tests to build the multi-slab CPU
+# oracle's inputs in a single process.  Such an object cannot exchange anything.
+VIRTUAL_WORLD = None
+
+
 class BoundaryCommunicator(object):
     def __init__(self, Nz, zmin, zmax, Nr, rmax, Nm, dt, v_comoving, use_galilean,
                  boundaries, n_order, n_guard, n_damp, cdt_over_dr, n_inject=None,
@@ -47,7 +53,9 @@ class BoundaryCommunicator(object):
         self.use_all_mpi_ranks = use_all_mpi_ranks
         # one rank per GPU: torch.distributed takes the place of mpi4py
         dist = _dist()
-        if use_all_mpi_ranks and dist.is_available() and dist.is_initialized():
+        if VIRTUAL_WORLD is not None:
+            self.rank, self.size = VIRTUAL_WORLD
+        elif use_all_mpi_ranks and dist.is_available() and dist.is_initialized():
             self.rank = dist.get_rank()
             self.size = dist.get_world_size()
         else:
@@ -210,27 +218,25 @@ class BoundaryCommunicator(object):
                 _capi.ptr(dr), 0 if dr is None else dr.shape[0], slab.shape[0], _capi.stream())
             _capi.check(rc, 'fb_damp_rows')
             return
+        # per-array path (a subset of the modes, or arrays that are not the Fields slab)
+        if not hasattr(interp[0].Er, 'is_cuda'):
+            raise _capi.BackendError('damp_EB_open_boundary: the fields are host arrays; fbpic_amd '
+                                     'only computes on the GPU (send_fields_to_gpu() first).')
+        dev = interp[0].Er.device
         if self.left_proc is None:
             if self.d_left_damp is None:
-                self.d_left_damp = t.as_tensor(self.left_damp, device=interp[0].Er.device)
+                self.d_left_damp = t.as_tensor(self.left_damp, device=dev)
             nd = self.d_left_damp.shape[0]
-            if slab is not None:
-                slab[:nd] *= self.d_left_damp[:, None, None]
-            else:
-                for g in interp:
-                    for k in names:
-                        getattr(g, k)[:nd, :] *= self.d_left_damp[:, None]
+            for g in interp:
+                for k in names:
+                    getattr(g, k)[:nd, :] *= self.d_left_damp[:, None]
         if self.right_proc is None:
             if self.d_right_damp is None:
-                self.d_right_damp = t.as_tensor(self.right_damp[::-1].copy(),
-                                                device=interp[0].Er.device)
+                self.d_right_damp = t.as_tensor(self.right_damp[::-1].copy(), device=dev)
             nd = self.d_right_damp.shape[0]
-            if slab is not None:
-                slab[-nd:] *= self.d_right_damp[:, None, None]
-            else:
-                for g in interp:
-                    for k in names:
-                        getattr(g, k)[-nd:, :] *= self.d_right_damp[:, None]
+            for g in interp:
+                for k in names:
+                    getattr(g, k)[-nd:, :] *= self.d_right_damp[:, None]
 
     # ---------------------------------------------------------------- field exchange
     def exchange_fields(self, interp, fldtype, method, slab=None):
@@ -283,6 +289,9 @@ class BoundaryCommunicator(object):
                         'fb_guard_buffers')
             return
         targets = [getattr(g, k) for g in interp for k in names]
+        if not all(hasattr(a, 'is_cuda') for a in targets):
+            raise _capi.BackendError('exchange_fields: the fields are on the host; fbpic_amd only '
+                                     'computes on device (or, in the CPU tests, torch) tensors.')
         send_l = t.stack([a[s_l] for a in targets]).contiguous() if has_l else None
         send_r = t.stack([a[s_r] for a in targets]).contiguous() if has_r else None
         recv_l = t.empty_like(send_l) if has_l else None

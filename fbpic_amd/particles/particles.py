@@ -105,24 +105,47 @@ class Particles(object):
 
     # ---------------------------------------------------------------- host <-> device
     def _alloc_device_helpers(self):
+        """Device-only helper buffers.  They are kept with ~6 % of headroom and re-used while the
+        particle number fits: a hand-over that moves a few particles between ranks (every
+        `exchange_period` steps) does not reallocate 14 N doubles + the sort workspace."""
         t = _capi.torch()
         dev = _capi.require_device()
         Nz, Nr = self.grid_shape
         n = self.Ntot
         ncell = Nz * (Nr + 1)
-        self.cell_idx = t.empty(n, dtype=t.int32, device=dev)
-        self.sorted_idx = t.empty(n, dtype=t.int32, device=dev)
-        self._cell_idx_alt = t.empty(n, dtype=t.int32, device=dev)
-        self._sorted_idx_alt = t.empty(n, dtype=t.int32, device=dev)
-        self.prefix_sum = t.zeros(ncell, dtype=t.int32, device=dev)
-        self._alt = [t.empty(n, dtype=t.float64, device=dev) for _ in range(14)]
+        cap = n + n // 16 + 1024
+
+        def fit(old, dtype, itemsize):
+            # a length-n tensor on the storage of `old` when it is large enough
+            if old is not None and old.device == dev and old.dtype == dtype \
+                    and old.untyped_storage().nbytes() >= n * itemsize \
+                    and old.untyped_storage().nbytes() <= 2 * cap * itemsize + 65536:
+                return t.empty(0, dtype=dtype, device=dev).set_(old.untyped_storage(), 0, (n,))
+            return t.empty(cap, dtype=dtype, device=dev)[:n]
+        self.cell_idx = fit(self.cell_idx, t.int32, 4)
+        self.sorted_idx = fit(self.sorted_idx, t.int32, 4)
+        self._cell_idx_alt = fit(getattr(self, '_cell_idx_alt', None), t.int32, 4)
+        self._sorted_idx_alt = fit(getattr(self, '_sorted_idx_alt', None), t.int32, 4)
+        if self.prefix_sum is None or self.prefix_sum.shape[0] != ncell or self.prefix_sum.device != dev:
+            self.prefix_sum = t.zeros(ncell, dtype=t.int32, device=dev)
+        olds = self._alt if self._alt is not None else [None] * 14
+        self._alt = [fit(o, t.float64, 8) for o in olds]
         self.sorting_buffer = self._alt[0]
         nbytes = max(int(_capi.lib().fb_sort_workspace_bytes(n, ncell)),
                      int(_capi.lib().fb_bin_sort_workspace_bytes(n, ncell)))
-        self._sort_ws = t.empty(nbytes, dtype=t.uint8, device=dev)
-        self._counts_clean = False       # per-cell counters of the workspace known to be zero
-        self._nflush = t.zeros(1024, dtype=t.int64, device=dev)
-        self._nflush_host = t.zeros(1024, dtype=t.int64).pin_memory()
+        if self._sort_ws is None or self._sort_ws.shape[0] < nbytes or self._sort_ws.device != dev \
+                or getattr(self, '_sort_ws_n', -1) != n:
+            # the workspace layout depends on n (per-particle cell and rank arrays): when n
+            # changes the per-cell counters move, so they are no longer known to be zero
+            nb_cap = max(int(_capi.lib().fb_sort_workspace_bytes(cap, ncell)),
+                         int(_capi.lib().fb_bin_sort_workspace_bytes(cap, ncell)), nbytes)
+            if self._sort_ws is None or self._sort_ws.shape[0] < nbytes or self._sort_ws.device != dev:
+                self._sort_ws = t.empty(nb_cap, dtype=t.uint8, device=dev)
+            self._sort_ws_n = n
+            self._counts_clean = False       # per-cell counters of the workspace known to be zero
+        if getattr(self, '_nflush', None) is None or self._nflush.device != dev:
+            self._nflush = t.zeros(1024, dtype=t.int64, device=dev)
+            self._nflush_host = t.zeros(1024, dtype=t.int64).pin_memory()
         self._runs_after_sort = None
         self._runs_latest = None
         self._stat_pending = None
