@@ -415,6 +415,11 @@ class Simulation(object):
     def set_moving_window(self, v=c, **deprecated):
         """Attach a window moving at velocity v to the simulation (main.py:1004-1032)."""
         self.comm.moving_win = MovingWindow(self.comm, self.dt, v, self.time)
+        # after restart_from_checkpoint: continue from the window's saved continuous position
+        saved = getattr(self, '_restart_window', None)
+        if saved is not None:
+            self.comm.moving_win.zmin, self.comm.moving_win.t_last_move = saved
+            self._restart_window = None
 
     # -------------------------------------------------------------------- species
     def add_new_species(self, q, m, n=None, dens_func=None, p_nz=None, p_nr=None, p_nt=None,

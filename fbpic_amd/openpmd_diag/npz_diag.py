@@ -152,9 +152,11 @@ class ParticleDiagnostic(_Periodic):
 
 
 class Checkpoint(_Periodic):
-    """End-of-iteration hook (main.py:564-565): everything a restart needs, one file per
-    rank: all particle arrays of every species, E and B on the interpolation grid including
-    guard / damp cells, the grid position and the iteration."""
+    """End-of-iteration hook (main.py:564-565): everything a restart needs
+    (checkpoint_restart.restart_from_checkpoint), one file per rank: all particle arrays of every
+    species, E and B on the interpolation grid including guard / damp cells, the position of
+    the grid and of the global domain, time and iteration, the continuous position of the
+    moving window and the book-keeping of the plasma injectors."""
 
     def __init__(self, sim, period, write_dir=None):
         _Periodic.__init__(self, period, sim.comm, write_dir, 0, np.inf, None, sim.dt)
@@ -168,11 +170,19 @@ class Checkpoint(_Periodic):
             sp.flush_pending_push()
             for k in ('x', 'y', 'z', 'ux', 'uy', 'uz', 'w', 'inv_gamma'):
                 out['species%d_%s' % (i, k)] = _to_host(getattr(sp, k))
+            inj = getattr(sp, 'injector', None)
+            if inj is not None and inj.z_inject is not None:
+                out['species%d_injector' % i] = np.array([inj.z_inject, inj.z_end_plasma,
+                                                          float(inj.nz_inject)])
         for m in range(sim.fld.Nm):
             for k in _COMP['E'] + _COMP['B']:
                 out['m%d_%s' % (m, k)] = _to_host(getattr(sim.fld.interp[m], k))
         out.update(iteration=iteration, time=sim.time, zmin=sim.fld.interp[0].zmin,
-                   zmax=sim.fld.interp[0].zmax)
+                   zmax=sim.fld.interp[0].zmax, Nm=sim.fld.Nm,
+                   zmin_global=sim.comm._zmin_global_domain)
+        win = sim.comm.moving_win
+        if win is not None:
+            out['window'] = np.array([win.zmin, win.t_last_move])
         path = self._path('checkpoint', iteration)
         np.savez(path, **out)
         return path

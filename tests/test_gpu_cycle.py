@@ -148,7 +148,7 @@ def test_cycle_vs_oracle_medium(oracle, shape, Nm):
         assert np.abs(got[j][o2] - ref[j][o1]).max() < 1e-11 * np.abs(ref[j]).max(), k
 
 
-def _plasma_wave(shape, Nz=64, Nr=64, Nm=2, ppc=(2, 2, 8), n_periods=1):
+def _plasma_wave(shape, Nz=64, Nr=64, Nm=2, ppc=(2, 2, 8), n_periods=1, n_order=-1):
     """tests/test_periodic_plasma_wave.py at the reference's own dz, dt, ppc (box = one
     plasma wavelength; Nm=2 with eps_2 = 0 when Nm == 2)."""
     import importlib
@@ -165,7 +165,7 @@ def _plasma_wave(shape, Nz=64, Nr=64, Nm=2, ppc=(2, 2, 8), n_periods=1):
     N_step = int(2 * np.pi / (wp * dt) * 0.75)
     np.random.seed(0)
     sim = Simulation(Nz, zmax, Nr, rmax, Nm, dt, 0., zmax + dz, 0., 18.e-6, ppc[0], ppc[1], ppc[2],
-                     n_e, n_order=-1, particle_shape=shape)
+                     n_e, n_order=n_order, particle_shape=shape)
     with GpuMemoryManager(sim):
         sim.deposit('rho_prev', exchange=True)
         sim.fld.spect2interp('rho_prev')
