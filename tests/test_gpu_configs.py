@@ -299,8 +299,12 @@ def test_c3_lwfa_full_size():
     # the window moved by nstep cells; the plasma uncovered at the right edge was injected
     moved = (zmin_w - (zmin - (sim.comm.n_guard + sim.comm.nz_damp + sim.comm.n_inject) * dz)) / dz
     assert nstep - 1.01 <= moved <= nstep + 0.01, moved
-    # injection happens at the particle exchanges (every exchange_period steps)
-    assert n1 > n0
-    assert abs((n1 - n0) - nstep * per_cell_z) <= (sim.comm.exchange_period + 2) * per_cell_z
+    # continuous injection (at the particle exchanges, every exchange_period steps): whole
+    # lattice planes of p_nr * 230 * p_nt macroparticles, at least the nstep cells the window
+    # uncovered (the first injection also fills the damping cells up to z_inject)
+    plane = per_cell_z // 2
+    assert (n1 - n0) % plane == 0
+    assert nstep * per_cell_z <= n1 - n0 <= (nstep + sim.comm.nz_damp + sim.comm.n_guard
+                                             + 2 * sim.comm.exchange_period) * per_cell_z
     assert 0.01 < umax < 50.
     print('C3: %d -> %d macroparticles over %d steps' % (n0, n1, nstep))
