@@ -36,6 +36,8 @@ _SIGNATURES = {
                                          _PP, P, P, P, P, Z, I, P]),
     'fb_deposit_J_rank_next': (I, [I, I, L, P, P, P, P, D, P, P, P, P, D, D, D, I, D, D, I, _PP, L, L, P, P, P,
                                    D, D, D, D, I, P, Z, I, P]),
+    'fb_push_x_sort_deposit_rho': (I, [L, I, P, P, P, P, P, P, P, D, D, D, D, D, D, D, I, D, D, I, I, _PP,
+                                       _PP, P, P, P, P, Z, I, I, I, D, _PP, L, L, P, P, P]),
     'fb_permute': (I, [L, P, I, _PP, _PP, P]),
     'fb_deposit_rho': (I, [I, I, L, P, P, P, P, D, D, D, I, D, D, I, _PP, L, L, P, P, P, P, P]),
     'fb_deposit_J': (I, [I, I, L, P, P, P, P, D, P, P, P, P, D, D, D, I, D, D, I, _PP, L, L,

@@ -22,11 +22,6 @@ def _dist():
     return dist
 
 
-# (rank, size) or None.  Host-side construction of the grids and tables of ONE slab of a
-# decomposed run without torch.distributed: used by the tests to build the multi-slab CPU
-# oracle's inputs in a single process.  Such an object cannot exchange anything.
-VIRTUAL_WORLD = None
-
 
 class BoundaryCommunicator(object):
     def __init__(self, Nz, zmin, zmax, Nr, rmax, Nm, dt, v_comoving, use_galilean,
@@ -53,9 +48,7 @@ class BoundaryCommunicator(object):
         self.use_all_mpi_ranks = use_all_mpi_ranks
         # one rank per GPU: torch.distributed takes the place of mpi4py
         dist = _dist()
-        if VIRTUAL_WORLD is not None:
-            self.rank, self.size = VIRTUAL_WORLD
-        elif use_all_mpi_ranks and dist.is_available() and dist.is_initialized():
+        if use_all_mpi_ranks and dist.is_available() and dist.is_initialized():
             self.rank = dist.get_rank()
             self.size = dist.get_world_size()
         else:

@@ -152,8 +152,26 @@ struct RankNext {
     int *cell, *rank, *count;
 };
 
+// Optional front end of the rho deposition (fb_push_x_sort_deposit_rho): the wave walks the
+// particles in DESTINATION order of the counting sort.  Lane ip reads its 8 attributes through
+// the inverse permutation sidx (nearly sequential: a particle moves at most a cell per step),
+// evaluates the pending push_x in registers (same expression as k_push_x / k_scatter), writes
+// the attributes contiguously at their sorted slot and deposits the charge of the pushed
+// position.  One pass does what k_scatter (72 B read + 64 B written per particle) and the rho
+// deposition (32 B read again, r / cos / sin / cell recomputed) did in two; the arithmetic of
+// the deposition overlaps the memory stalls of the permutation.
+struct PermArgs {
+    const int *sidx;              // n, destination -> source
+    CPtrs16 src;                  // x, y, z, ux, uy, uz, w, inv_gamma [, extra attributes]
+    Ptrs16 dst;
+    int nattr;
+    double chdt, px, py, pz;
+    const int *cell;              // source-ordered cell of the pushed position (sort workspace)
+    int *cell_sorted;             // optional output
+};
+
 // NCOMP = 1 (rho) or 3 (Jr,Jt,Jz); this launch handles modes m0 .. m0+NM-1; Z0 <=> m0 == 0
-template <int SHAPE, int NCOMP, int NM, bool Z0, bool RANK>
+template <int SHAPE, int NCOMP, int NM, bool Z0, bool RANK, bool PERM = false>
 __global__ __launch_bounds__(256) void k_deposit(long n,
         const double *__restrict__ x, const double *__restrict__ y,
         const double *__restrict__ z, const double *__restrict__ w, double q,
@@ -162,9 +180,10 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
         double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
         DepGrids G, long rs, int m0,
         const double *__restrict__ beta0, const double *__restrict__ betah,
-        int chunks_per_wave, unsigned long long *__restrict__ nflush, RankNext RK)
+        int chunks_per_wave, unsigned long long *__restrict__ nflush, RankNext RK, PermArgs PM)
 {
     static_assert(!RANK || NCOMP == 3, "ranking needs the momenta");
+    static_assert(!PERM || NCOMP == 1, "the permuting front end belongs to the rho deposition");
     using L = DepLayout<SHAPE, NCOMP, NM, Z0>;
     constexpr int S = L::S, H = ShapeTraits<SHAPE>::H;
     constexpr int NPT = L::NPT, RG = L::RG, NW = L::NW, NT = L::NT, T1 = L::T1;
@@ -269,14 +288,29 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
     const long chunk0 = (xcd_block_id() * nwaves + wave) * chunks_per_wave;
     // software pipeline: particle data of chunk ch+1 is requested before chunk ch is
     // processed, hiding the HBM latency behind the staging + accumulation work
-    double pn[NCOMP == 1 ? 4 : 8];
+    constexpr int NP = (NCOMP == 1 && !PERM) ? 4 : 8;
+    double pn[NP];
+    int idx_n = 0, idx_c = 0;        // PERM: source index of the next / current chunk's particle
     auto prefetch = [&](long ip) {
         if (ip < n) {
-            pn[0] = x[ip]; pn[1] = y[ip]; pn[2] = z[ip]; pn[3] = w[ip];
-            if constexpr (NCOMP == 3) { pn[4] = ux[ip]; pn[5] = uy[ip]; pn[6] = uz[ip]; pn[7] = inv_gamma[ip]; }
+            if constexpr (PERM) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) pn[k] = PM.src.p[k][idx_n];
+            } else {
+                pn[0] = x[ip]; pn[1] = y[ip]; pn[2] = z[ip]; pn[3] = w[ip];
+                if constexpr (NCOMP == 3) { pn[4] = ux[ip]; pn[5] = uy[ip]; pn[6] = uz[ip]; pn[7] = inv_gamma[ip]; }
+            }
         }
     };
+    // PERM: two-stage pipeline - the index of chunk ch+2 is requested while the attributes
+    // of chunk ch+1 (through the index requested one iteration earlier) are in flight
+    if constexpr (PERM) { if (chunk0 * 64 + lane < n) idx_n = PM.sidx[chunk0 * 64 + lane]; }
     prefetch(chunk0 * 64 + lane);
+    int idx_nn = 0;
+    if constexpr (PERM) {
+        idx_c = idx_n;
+        if (chunks_per_wave > 1 && (chunk0 + 1) * 64 + lane < n) idx_nn = PM.sidx[(chunk0 + 1) * 64 + lane];
+    }
     for (int ch = 0; ch < chunks_per_wave; ch++) {
         const long base = (chunk0 + ch) * 64;
         if (base >= n) break;
@@ -284,13 +318,33 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
         // ---- phase 1: lane = particle; stage weights / amplitudes, keep the cell key
         int my_kz = DEP_NOKEY, my_kr = DEP_NOKEY, my_nb = 0;
         int rk_c = -1, rk_run0 = 0, rk_base = 0;
-        double pc[NCOMP == 1 ? 4 : 8];
+        double pc[NP];
 #pragma unroll
-        for (int k = 0; k < (NCOMP == 1 ? 4 : 8); k++) pc[k] = pn[k];
+        for (int k = 0; k < NP; k++) pc[k] = pn[k];
+        if constexpr (PERM) {
+            if (ch > 0) idx_c = idx_n;
+            idx_n = idx_nn;
+        }
         if (ch + 1 < chunks_per_wave) prefetch(ip + 64);
+        if constexpr (PERM) {
+            if (ch + 2 < chunks_per_wave && ip + 128 < n) idx_nn = PM.sidx[ip + 128];
+        }
         if (ip < n) {
-            const double xj = pc[0], yj = pc[1], zj = pc[2];
-            const double wj = q * pc[3];
+            double xj = pc[0], yj = pc[1], zj = pc[2];
+            if constexpr (PERM) {
+                // pending push_x (numba_methods.py:25-30, expression of k_push_x), then every
+                // attribute is written once, at its sorted slot
+                const double g = pc[7];
+                xj = pc[0] + PM.chdt * g * PM.px * pc[3];
+                yj = pc[1] + PM.chdt * g * PM.py * pc[4];
+                zj = pc[2] + PM.chdt * g * PM.pz * pc[5];
+                PM.dst.p[0][ip] = xj; PM.dst.p[1][ip] = yj; PM.dst.p[2][ip] = zj;
+                PM.dst.p[3][ip] = pc[3]; PM.dst.p[4][ip] = pc[4]; PM.dst.p[5][ip] = pc[5];
+                PM.dst.p[6][ip] = pc[6]; PM.dst.p[7][ip] = g;
+                for (int k = 8; k < PM.nattr; k++) PM.dst.p[k][ip] = PM.src.p[k][idx_c];
+                if (PM.cell_sorted) PM.cell_sorted[ip] = PM.cell[idx_c];
+            }
+            const double wj = q * pc[PERM ? 6 : 3];
             const double rj = sqrt(xj * xj + yj * yj);
             double cs, sn;
             if (rj != 0.) {
@@ -469,14 +523,17 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
         atomicAdd(nflush + ((blockIdx.x * nwaves + wave) & 1023), (unsigned long long)my_flushes);
 }
 
-template <int SHAPE, int NCOMP, int NM, bool Z0, bool RANK>
+template <int SHAPE, int NCOMP, int NM, bool Z0, bool RANK, bool PERM = false>
 static int launch_z(long n, const double *x, const double *y, const double *z, const double *w,
         double q, const double *ux, const double *uy, const double *uz, const double *ig,
         double c, double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
         const DepGrids &G, long rs, int m0, const double *b0, const double *bh,
-        unsigned long long *nflush, const RankNext &RK, hipStream_t s)
+        unsigned long long *nflush, const RankNext &RK, hipStream_t s,
+        const PermArgs *PMp = nullptr)
 {
     using L = DepLayout<SHAPE, NCOMP, NM, Z0>;
+    PermArgs PM = {};
+    if (PMp) PM = *PMp;
     // waves per workgroup: keep the LDS panel <= 64 KiB
     int nwaves = 4;
     while (nwaves > 1 && L::wave_bytes() * nwaves > 64 * 1024) nwaves >>= 1;
@@ -489,11 +546,11 @@ static int launch_z(long n, const double *x, const double *y, const double *z, c
     if (cpw > 64) cpw = 64;
     const long total_waves = (nchunks + cpw - 1) / cpw;
     const long nblocks = xcd_grid((total_waves + nwaves - 1) / nwaves);
-    auto kern = k_deposit<SHAPE, NCOMP, NM, Z0, RANK>;
+    auto kern = k_deposit<SHAPE, NCOMP, NM, Z0, RANK, PERM>;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(64 * nwaves),
                        L::wave_bytes() * nwaves, s, n, x, y, z, w, q, ux, uy, uz, ig, c,
                        invdz, zmin, Nz, invdr, rmin, Nr, G, rs, m0, b0, bh, cpw,
-                       (m0 == 0) ? nflush : nullptr, RK);
+                       (m0 == 0) ? nflush : nullptr, RK, PM);
     return check(hipGetLastError(), "fb_deposit");
 }
 
@@ -502,13 +559,16 @@ static int launch_one(long n, const double *x, const double *y, const double *z,
         double q, const double *ux, const double *uy, const double *uz, const double *ig,
         double c, double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
         const DepGrids &G, long rs, int m0, const double *b0, const double *bh,
-        unsigned long long *nflush, const RankNext *RK, hipStream_t s)
+        unsigned long long *nflush, const RankNext *RK, hipStream_t s, const PermArgs *PM = nullptr)
 {
     const RankNext none = {0., 0., 0., 0., nullptr, nullptr, nullptr};
 #define ZARGS n, x, y, z, w, q, ux, uy, uz, ig, c, invdz, zmin, Nz, invdr, rmin, Nr, G, rs, m0, b0, bh, nflush
     if (m0 == 0) {
         if constexpr (NCOMP == 3) {
             if (RK) return launch_z<SHAPE, NCOMP, NM, true, true>(ZARGS, *RK, s);
+        }
+        if constexpr (NCOMP == 1) {
+            if (PM) return launch_z<SHAPE, NCOMP, NM, true, false, true>(ZARGS, none, s, PM);
         }
         return launch_z<SHAPE, NCOMP, NM, true, false>(ZARGS, none, s);
     }
@@ -521,18 +581,23 @@ static int launch_modes(int Nm, long n, const double *x, const double *y, const 
         const double *w, double q, const double *ux, const double *uy, const double *uz,
         const double *ig, double c, double invdz, double zmin, int Nz, double invdr, double rmin,
         int Nr, const DepGrids &G, long rs, const double *b0, const double *bh,
-        unsigned long long *nflush, const RankNext *RK, hipStream_t s)
+        unsigned long long *nflush, const RankNext *RK, hipStream_t s, const PermArgs *PM = nullptr)
 {
     int m0 = 0;
     while (m0 < Nm) {
         int left = Nm - m0, r;
-#define ARGS n, x, y, z, w, q, ux, uy, uz, ig, c, invdz, zmin, Nz, invdr, rmin, Nr, G, rs, m0, b0, bh, nflush, RK, s
+#define ARGS n, x, y, z, w, q, ux, uy, uz, ig, c, invdz, zmin, Nz, invdr, rmin, Nr, G, rs, m0, b0, bh, nflush, RK, s, PM
         if (left >= 4) { r = launch_one<SHAPE, NCOMP, 4>(ARGS); m0 += 4; }
         else if (left == 3) { r = launch_one<SHAPE, NCOMP, 3>(ARGS); m0 += 3; }
         else if (left == 2) { r = launch_one<SHAPE, NCOMP, 2>(ARGS); m0 += 2; }
         else { r = launch_one<SHAPE, NCOMP, 1>(ARGS); m0 += 1; }
 #undef ARGS
         if (r) return r;
+        if (PM) {
+            // modes beyond the first launch (Nm > 4) read the sorted arrays it has written
+            x = PM->dst.p[0]; y = PM->dst.p[1]; z = PM->dst.p[2]; w = PM->dst.p[6];
+            PM = nullptr;
+        }
     }
     return 0;
 }
@@ -626,4 +691,47 @@ extern "C" int fb_deposit_J_rank_next(int shape, int Nm, long n, const double *x
     return deposit_J_impl("fb_deposit_J_rank_next", shape, Nm, n, x, y, z, w, q, ux, uy, uz,
                           inv_gamma, c, invdz, zmin, Nz, invdr, rmin, Nr, J, row_stride, col_stride,
                           ruyten_m0, ruyten_mh, nflush, &RK, s);
+}
+
+extern "C" int fb_push_x_sort_deposit_rho(long n, int ncell, const double *x, const double *y,
+        const double *z, const double *ux, const double *uy, const double *uz,
+        const double *inv_gamma, double c, double dt, double x_push, double y_push, double z_push,
+        double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
+        int nattr, const double *const *src, double *const *dst,
+        int *cell_idx_sorted, int *sorted_idx, int *prefix_sum,
+        void *workspace, size_t workspace_bytes, int preranked,
+        int shape, int Nm, double q, void *const *rho, long row_stride, long col_stride,
+        const double *ruyten_m0, const double *ruyten_mh, void *stream)
+{
+    const char *who = "fb_push_x_sort_deposit_rho";
+    hipStream_t s = (hipStream_t)stream;
+    if (Nm < 1 || Nm > FB_MAX_MODES) { set_error(who, "Nm out of range"); return -1; }
+    if (shape != FB_SHAPE_LINEAR && shape != FB_SHAPE_CUBIC) { set_error(who, "unknown shape"); return -1; }
+    if (!sorted_idx) { set_error(who, "sorted_idx (n ints) is required: it holds the permutation"); return -1; }
+    if (nattr < 8) { set_error(who, "src / dst must hold x, y, z, ux, uy, uz, w, inv_gamma"); return -1; }
+    // fbpic/particles/push/numba_methods.py:24-30: chdt = c * dt
+    const PushX P = {ux, uy, uz, inv_gamma, c * dt, x_push, y_push, z_push};
+    BinSortWs W;
+    int r = bin_sort_prepare(who, true, preranked != 0, P, n, ncell, x, y, z, invdz, zmin, Nz, invdr,
+                             rmin, Nr, nattr, src, prefix_sum, workspace, workspace_bytes, &W, s);
+    if (r) return r;
+    r = bin_sort_build_sidx(who, n, ncell, W, prefix_sum, sorted_idx, s);
+    if (r || n <= 0) return r;
+    PermArgs PM;
+    PM.sidx = sorted_idx;
+    for (int k = 0; k < 16; k++) { PM.src.p[k] = k < nattr ? src[k] : nullptr; PM.dst.p[k] = k < nattr ? dst[k] : nullptr; }
+    PM.nattr = nattr;
+    PM.chdt = P.chdt; PM.px = x_push; PM.py = y_push; PM.pz = z_push;
+    PM.cell = W.cell;
+    PM.cell_sorted = cell_idx_sorted;
+    DepGrids G;
+    G.cs = col_stride > 0 ? col_stride : 1;
+    for (int i = 0; i < 3 * FB_MAX_MODES; i++) G.g[i] = i < Nm ? (cplx *)rho[i] : nullptr;
+    if (shape == FB_SHAPE_LINEAR)
+        return launch_modes<FB_SHAPE_LINEAR, 1>(Nm, n, x, y, z, src[6], q, nullptr, nullptr, nullptr,
+                nullptr, 0., invdz, zmin, Nz, invdr, rmin, Nr, G, row_stride, ruyten_m0,
+                ruyten_mh, nullptr, nullptr, s, &PM);
+    return launch_modes<FB_SHAPE_CUBIC, 1>(Nm, n, x, y, z, src[6], q, nullptr, nullptr, nullptr,
+            nullptr, 0., invdz, zmin, Nz, invdr, rmin, Nr, G, row_stride, ruyten_m0,
+            ruyten_mh, nullptr, nullptr, s, &PM);
 }

@@ -78,6 +78,15 @@ struct PushX {
     double chdt, px, py, pz;
 };
 
+// sort.hip: rank pass (unless preranked) + scan of the counting sort, and the inverse
+// permutation sidx[destination] = source; used by the fused sort + push_x + rho deposition
+int bin_sort_prepare(const char *who, bool push, bool preranked, const PushX &P, long n, int ncell,
+        const double *x, const double *y, const double *z, double invdz, double zmin, int Nz,
+        double invdr, double rmin, int Nr, int nattr, const double *const *src, int *prefix_sum,
+        void *workspace, size_t workspace_bytes, BinSortWs *Wout, hipStream_t s);
+int bin_sort_build_sidx(const char *who, long n, int ncell, const BinSortWs &W, const int *prefix_sum,
+                        int *sidx, hipStream_t s);
+
 }  // namespace fb
 
 #define FB_CHECK_LAUNCH(where) return fb::check(hipGetLastError(), where)

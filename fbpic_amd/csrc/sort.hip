@@ -165,6 +165,23 @@ __global__ __launch_bounds__(256) void k_scatter(long n, const int *__restrict__
     }
 }
 
+// Inverse of the scatter's destination map: sidx[prefix[c-1] + rank[i]] = i.  With it the
+// particles can be walked in DESTINATION (cell-sorted) order by a kernel that reads its
+// attributes through sidx and writes them contiguously - the fused sort + push_x + rho
+// deposition (deposit.hip, fb_push_x_sort_deposit_rho).  Also leaves the per-cell counters
+// zeroed for the next rank pass, like k_scatter.
+__global__ __launch_bounds__(256) void k_build_sidx(long n, const int *__restrict__ cell,
+        const int *__restrict__ rank, const int *__restrict__ prefix, int *__restrict__ sidx,
+        int *__restrict__ count, int ncell)
+{
+    long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < ncell; i += stride) count[i] = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int c = cell[i];
+        sidx[(c > 0 ? prefix[c - 1] : 0) + rank[i]] = (int)i;
+    }
+}
+
 static size_t scan_temp_bytes(int ncell)
 {
     size_t bytes = 0;
@@ -266,11 +283,14 @@ extern "C" size_t fb_bin_sort_workspace_bytes(long n, int ncell)
            + align_up(scan_temp_bytes(ncell), 256) + 256;
 }
 
-static int bin_sort_impl(const char *who, bool push, bool preranked, const PushX &P, long n, int ncell,
+namespace fb {
+
+// Rank pass (unless `preranked`) + scan: fills W.cell / W.rank and prefix_sum.  Shared by the
+// counting sort below and by the fused sort + deposition of deposit.hip.
+int bin_sort_prepare(const char *who, bool push, bool preranked, const PushX &P, long n, int ncell,
         const double *x, const double *y, const double *z, double invdz, double zmin, int Nz,
-        double invdr, double rmin, int Nr, int nattr, const double *const *src,
-        double *const *dst, int *cell_idx_sorted, int *sorted_idx, int *prefix_sum,
-        void *workspace, size_t workspace_bytes, hipStream_t s)
+        double invdr, double rmin, int Nr, int nattr, const double *const *src, int *prefix_sum,
+        void *workspace, size_t workspace_bytes, BinSortWs *Wout, hipStream_t s)
 {
     if (nattr < 0 || nattr > 16) { set_error(who, "nattr > 16"); return -1; }
     if (ncell != Nz * (Nr + 1)) { set_error(who, "ncell != Nz*(Nr+1)"); return -1; }
@@ -284,29 +304,50 @@ static int bin_sort_impl(const char *who, bool push, bool preranked, const PushX
         return -1;
     }
     const BinSortWs W = carve_bin_sort_ws(workspace, workspace_bytes, n, ncell);
-    int *count = W.count, *cell = W.cell, *rank = W.rank;
-    void *temp = W.temp;
-    size_t temp_bytes = W.temp_bytes;
+    *Wout = W;
     hipError_t e = hipSuccess;
     if (!preranked) {
         // (when `preranked`, fb_deposit_J_rank_next has already filled count, cell and rank)
-        e = hipMemsetAsync(count, 0, (size_t)ncell * sizeof(int), s);
+        e = hipMemsetAsync(W.count, 0, (size_t)ncell * sizeof(int), s);
         if (e != hipSuccess) return check(e, who);
     }
     if (n > 0 && !preranked) {
         const dim3 grid(stream_grid(n, 256, 256 * 16));
         if (push)
             hipLaunchKernelGGL(k_bin_rank<true>, grid, dim3(256), 0, s, n, x, y, z, P, invdz, zmin,
-                               Nz, invdr, rmin, Nr, cell, rank, count);
+                               Nz, invdr, rmin, Nr, W.cell, W.rank, W.count);
         else
             hipLaunchKernelGGL(k_bin_rank<false>, grid, dim3(256), 0, s, n, x, y, z, P, invdz, zmin,
-                               Nz, invdr, rmin, Nr, cell, rank, count);
+                               Nz, invdr, rmin, Nr, W.cell, W.rank, W.count);
         int r = check(hipGetLastError(), who);
         if (r) return r;
     }
-    e = rocprim::inclusive_scan(temp, temp_bytes, count, prefix_sum, (size_t)ncell,
+    size_t temp_bytes = W.temp_bytes;
+    e = rocprim::inclusive_scan(W.temp, temp_bytes, W.count, prefix_sum, (size_t)ncell,
                                 rocprim::plus<int>(), s, false);
     if (e != hipSuccess) return check(e, who);
+    return 0;
+}
+
+int bin_sort_build_sidx(const char *who, long n, int ncell, const BinSortWs &W, const int *prefix_sum,
+                        int *sidx, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_build_sidx, dim3(stream_grid(n > ncell ? n : ncell)), dim3(256), 0, s, n,
+                       W.cell, W.rank, prefix_sum, sidx, W.count, ncell);
+    return check(hipGetLastError(), who);
+}
+
+static int bin_sort_impl(const char *who, bool push, bool preranked, const PushX &P, long n, int ncell,
+        const double *x, const double *y, const double *z, double invdz, double zmin, int Nz,
+        double invdr, double rmin, int Nr, int nattr, const double *const *src,
+        double *const *dst, int *cell_idx_sorted, int *sorted_idx, int *prefix_sum,
+        void *workspace, size_t workspace_bytes, hipStream_t s)
+{
+    BinSortWs W;
+    int r = bin_sort_prepare(who, push, preranked, P, n, ncell, x, y, z, invdz, zmin, Nz, invdr, rmin,
+                             Nr, nattr, src, prefix_sum, workspace, workspace_bytes, &W, s);
+    if (r) return r;
+    int *count = W.count, *cell = W.cell, *rank = W.rank;
     if (n > 0) {
         CPtrs16 a;
         Ptrs16 b;
@@ -320,6 +361,10 @@ static int bin_sort_impl(const char *who, bool push, bool preranked, const PushX
     }
     FB_CHECK_LAUNCH(who);
 }
+
+}  // namespace fb
+
+using namespace fb;
 
 extern "C" int fb_bin_sort_particles(long n, int ncell, const double *x, const double *y,
         const double *z, double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,

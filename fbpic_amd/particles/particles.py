@@ -7,6 +7,7 @@ rearrange_particle_arrays, send_particles_to_gpu, receive_particles_from_gpu.
 Every compute method launches a HIP kernel of libfbpic_amd.so; nothing runs on the host.
 """
 import ctypes
+import os
 import numpy as np
 from scipy.constants import c
 from .. import _capi
@@ -85,6 +86,9 @@ class Particles(object):
         # counting sort (fb_bin_sort_particles) instead of cell_index + radix sort + permute;
         # False restores the reference-like stable three-stage sort
         self.use_bin_sort = True
+        # push_x + counting sort + deposit('rho') as one destination-ordered pass
+        # (fb_push_x_sort_deposit_rho) when a deferred push and a re-sort precede a rho deposit
+        self.fuse_sort_deposit_rho = os.environ.get('FBPIC_AMD_FUSE_RHO', '1') != '0'
         # the counting sort only materialises `cell_idx` / `sorted_idx` (sorted cell of every
         # particle, permutation) when asked: nothing on the hot path reads them
         self.keep_sort_outputs = False
@@ -373,6 +377,45 @@ class Particles(object):
         self._moved_since_sort = 0.
         self.rearrange_particle_arrays()
 
+    def _push_sort_deposit_rho(self, fld, records):
+        """fb_push_x_sort_deposit_rho: the deferred push_x, the counting sort and the charge
+        deposition in one pass over the particles (destination-ordered)."""
+        grid = fld.interp
+        Nm = len(grid)
+        g0 = grid[0]
+        lib, p, st = _capi.lib(), _capi.ptr, _capi.stream()
+        names = list(_STATE) + (list(_FIELDS) if self.keep_fields_sorted else [])
+        src = [getattr(self, k) for k in names]
+        dst = self._alt[:len(names)]
+        pend, self._pending_push = self._pending_push, None
+        preranked = int(self._prerank == pend)
+        self._prerank = None
+        suffix = 'linear' if self.particle_shape == 'linear' else 'cubic'
+        ruy0 = getattr(grid[0], 'd_ruyten_%s_coef' % suffix)
+        ruyh = getattr(grid[1 if Nm > 1 else 0], 'd_ruyten_%s_coef' % suffix)
+        views = fld.record_views('rho') if records else [grid[m].rho for m in range(Nm)]
+        rc = lib.fb_push_x_sort_deposit_rho(
+            self.Ntot, self.prefix_sum.shape[0], p(self.x), p(self.y), p(self.z),
+            p(self.ux), p(self.uy), p(self.uz), p(self.inv_gamma), c, pend[0], pend[1], pend[2],
+            pend[3], g0.invdz, g0.zmin, g0.Nz, g0.invdr, g0.rmin, g0.Nr,
+            len(names), _capi.ptr_array(src), _capi.ptr_array(dst),
+            p(self.cell_idx) if self.keep_sort_outputs else None, p(self.sorted_idx),
+            p(self.prefix_sum), p(self._sort_ws), self._sort_ws.shape[0], preranked,
+            _SHAPE[self.particle_shape], Nm, self.q, _capi.ptr_array(views),
+            views[0].stride(0), views[0].stride(1), p(ruy0), p(ruyh), st)
+        _capi.check(rc, 'fb_push_x_sort_deposit_rho')
+        self._counts_clean = True
+        for i, k in enumerate(names):
+            setattr(self, k, dst[i])
+            self._alt[i] = src[i]
+        self.sorting_buffer = self._alt[0]
+        self.prefix_sum_shift = 0
+        self._cell_size = (g0.dz, g0.dr)
+        self._moved_since_sort = 0.
+        self.sorted = True
+        self._deposits_since_sort = 0
+        self._runs_latest = None
+
     def rearrange_particle_arrays(self):
         """Apply sorted_idx to every particle attribute in one launch (ping-pong buffers)."""
         names = list(_STATE)
@@ -433,6 +476,12 @@ class Particles(object):
             return
         assert fieldtype in ['rho', 'J']
         self._need_gpu()
+        if (fieldtype == 'rho' and self.fuse_sort_deposit_rho and self.use_bin_sort
+                and self._pending_push is not None and not self.sorted and self._needs_sort()
+                and self.Ntot > 0):
+            # the step's push_x(dt/2) -> re-sort -> deposit('rho_next'): one pass
+            self._push_sort_deposit_rho(fld, records)
+            return
         if not self.sorted and self._needs_sort():
             self.sort_particles(fld=fld)
             self.sorted = True

@@ -182,6 +182,32 @@ int fb_deposit_J(int shape, int Nm, long n,
                  const int *prefix_sum, const double *ruyten_m0, const double *ruyten_mh,
                  unsigned long long *nflush, void *stream);
 
+/* push_x + counting sort + deposit('rho') in ONE pass over the particles: the tail of
+ * Simulation.step's particle work (main.py:519-528: push_x(dt/2), then deposit('rho_next'),
+ * whose Particles.deposit re-sorts, particles.py:1049-1094, and launches deposit_rho_gpu_*,
+ * deposition/cuda_methods.py:84,517).  Identical result to
+ *   fb_push_x_bin_sort_particles(n, ncell, x, ..., preranked, stream)   followed by
+ *   fb_deposit_rho(shape, Nm, n, dst[0], dst[1], dst[2], dst[6], q, ..., stream)
+ * (same arithmetic per particle; the deposition sums differ by summation order only).
+ * The particles are walked in DESTINATION order: sorted_idx (required, n ints; on return the
+ * old index of each sorted particle, as from the sort) is built from the rank pass, every lane
+ * reads its 8 attributes through it, pushes the position in registers, writes all attributes
+ * contiguously at the sorted slot and deposits its charge - the stand-alone scatter (72 B read
+ * + 64 B written per particle) and the re-read of x, y, z, w by the deposition (32 B) become
+ * one pass of 68 B read + 64 B written, whose arithmetic overlaps its memory stalls.
+ * src[0..7] = x, y, z, ux, uy, uz, w, inv_gamma; arguments otherwise as the two calls above. */
+int fb_push_x_sort_deposit_rho(long n, int ncell, const double *x, const double *y,
+                               const double *z, const double *ux, const double *uy,
+                               const double *uz, const double *inv_gamma, double c, double dt,
+                               double x_push, double y_push, double z_push,
+                               double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
+                               int nattr, const double *const *src, double *const *dst,
+                               int *cell_idx_sorted, int *sorted_idx, int *prefix_sum,
+                               void *workspace, size_t workspace_bytes, int preranked,
+                               int shape, int Nm, double q, void *const *rho, long row_stride,
+                               long col_stride, const double *ruyten_m0, const double *ruyten_mh,
+                               void *stream);
+
 /* fb_deposit_J that also prepares the counting sort which Simulation.step runs after the
  * next push_x (main.py:515-528: deposit J, push_x(dt/2), re-sort for deposit rho_next): for
  * every particle, the cell of the position pushed by (dt_push, x_push, y_push, z_push) and

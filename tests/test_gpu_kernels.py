@@ -819,6 +819,112 @@ def test_push_x_folded_into_sort(hip, oracle, preranked):
         assert np.array_equal(host(b), a)
 
 
+@pytest.mark.parametrize('shape,Nm,preranked,nattr,records', [(1, 2, 1, 8, True), (1, 2, 0, 8, False),
+                                                            (3, 2, 1, 14, False), (3, 4, 0, 8, False),
+                                                            (1, 5, 1, 8, False), (1, 1, 1, 8, True)])
+def test_push_sort_deposit_rho_fused(hip, oracle, shape, Nm, preranked, nattr, records):
+    """fb_push_x_sort_deposit_rho == fb_push_x_bin_sort_particles followed by fb_deposit_rho:
+    pushed positions bit-identical to the oracle push, same cells / prefix sums / permutation
+    property, charge density equal to the two-call sequence AND to the oracle deposition of the
+    pushed particles (1e-13, summation order).  Variants: preranked by fb_deposit_J_rank_next,
+    extra attributes riding along (keep_fields_sorted), node-major record target, Nm > 4 (second
+    deposition launch reads the arrays the first one wrote)."""
+    from scipy.constants import c
+    rng = np.random.default_rng(41 + Nm)
+    n, Nz, Nr = 150001, 48, 24
+    dzc = 0.2e-6
+    # cell-sorted stream with thermal motion, as inside the PIC cycle
+    r = rng.uniform(0, 1.02 * Nr * dzc, n)
+    th = rng.uniform(0, 2 * np.pi, n)
+    x, y = r * np.cos(th), r * np.sin(th)
+    z = rng.uniform(0., Nz * dzc, n)       # pushed: within half a cell of the box (guard range)
+    geom = (1. / dzc, 0., Nz, 1. / dzc, 0., Nr)
+    o = np.argsort(oracle.cell_index(x, y, z, *geom), kind='stable')
+    x, y, z = x[o], y[o], z[o]
+    ux, uy, uz = (rng.normal(size=n) * 0.3 for _ in range(3))
+    ig = 1. / np.sqrt(1. + ux**2 + uy**2 + uz**2)
+    w = rng.uniform(0.5, 1.5, n)
+    extra = [rng.normal(size=n) for _ in range(nattr - 8)]
+    dt = 0.5 * dzc / c
+    q = -1.6e-19
+    xr, yr, zr = x.copy(), y.copy(), z.copy()
+    oracle.push_x(xr, yr, zr, ux, uy, uz, ig, dt, 1., 1., 1.)
+    ref_cell = oracle.cell_index(xr, yr, zr, *geom)
+    t = hip.torch()
+    p = hip.ptr
+    ncell = Nz * (Nr + 1)
+    host_attrs = [x, y, z, ux, uy, uz, w, ig] + extra
+    src = [dev(hip, a) for a in host_attrs]
+    ruy0 = dev(hip, rng.uniform(-0.05, 0.05, Nr + 1))
+    ruyh = dev(hip, rng.uniform(-0.05, 0.05, Nr + 1))
+    nb = int(hip.lib().fb_bin_sort_workspace_bytes(n, ncell))
+
+    def target():
+        if records:      # node-major records: (Nz, Nr, 4 Nm), rho of mode m at slot 4m+3
+            rec = t.zeros((Nz, Nr, 4 * Nm), dtype=t.complex128, device='cuda')
+            return rec, [rec[:, :, 4 * m + 3] for m in range(Nm)]
+        g = t.zeros((Nz, Nm, Nr), dtype=t.complex128, device='cuda')
+        return g, [g[:, m, :] for m in range(Nm)]
+
+    def prerank(ws):
+        J = t.zeros((Nz, 3 * Nm, Nr), dtype=t.complex128, device='cuda')
+        hip.check(hip.lib().fb_deposit_J_rank_next(
+            shape, Nm, n, p(src[0]), p(src[1]), p(src[2]), p(src[6]), q, p(src[3]), p(src[4]),
+            p(src[5]), p(src[7]), c, *geom, hip.ptr_array([J[:, k, :] for k in range(3 * Nm)]),
+            3 * Nm * Nr, 1, p(ruy0), p(ruyh), None, dt, 1., 1., 1., ncell, p(ws), nb, 0,
+            hip.stream()), 'deposit_J_rank_next')
+    # ---- fused
+    ws = t.empty(nb, dtype=t.uint8, device='cuda')
+    if preranked:
+        prerank(ws)
+    dst = [t.empty_like(a) for a in src]
+    ci = t.empty(n, dtype=t.int32, device='cuda')
+    si = t.empty(n, dtype=t.int32, device='cuda')
+    pre = t.empty(ncell, dtype=t.int32, device='cuda')
+    base, views = target()
+    hip.check(hip.lib().fb_push_x_sort_deposit_rho(
+        n, ncell, p(src[0]), p(src[1]), p(src[2]), p(src[3]), p(src[4]), p(src[5]), p(src[7]),
+        c, dt, 1., 1., 1., *geom, nattr, hip.ptr_array(src), hip.ptr_array(dst), p(ci), p(si), p(pre),
+        p(ws), nb, preranked, shape, Nm, q, hip.ptr_array(views), views[0].stride(0),
+        views[0].stride(1), p(ruy0), p(ruyh), hip.stream()), 'push_x_sort_deposit_rho')
+    cis, sidx, prefix = host(ci), host(si), host(pre)
+    assert np.all(np.diff(cis) >= 0)
+    assert np.array_equal(np.sort(sidx), np.arange(n, dtype=np.int32))
+    assert np.array_equal(cis, ref_cell[sidx])
+    assert np.array_equal(prefix, np.cumsum(np.bincount(ref_cell, minlength=ncell)).astype(np.int32))
+    for a, b in zip([xr, yr, zr, ux, uy, uz, w, ig] + extra, dst):
+        assert np.array_equal(host(b), a[sidx])
+    assert np.all(host(ws[:4 * ncell].view(t.int32)) == 0)       # counters left zeroed
+    for a, b in zip(host_attrs, src):
+        assert np.array_equal(host(b), a)                        # inputs untouched
+    # ---- the two-call sequence
+    ws2 = t.empty(nb, dtype=t.uint8, device='cuda')
+    if preranked:
+        prerank(ws2)
+    dst2 = [t.empty_like(a) for a in src]
+    pre2 = t.empty(ncell, dtype=t.int32, device='cuda')
+    hip.check(hip.lib().fb_push_x_bin_sort_particles(
+        n, ncell, p(src[0]), p(src[1]), p(src[2]), p(src[3]), p(src[4]), p(src[5]), p(src[7]),
+        c, dt, 1., 1., 1., *geom, nattr, hip.ptr_array(src), hip.ptr_array(dst2), None, None, p(pre2),
+        p(ws2), nb, preranked, hip.stream()), 'push_x_bin_sort')
+    base2, views2 = target()
+    hip.check(hip.lib().fb_deposit_rho(shape, Nm, n, p(dst2[0]), p(dst2[1]), p(dst2[2]), p(dst2[6]), q,
+                                       *geom, hip.ptr_array(views2), views2[0].stride(0),
+                                       views2[0].stride(1), p(pre2), p(ruy0), p(ruyh), None,
+                                       hip.stream()), 'deposit_rho')
+    assert np.array_equal(host(pre2), prefix)
+    assert rel_err(host(base), host(base2)) < 1e-13
+    # ---- the oracle deposition of the pushed particles
+    if Nm <= 4:
+        glob = np.zeros((1, Nm, Nz + 4, Nr + 4), dtype=np.complex128)
+        oracle.deposit_rho_global('linear' if shape == 1 else 'cubic', Nm, xr, yr, zr, w, q, *geom,
+                                  host(ruy0), host(ruyh), 1, glob)
+        for m in range(Nm):
+            red = np.zeros((Nz, Nr), dtype=np.complex128)
+            oracle.sum_reduce(glob, m, red)
+            assert rel_err(host(views[m]), red) < 1e-13, m
+
+
 def test_guard_buffers_and_damping(hip):
     """fb_guard_buffers (pack / replace / add of the guard rows of a field group, both z ends
     in one launch; boundaries/cuda_methods.py:12-484) and fb_damp_rows (:486-640) against
