@@ -120,13 +120,23 @@ struct DepLayout {
     static constexpr int RH = (NM - 1) * NCOMP * 2;   // rows of the other modes
     static constexpr int TH = (RH + 3) / 4;
     static constexpr int NT = T1 + TH;                // column tiles
-    static constexpr int NA = 4 * NT;                 // amplitude rows incl. padding
+    // amplitude rows actually staged: the panel holds no padding rows (a column tile whose
+    // last columns are unused reads its last valid row again; those outputs are discarded).
+    // J, linear, Nm = 2: 17 rows x 65 doubles = 8.8 KB per wave -> 4 workgroups of 4 waves per
+    // CU instead of 3 with the padded 20 rows; rho: 11 rows -> 6 instead of 4.
+    static constexpr int NA = R1 + RH;
     static constexpr int WAVE_DOUBLES = (NW + NA) * DEP_PAD + 1;
     static constexpr size_t wave_bytes() { return (size_t)WAVE_DOUBLES * 8; }
     // panel row of amplitude (component k, launch-local mode mm, re/im)
     __host__ __device__ static constexpr int row(int k, int mm, int ri)
     {
-        return (mm == 0) ? (Z0 ? k : 2 * k + ri) : 4 * T1 + ((mm - 1) * NCOMP + k) * 2 + ri;
+        return (mm == 0) ? (Z0 ? k : 2 * k + ri) : R1 + ((mm - 1) * NCOMP + k) * 2 + ri;
+    }
+    // panel row read by the lanes with column index jl of tile t
+    __host__ __device__ static constexpr int tile_row(int t, int jl)
+    {
+        return (t < T1) ? ((4 * t + jl < R1) ? 4 * t + jl : R1 - 1)
+                        : R1 + ((4 * (t - T1) + jl < RH) ? 4 * (t - T1) + jl : RH - 1);
     }
 };
 
@@ -235,6 +245,9 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
     }
 
     double acc[RG][NT];
+    int aoff[NT];               // LDS offset of the amplitude row this lane feeds to tile t
+#pragma unroll
+    for (int t = 0; t < NT; t++) aoff[t] = L::tile_row(t, jl) * DEP_PAD;
 #pragma unroll
     for (int rg = 0; rg < RG; rg++)
 #pragma unroll
@@ -493,7 +506,7 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
                 }
 #pragma unroll
                 for (int t = 0; t < NT; t++) {
-                    const double av = Al[(4 * t + jl) * DEP_PAD + pi];
+                    const double av = Al[aoff[t] + pi];
 #pragma unroll
                     for (int rg = 0; rg < RG; rg++) {
                         double wv;
@@ -534,7 +547,8 @@ static int launch_z(long n, const double *x, const double *y, const double *z, c
     using L = DepLayout<SHAPE, NCOMP, NM, Z0>;
     PermArgs PM = {};
     if (PMp) PM = *PMp;
-    // waves per workgroup: keep the LDS panel <= 64 KiB
+    // waves per workgroup: keep the LDS panel <= 64 KiB (1, 2 or 4 waves per workgroup and 32 /
+    // 64 / 128 waves per CU in flight measured: 4 and 64 as good as any)
     int nwaves = 4;
     while (nwaves > 1 && L::wave_bytes() * nwaves > 64 * 1024) nwaves >>= 1;
     const long nchunks = (n + 63) / 64;
