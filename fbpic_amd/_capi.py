@@ -21,6 +21,10 @@ _SIGNATURES = {
     'fb_last_error': (ctypes.c_char_p, []),
     'fb_set_device': (I, [I]),
     'fb_sync': (I, [P]),
+    'fb_comm_unique_id': (I, [P]),
+    'fb_comm_init': (I, [P, I, I, ctypes.POINTER(P)]),
+    'fb_comm_destroy': (I, [P]),
+    'fb_exchange': (I, [P, I, I, P, Z, P, Z, P, Z, P, Z, P]),
     'fb_push_x': (I, [L, P, P, P, P, P, P, P, D, D, D, D, D, P]),
     'fb_push_p': (I, [L, P, P, P, P, P, P, P, P, P, P, D, D, D, D, P]),
     'fb_shift_periodic': (I, [L, P, D, D, P]),
@@ -181,7 +185,7 @@ class _TimedLib(object):
         f = getattr(self._real, name)
         if not name.startswith('fb_') or name in ('fb_last_error', 'fb_abi_version',
                                                   'fb_sort_workspace_bytes', 'fb_bin_sort_workspace_bytes', 'fb_fft_plan_create',
-                                                  'fb_fft_plan_destroy', 'fb_sync', 'fb_set_device', 'fb_zfft_supported', 'fb_fft_generic_supported'):
+                                                  'fb_fft_plan_destroy', 'fb_sync', 'fb_set_device', 'fb_comm_unique_id', 'fb_comm_init', 'fb_comm_destroy', 'fb_zfft_supported', 'fb_fft_generic_supported'):
             return f
         t = torch()
         recs = self._records.setdefault(name, [])

@@ -11,6 +11,8 @@ only, no collective on the data path.  Because the device field slabs are z-majo
 (fields.py), the guard region of *all* components and modes of a field group is a single
 contiguous block: a message is one `slab[z0:z1, f0:f1, :]` slice, no pack kernels.
 """
+import ctypes
+import os
 import numpy as np
 from scipy.constants import c
 from .. import _capi
@@ -21,6 +23,46 @@ def _dist():
     import torch.distributed as dist
     return dist
 
+
+
+_GPU_SELECTED = False
+
+
+def select_gpu_for_this_rank():
+    """One rank per GPU (the reference's mpi_select_gpus, fbpic/utils/cuda.py:60-99, called when
+    main.py is imported): bind this process to GPU LOCAL_RANK % device_count unless the script
+    already chose a device (a HIP context exists on a device other than 0, or
+    torch.cuda.set_device was called before).  Under the `nccl` (= RCCL) backend two ranks of
+    one host on the same GPU cannot exchange: that is reported here instead of as an RCCL
+    hang.  (gloo - the CPU tests, several ranks sharing the single GPU of a test box - is
+    exempt.)"""
+    global _GPU_SELECTED
+    if _GPU_SELECTED:
+        return
+    _GPU_SELECTED = True
+    import os
+    import socket
+    t = _capi.torch()
+    dist = _dist()
+    if not t.cuda.is_available():
+        return
+    ndev = t.cuda.device_count()
+    local_rank = os.environ.get('LOCAL_RANK')
+    chosen = t.cuda.current_device() if t.cuda.is_initialized() else None
+    if local_rank is not None and ndev > 1 and chosen in (None, 0):
+        # nothing chose a device yet (or only the default context exists): one GPU per rank
+        t.cuda.set_device(int(local_rank) % ndev)
+    dev = t.cuda.current_device()
+    _capi.check(_capi.lib().fb_set_device(dev), 'fb_set_device')
+    if dist.get_backend() == 'nccl':
+        mine = (socket.gethostname(), dev)
+        everyone = [None] * dist.get_world_size()
+        dist.all_gather_object(everyone, mine)
+        if len(set(everyone)) != len(everyone):
+            raise _capi.BackendError(
+                'Two ranks are bound to the same GPU %s (all ranks: %s).  Launch one process per '
+                'GPU (torchrun sets LOCAL_RANK) or call torch.cuda.set_device before building the '
+                'Simulation.' % (mine, everyone))
 
 
 class BoundaryCommunicator(object):
@@ -53,6 +95,8 @@ class BoundaryCommunicator(object):
             self.size = dist.get_world_size()
         else:
             self.rank, self.size = 0, 1
+        if self.size > 1:
+            select_gpu_for_this_rank()
         self.mpi_comm = None
         self.left_proc = self.rank - 1
         self.right_proc = self.rank + 1
@@ -108,6 +152,11 @@ class BoundaryCommunicator(object):
         self.d_left_damp = None
         self.d_right_damp = None
         self._guard_bufs = {}
+        # transport of device buffers between ranks: 'torch' = torch.distributed point-to-point
+        # (backend nccl = RCCL; gloo stages through the host), 'rccl' = fb_exchange, RCCL
+        # send/recv inside the library on the compute stream (no host synchronisation)
+        self.transport = os.environ.get('FBPIC_AMD_TRANSPORT', 'torch')
+        self._rccl_comm = None
 
     # ---------------------------------------------------------------- decomposition
     def divide_into_domain(self):
@@ -310,6 +359,10 @@ class BoundaryCommunicator(object):
             return
         dist = _dist()
         t = _capi.torch()
+        if self.transport == 'rccl' and all(x is None or x.is_cuda for x in
+                                            (send_left, send_right, recv_left, recv_right)):
+            self._exchange_rccl(send_left, send_right, recv_left, recv_right)
+            return
         # RCCL moves device buffers directly over xGMI.  Under the gloo backend (CPU tests,
         # or several ranks sharing one GPU) device tensors are staged through the host.
         stage = (dist.get_backend() == 'gloo')
@@ -349,6 +402,35 @@ class BoundaryCommunicator(object):
                 req.wait()
         for dev_t, host_t in staged:
             dev_t.copy_(host_t)
+
+    def _rccl_communicator(self):
+        """Communicator of the library's own transport: rank 0 creates the id, torch.distributed
+        (any backend) carries it to the other ranks once."""
+        if self._rccl_comm is None:
+            lib = _capi.lib()
+            dist = _dist()
+            buf = ctypes.create_string_buffer(128)
+            if self.rank == 0:
+                _capi.check(lib.fb_comm_unique_id(buf), 'fb_comm_unique_id')
+            box = [bytes(buf.raw)]
+            dist.broadcast_object_list(box, src=0)
+            comm = ctypes.c_void_p()
+            _capi.check(lib.fb_comm_init(ctypes.c_char_p(box[0]), self.rank, self.size,
+                                         ctypes.byref(comm)), 'fb_comm_init')
+            self._rccl_comm = comm
+        return self._rccl_comm
+
+    def _exchange_rccl(self, send_left, send_right, recv_left, recv_right):
+        def pb(x):
+            return (None, 0) if x is None else (x.data_ptr(), x.numel() * x.element_size())
+        for x in (send_left, send_right, recv_left, recv_right):
+            assert x is None or x.is_contiguous()
+        sl, sr, rl, rr = pb(send_left), pb(send_right), pb(recv_left), pb(recv_right)
+        left = -1 if self.left_proc is None else self.left_proc
+        right = -1 if self.right_proc is None else self.right_proc
+        rc = _capi.lib().fb_exchange(self._rccl_communicator(), left, right, sl[0], sl[1], sr[0], sr[1],
+                                     rl[0], rl[1], rr[0], rr[1], _capi.stream())
+        _capi.check(rc, 'fb_exchange')
 
     # ---------------------------------------------------------------- gathering (diagnostics)
     def gather_grid_array(self, array, root=0, with_damp=False):

@@ -12,12 +12,9 @@
 // shares the same B operand; the two accumulators hold re/im of the same output element
 // in the same lane/register, so the store is again one 16-B complex write.
 //
-// Tiling: workgroup = 4 waves = 64 z rows x 64 output columns; wave w owns rows
-// [16w,16w+16) and 4 column sub-tiles -> 8 independent accumulator chains (64 VGPRs): one
-// wave per SIMD keeps the 64-cycle f64 MFMA pipe busy as long as its operands arrive.
-// Operands are double-buffered through LDS (see k_hankel): fragment-shaped loads straight
-// from global memory touch 16 half-used cache lines per instruction and saturate the
-// texture-address path long before the MFMA pipe (measured: 12% of peak).
+// Operands are staged through LDS (see k_hankel): fragment-shaped loads straight from global
+// memory touch 16 half-used cache lines per instruction and saturate the texture-address path
+// long before the MFMA pipe (measured in round 1: 12% of peak).
 // Jobs (field x mode) are batched along gridDim.z so one launch fills 256 CUs.
 //
 // Fragment layouts (cdna_hip_programming.md section 3, f64 row formula):
@@ -48,35 +45,28 @@ struct HankelScales {
     const double *fr[HK_MAXJOBS];     // per output column n (filter along r), or null
 };
 
-constexpr int HK_KC = 32;                 // k-chunk staged per pipeline stage
-constexpr int HK_RSA = HK_KC * 2 + 2;     // A panel row stride in doubles (16-B pad: rows rotate banks)
-constexpr int HK_RSB = 64 + 16;           // B panel row stride in doubles (+128 B: k rows alternate bank halves)
-constexpr int HK_TZ = 32;                 // z rows per workgroup
-constexpr int HK_ABUF = HK_TZ * HK_RSA;   // doubles per A buffer
-constexpr int HK_BBUF = HK_KC * HK_RSB;   // doubles per B buffer
-constexpr size_t HK_LDS_BYTES = (size_t)2 * (HK_ABUF + HK_BBUF) * 8;
-
-// Workgroup = 4 waves (2 x 2) = 32 z rows x 64 output columns; wave (wz, wn) owns rows
-// [16 wz, +16) and columns [32 wn, +32): 2 column sub-tiles x (re, im) = 4 accumulator
-// chains.  The small tile keeps the launch balanced over 256 CUs (C2: 768 workgroups for
-// E+B, 3 per CU, two co-resident so one's load latency hides under the other's MFMAs).
-// Measured limits (rocprofv3 + tools/hankel_probe.py): 55-58 % MfmaUtil at 2048 x 512 and
-// 4096 x 256, 30-40 % at 1024 x 128 where a launch holds only 2-12 transforms of 67 MFLOP
-// (LdsUtil 7-20 %, no bank conflicts, L2 hit rate 83 %).  Variants tried and discarded
-// because they changed nothing at the headline size: all operands of a chunk requested up
-// front, XCD-aware tile order, matrix column block stationary in LDS with fragment-shaped
-// global loads of the input (with and without split-K across waves), matrix columns
-// stationary in registers with the input tile streamed through LDS by a persistent
-// workgroup.  All land on ~2 us per transform = its memory phase (~1 us for 4 MB in + out,
-// measured with the MFMAs removed) plus its MFMA phase (~0.9 us): at this size the two do
-// not overlap whatever the tiling.  A register-only loop of the same MFMA sustains 66-72
-// TFLOP/s (tools/mfma4_probe.hip), so the instruction itself is not the limit.
-// K is walked in chunks of 32:
-//   global -> registers (coalesced: full 512-B row segments of the complex input and of the
-//   matrix) for chunk c+1 is issued BEFORE the 32 MFMAs (2048 cycles) of chunk c, then
-//   written to the other LDS buffer; one barrier per chunk.  MFMA operands come from LDS
-//   (padded panels, conflict-free ds_read_b128 / ds_read_b64), so the vector-memory path
-//   only sees coalesced traffic and each matrix element is fetched once per workgroup.
+// Tiling.  Workgroup = 4 waves (2 x 2) = 32 z rows x 64 output columns; wave (wz, wn) owns rows
+// [16 wz, +16) and columns [32 wn, +32): 2 column sub-tiles x (re, im) = 4 accumulator chains.
+// K is walked in chunks of 16 through double-buffered LDS panels (A[row][k] complex, row
+// stride 2*16+2 doubles: the ds_read_b128 of 16 rows hits 64 distinct banks; B[k][n] doubles,
+// row stride 64+16: the four k rows of a fragment alternate between the two bank halves), with
+// TWO register stages in front of them: the coalesced global loads (256-B row segments of the
+// input, full rows of the matrix panel) of chunk c+2 are issued before the MFMAs of chunk c,
+// those of chunk c+1 - issued one chunk earlier - are written to the other LDS buffer after
+// them; one barrier per chunk.
+//
+// What limits the transform at the headline size (1024 x 128: 67 MFLOP and 4 MB per job) is not
+// the matrix pipe but keeping it fed (rocprofv3 SQ counters, profiles/): the round-1 kernel
+// (K-chunks of 32, one register stage, 75 KB of LDS -> two of the three workgroups of a CU
+// resident) ran its load / compute / store phases in lockstep across the chip, 1.1 waves
+// resident per SIMD on average, MFMA pipe 31 % busy.  With 38 KB of LDS all workgroups of a
+// launch are resident at once (768 for E + B: every SIMD holds exactly 3 waves, no second
+// round), and two chunks of global traffic are in flight per workgroup: 27.1 -> 22.6 us for
+// the 12 transforms of E + B at 1024 x 128, 1080 -> 867 us for the 24 of 2048 x 512 (Nm = 4),
+// 283 -> 224 us at 4096 x 256.  Larger tiles (32 x 128 and 64 x 128 with 8 / 16 accumulator
+// chains per wave, which re-read the matrix 2-4x less often) are no faster at any of the three
+// sizes and lose at the headline size, where they leave whole SIMDs without a wave.
+//
 // DUAL (backward transform of a vector field, (p, m) -> (r, t) folded into the GEMM,
 // spectral_transformer.py:89-155): a job with in2 != 0 computes BOTH p' = in . mat and
 // m' = in2 . mat2 (K walked over the first product, then over the second, two accumulator
@@ -84,10 +74,26 @@ constexpr size_t HK_LDS_BYTES = (size_t)2 * (HK_ABUF + HK_BBUF) * 8;
 //   out = p' + m' (the r slot)  and  out2 = i (p' - m') (the t slot).
 // in2 comes from Pr.in2, mat2 travels in Sc.sk and out2 in Sc.fz; jobs with in2 == 0 are
 // plain transforms (the z components).
-template <bool SCALED, bool PAIRED, bool DUAL = false>
-__global__ __launch_bounds__(256) void k_hankel(HankelJobs J, HankelScales Sc, HankelPairs Pr, long irs,
-                                                long ors, double alpha, int Nz, int Nr)
+constexpr int H2_KC = 16;
+constexpr int H2_RSA = 2 * H2_KC + 2;
+// 4 waves = WZ x WN (rows x columns) of wave tiles of 16 rows x WC columns
+template <int WC, int WN> struct H2Cfg {
+    static constexpr int WZ = 4 / WN;
+    static constexpr int TZ = 16 * WZ, TN = WC * WN;        // rows / columns per workgroup
+    static constexpr int RSB = TN + 16;
+    static constexpr int ABUF = TZ * H2_RSA, BBUF = H2_KC * RSB;
+    static constexpr size_t LDS_BYTES = (size_t)2 * (ABUF + BBUF) * 8;
+};
+
+template <bool SCALED, bool PAIRED, bool DUAL, int WC, int WN, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 4))) void k_hankel(HankelJobs J, HankelScales Sc, HankelPairs Pr, long irs,
+                                                 long ors, double alpha, int Nz, int Nr)
 {
+    using C = H2Cfg<WC, WN>;
+    constexpr int TZ = C::TZ, TN = C::TN, NT = WC / 16;     // NT: column tiles per wave
+    constexpr int H2_RSB = C::RSB;
+    constexpr int NA = TZ * H2_KC / 256;                    // complex A elements per thread and chunk
+    constexpr int NB = H2_KC * TN / 2 / 256;                // matrix element pairs per thread and chunk
     extern __shared__ double hk_lds[];
     const int job = blockIdx.z;
     const cplx *__restrict__ in = J.in[job];
@@ -99,33 +105,38 @@ __global__ __launch_bounds__(256) void k_hankel(HankelJobs J, HankelScales Sc, H
     const double *__restrict__ mat = J.mat[job];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    const int wz = wave >> 1, wn = wave & 1;
-    const int zb = blockIdx.x * HK_TZ, n0 = blockIdx.y * 64;
+    const int wrow = wave / WN;                             // 16-row block of this wave
+    const int wcol = WC * (wave % WN);                      // first column of this wave in the tile
+    const int zb = blockIdx.x * TZ, n0 = blockIdx.y * TN;
     const double *sk = SCALED ? Sc.sk[job] : nullptr;
 
-    double4_t acc_re[2], acc_im[2], acc2_re[2], acc2_im[2];
+    double4_t acc_re[NT], acc_im[NT];
+    double4_t acc2_re[DUAL ? NT : 1], acc2_im[DUAL ? NT : 1];
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
+    for (int t = 0; t < NT; t++) {
         acc_re[t] = (double4_t){0., 0., 0., 0.};
         acc_im[t] = (double4_t){0., 0., 0., 0.};
+    }
+#pragma unroll
+    for (int t = 0; t < (DUAL ? NT : 1); t++) {
         acc2_re[t] = (double4_t){0., 0., 0., 0.};
         acc2_im[t] = (double4_t){0., 0., 0., 0.};
     }
-    // staging registers: A chunk = 32 rows x 32 complex (4 per thread), B chunk = 32 x 64
-    // doubles (8 per thread)
-    double2 ra[4];
-    double rb[8];
-    const int nchunks = (Nr + HK_KC - 1) / HK_KC;
-    // chunk index -> which of the two products it belongs to (DUAL), and its k offset
-    auto gload = [&](int c) {
+    // two register stages: the loads of chunk c+2 are issued before the MFMAs of chunk c (the
+    // loads of chunk c+1 were issued one chunk earlier and are written to LDS after them), so a
+    // single resident workgroup per CU keeps two chunks of global traffic in flight
+    double2 ra0[NA], ra1[NA];
+    double2 rb0[NB], rb1[NB];
+    const int nchunks = (Nr + H2_KC - 1) / H2_KC;
+    auto gload = [&](int c, double2 *ra, double2 *rb) {
         const bool second = DUAL && c >= nchunks;
-        const int k0 = (second ? c - nchunks : c) * HK_KC;
+        const int k0 = (second ? c - nchunks : c) * H2_KC;
         const cplx *__restrict__ src = second ? in2 : in;
         const double *__restrict__ mm = second ? mat2 : mat;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < NA; j++) {
             const int idx = j * 256 + tid;
-            const int row = idx >> 5, kk = idx & 31;
+            const int row = idx >> 4, kk = idx & 15;        // 16 lanes = 256 contiguous bytes of a row
             const int zz = zb + row, k = k0 + kk;
             double2 v = make_double2(0., 0.);
             if (zz < Nz && k < Nr) {
@@ -141,46 +152,48 @@ __global__ __launch_bounds__(256) void k_hankel(HankelJobs J, HankelScales Sc, H
             ra[j] = v;
         }
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int idx = j * 256 + tid;
-            const int kr = idx >> 6, nn = idx & 63;
+        for (int j = 0; j < NB; j++) {
+            const int idx = j * 256 + tid;                  // pair index: TN/2 pairs per k row
+            const int kr = idx / (TN / 2), nn = 2 * (idx % (TN / 2));
             const int k = k0 + kr, n = n0 + nn;
-            rb[j] = (k < Nr && n < Nr) ? mm[(long)k * Nr + n] : 0.;
+            double2 v = make_double2(0., 0.);
+            if (k < Nr) {
+                const double *mrow = mm + (long)k * Nr;
+                if (n + 1 < Nr && ((Nr & 1) == 0)) v = *(const double2 *)(mrow + n);
+                else { if (n < Nr) v.x = mrow[n]; if (n + 1 < Nr) v.y = mrow[n + 1]; }
+            }
+            rb[j] = v;
         }
     };
-    auto lstore = [&](int buf) {
-        double *A = hk_lds + buf * (HK_ABUF + HK_BBUF);
-        double *B = A + HK_ABUF;
+    auto lstore = [&](int buf, const double2 *ra, const double2 *rb) {
+        double *A = hk_lds + buf * (C::ABUF + C::BBUF);
+        double *B = A + C::ABUF;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < NA; j++) {
             const int idx = j * 256 + tid;
-            *(double2 *)(A + (idx >> 5) * HK_RSA + 2 * (idx & 31)) = ra[j];
+            *(double2 *)(A + (idx >> 4) * H2_RSA + 2 * (idx & 15)) = ra[j];
         }
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
+        for (int j = 0; j < NB; j++) {
             const int idx = j * 256 + tid;
-            B[(idx >> 6) * HK_RSB + (idx & 63)] = rb[j];
+            *(double2 *)(B + (idx / (TN / 2)) * H2_RSB + 2 * (idx % (TN / 2))) = rb[j];
         }
     };
     const int ntot = (DUAL && in2) ? 2 * nchunks : nchunks;
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    for (int c = 0; c < ntot; c++) {
+    auto compute = [&](int c) {
         const int cur = c & 1;
-        if (c + 1 < ntot) gload(c + 1);
-        const double *A = hk_lds + cur * (HK_ABUF + HK_BBUF) + (wz * 16 + li) * HK_RSA;
-        const double *B = hk_lds + cur * (HK_ABUF + HK_BBUF) + HK_ABUF + 32 * wn;
+        const double *A = hk_lds + cur * (C::ABUF + C::BBUF) + (wrow * 16 + li) * H2_RSA;
+        const double *B = hk_lds + cur * (C::ABUF + C::BBUF) + C::ABUF + wcol + li;
         auto mma_chunk = [&](double4_t *are, double4_t *aim) {
 #pragma unroll
-            for (int s = 0; s < HK_KC / 4; s++) {
+            for (int s = 0; s < H2_KC / 4; s++) {
                 const double2 a = *(const double2 *)(A + 2 * (4 * s + lk));
-                const double *brow = B + (4 * s + lk) * HK_RSB + li;
-                double b[2];
+                const double *brow = B + (4 * s + lk) * H2_RSB;
+                double b[NT];
 #pragma unroll
-                for (int t = 0; t < 2; t++) b[t] = brow[16 * t];
+                for (int t = 0; t < NT; t++) b[t] = brow[16 * t];
 #pragma unroll
-                for (int t = 0; t < 2; t++) {
+                for (int t = 0; t < NT; t++) {
                     are[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b[t], are[t], 0, 0, 0);
                     aim[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b[t], aim[t], 0, 0, 0);
                 }
@@ -188,16 +201,29 @@ __global__ __launch_bounds__(256) void k_hankel(HankelJobs J, HankelScales Sc, H
         };
         if (DUAL && c >= nchunks) mma_chunk(acc2_re, acc2_im);
         else mma_chunk(acc_re, acc_im);
-        if (c + 1 < ntot) lstore(cur ^ 1);
+    };
+    gload(0, ra0, rb0);
+    lstore(0, ra0, rb0);
+    if (ntot > 1) gload(1, ra1, rb1);
+    __syncthreads();
+    for (int c = 0; c < ntot; c += 2) {
+        if (c + 2 < ntot) gload(c + 2, ra0, rb0);
+        compute(c);
+        if (c + 1 < ntot) lstore(1, ra1, rb1);
+        __syncthreads();
+        if (c + 1 >= ntot) break;
+        if (c + 3 < ntot) gload(c + 3, ra1, rb1);
+        compute(c + 1);
+        if (c + 2 < ntot) lstore(0, ra0, rb0);
         __syncthreads();
     }
     const bool pair = DUAL && in2;
-    const int z0 = zb + wz * 16;
+    const int z0 = zb + wrow * 16;
     const double *fz = SCALED ? Sc.fz[job] : nullptr;
     const double *fr = SCALED ? Sc.fr[job] : nullptr;
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
-        const int n = n0 + 32 * wn + 16 * t + li;
+    for (int t = 0; t < NT; t++) {
+        const int n = n0 + wcol + 16 * t + li;
         if (n >= Nr) continue;
         double cn = alpha;
         if (SCALED && fr) cn *= fr[n];
@@ -209,7 +235,7 @@ __global__ __launch_bounds__(256) void k_hankel(HankelJobs J, HankelScales Sc, H
                 if (SCALED && fz) cz = fz[zz] * cn;     // fz[iz]*fr[ir]*F as in numba_filter_*
                 if (pair) {
                     const double pr = cz * acc_re[t][r], pi = cz * acc_im[t][r];
-                    const double mr = cz * acc2_re[t][r], mi = cz * acc2_im[t][r];
+                    const double mr = cz * acc2_re[DUAL ? t : 0][r], mi = cz * acc2_im[DUAL ? t : 0][r];
                     *(double2 *)(out + (long)zz * ors + n) = make_double2(pr + mr, pi + mi);
                     *(double2 *)(out2 + (long)zz * ors + n) = make_double2(-(pi - mi), pr - mr);
                 } else {
@@ -219,6 +245,24 @@ __global__ __launch_bounds__(256) void k_hankel(HankelJobs J, HankelScales Sc, H
             }
         }
     }
+}
+
+template <bool SCALED, bool PAIRED, bool DUAL, int WC, int WN, int WPE>
+static int launch_tile(const HankelJobs &J, const HankelScales &Sc, const HankelPairs &Pr, int nj, long irs,
+                   long ors, double alpha, int Nz, int Nr, hipStream_t s)
+{
+    using C = H2Cfg<WC, WN>;
+    auto kern = k_hankel<SCALED, PAIRED, DUAL, WC, WN, WPE>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e1 = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)C::LDS_BYTES);
+        if (e1 != hipSuccess) return check(e1, "fb_hankel(attr)");
+        attr_done = true;
+    }
+    dim3 grid((Nz + C::TZ - 1) / C::TZ, (Nr + C::TN - 1) / C::TN, nj);
+    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, s, J, Sc, Pr, irs, ors, alpha, Nz, Nr);
+    return check(hipGetLastError(), "fb_hankel");
 }
 
 static int launch(int njobs, const void *const *in, long irs, void *const *out, long ors,
@@ -246,32 +290,15 @@ static int launch(int njobs, const void *const *in, long irs, void *const *out, 
             Sc.fz[j] = (v && dual) ? (const double *)out2[j0 + j] : ((v && fz) ? fz[j0 + j] : nullptr);
             Sc.fr[j] = (v && fr) ? fr[j0 + j] : nullptr;
         }
-        dim3 grid((Nz + HK_TZ - 1) / HK_TZ, (Nr + 63) / 64, nj);
-        static bool attr_done = false;
-        if (!attr_done) {
-            const void *ks[4] = {(const void *)k_hankel<true, true>, (const void *)k_hankel<true, false>,
-                                 (const void *)k_hankel<false, false>,
-                                 (const void *)k_hankel<false, false, true>};
-            for (int i = 0; i < 4; i++) {
-                hipError_t e1 = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                    (int)HK_LDS_BYTES);
-                if (e1 != hipSuccess) return check(e1, "fb_hankel(attr)");
-            }
-            attr_done = true;
-        }
-        if (dual)
-            hipLaunchKernelGGL((k_hankel<false, false, true>), grid, dim3(256), HK_LDS_BYTES, s, J, Sc, Pr,
-                               irs, ors, alpha, Nz, Nr);
-        else if (paired)
-            hipLaunchKernelGGL((k_hankel<true, true>), grid, dim3(256), HK_LDS_BYTES, s, J, Sc, Pr, irs, ors,
-                               alpha, Nz, Nr);
-        else if (scaled)
-            hipLaunchKernelGGL((k_hankel<true, false>), grid, dim3(256), HK_LDS_BYTES, s, J, Sc, Pr, irs, ors,
-                               alpha, Nz, Nr);
-        else
-            hipLaunchKernelGGL((k_hankel<false, false>), grid, dim3(256), HK_LDS_BYTES, s, J, Sc, Pr, irs, ors,
-                               alpha, Nz, Nr);
-        int r = check(hipGetLastError(), "fb_hankel");
+        // wave tile: 16 x 128 columns when that still gives every CU a workgroup, else 16 x 64
+        // (twice the workgroups); the dual (two accumulator sets) variant always uses 16 x 64
+        int r;
+#define H2(SC, PA, DU, WP) launch_tile<SC, PA, DU, 32, 2, WP>(J, Sc, Pr, nj, irs, ors, alpha, Nz, Nr, s)
+        if (dual) r = H2(false, false, true, 2);
+        else if (paired) r = H2(true, true, false, 3);
+        else if (scaled) r = H2(true, false, false, 3);
+        else r = H2(false, false, false, 3);
+#undef H2
         if (r) return r;
     }
     return 0;

@@ -38,6 +38,32 @@ const char *fb_last_error(void);
 int fb_set_device(int device);
 int fb_sync(void *stream);
 
+/* ---- transport between the z-slabs of neighbouring ranks (one rank per GPU) ----------------
+ * Replaces BoundaryCommunicator.exchange_domains, fbpic/boundaries/boundary_communicator.py:
+ * 674-707 (mpi_comm.Isend / Irecv / Wait of the four guard-cell or particle buffers), with RCCL
+ * point-to-point over xGMI INSIDE the library: a host application that binds this C ABI (CuPy +
+ * mpi4py in the reference) gets the multi-GPU path without torch.distributed.
+ *   fb_comm_unique_id : 128-byte id created on one rank; the host distributes it to the others
+ *                       by whatever it already has (MPI bcast, a file, torch.distributed)
+ *   fb_comm_init      : collective over `size` ranks (ncclCommInitRank); call after
+ *                       fb_set_device
+ *   fb_exchange       : one grouped launch (ncclGroupStart, <= 2 ncclSend + 2 ncclRecv,
+ *                       ncclGroupEnd) on `stream`: ordered after the kernels that filled the send
+ *                       buffers (e.g. fb_guard_buffers mode 0) and before those that read the
+ *                       receive buffers; no host synchronisation.  left_rank / right_rank < 0:
+ *                       no neighbour on that side (open boundary).  Sizes in bytes; both sides
+ *                       must agree on them (send_left of a rank pairs with recv_right of its left
+ *                       neighbour).  A 2-rank periodic ring (left_rank == right_rank) is handled.
+ * RCCL is loaded at run time (the copy already in the process, else librccl.so.1 of ROCm). */
+int fb_comm_unique_id(void *id128);
+int fb_comm_init(const void *id128, int rank, int size, void **comm);
+int fb_comm_destroy(void *comm);
+int fb_exchange(void *comm, int left_rank, int right_rank,
+                const void *send_left, size_t send_left_bytes,
+                const void *send_right, size_t send_right_bytes,
+                void *recv_left, size_t recv_left_bytes,
+                void *recv_right, size_t recv_right_bytes, void *stream);
+
 /* ---- particle push ---------------------------------------------------------- */
 /* particles/particles.py:660-663 -> push_x_gpu (push/cuda_methods.py:16-52);
  * arithmetic order of the CPU twin push_x_numba (push/numba_methods.py:16-32). */
