@@ -10,7 +10,17 @@ cells in z), dz = dr = 0.2 um, dt = dz/c, z-periodic, linear shape, curl-free co
 filtered currents, thermal momenta N(0, 0.01^2).  A "step" is one full PIC cycle
 (Simulation.step: sort, deposit rho/J, transforms, gather, Vay push, PSATD solve).
 With N > 1 ranks the domain is decomposed in z (one rank per GPU, RCCL guard-cell
-exchange); every rank owns a 1024-cell slab (weak scaling: global Nz = 1024 * N).
+exchange).  --scaling weak (default): every rank owns a 1024-cell slab (global Nz = 1024 * N,
+"C2 per rank x N"); --scaling strong: the fixed 1024 x 128 box of BASELINE.json is cut into N
+slabs (n_order = 32, n_guard = 64: 128 + 2 x 64 local rows at N = 8).
+
+Inside the timed region Simulation.step runs its default MI355X orchestration, which differs
+from the reference's launch sequence in three sanctioned ways (results
+equal within the stated tolerances, named in config.workload): rho_prev is not re-deposited
+after the first step of a call on a single periodic domain, the iFFT/FFT round trip of E, B
+on a single periodic domain is skipped, and the gathered E, B are written to the particle
+arrays only on the last step.  --reference-sequence turns all of that (and the kernel
+fusions) off: every operation of fbpic/main.py:346-586 is launched on its own.
 
 Prints ONE JSON line on rank 0.  `value` = macroparticle updates per second over all
 ranks with all data resident in HBM.  `roofline` is for the kernel with the largest
@@ -46,12 +56,31 @@ WORK = {
     # push_x folded into the counting sort (pre-ranked): 8 arrays + cell + rank read, 8 arrays +
     # sorted cell + permutation written (sort = implementation overhead)
     'fb_push_x_bin_sort_particles': ('hbm', lambda a: 144.0 * a[0]),
+    # destination-ordered push_x + sort + rho deposition: permutation (4 B) + 8 arrays read,
+    # 8 arrays written (union rule; building the permutation is sort overhead, as above)
+    'fb_push_x_sort_deposit_rho': ('hbm', lambda a: 132.0 * a[0]),
     'fb_zfft': ('hbm', lambda a: 32.0 * a[0] * a[1]),
     'fb_cell_index': ('hbm', lambda a: 32.0 * a[0]),
     'fb_sort_by_cell': ('hbm', lambda a: 16.0 * a[0]),          # one read+write of (key, value)
     'fb_permute': ('hbm', lambda a: (16.0 * a[2] + 4.0) * a[0]),
     'fb_shift_periodic': ('hbm', lambda a: 8.0 * a[0]),
     'fb_hankel': ('mfma', lambda a: 4.0 * a[7] * a[8] * a[8] * a[0]),
+    # (p | m) formed in the operand load: same GEMM work per job
+    'fb_hankel_rt_to_pm_scaled': ('mfma', lambda a: 4.0 * a[12] * a[13] * a[13] * a[0]),
+    'fb_hankel_scaled': ('mfma', lambda a: 4.0 * a[10] * a[11] * a[11] * a[0]),
+    # pair jobs carry two products
+    'fb_hankel_pm_to_rt': ('mfma', lambda a: 4.0 * a[10] * a[11] * a[11]
+                           * sum(2 if a[2][j] else 1 for j in range(a[0]))),
+}
+
+
+SEQUENCE_NOTE = {
+    False: 'fused MI355X sequence: gather+push_p+push_x one pass, J deposit pre-ranks the sort, '
+           'push_x+sort+rho deposit one pass; sanctioned skips inside the timed region: rho_prev '
+           're-deposit after the first step of a call, identity iFFT/FFT of E,B on the single '
+           'periodic domain, gathered E,B stored on the last step only',
+    True: "reference sequence (fbpic/main.py:346-586): every operation its own launch, rho_prev "
+          "re-deposited every step, E,B stored by every gather",
 }
 
 
@@ -70,14 +99,21 @@ def parse():
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--resort-fragmentation', type=float, default=None,
                     help='override Particles.resort_fragmentation (adaptive sort policy)')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
+    ap.add_argument('--reference-sequence', action='store_true',
+                    help="the reference's launch sequence: no fusion, rho_prev re-deposited every step")
     return ap.parse_args()
 
 
-def config_name(args, ppc):
-    """Which entry of BASELINE.json's `configs` the per-rank workload is (C2 = configs[1], the
-    one the metric is quoted on; C5 = configs[4]); anything else is a custom size."""
+def config_name(args, ppc, world):
+    """Which entry of BASELINE.json's `configs` the workload is (C2 = configs[1], the one the
+    metric is quoted on; C5 = configs[4]); anything else is a custom size.  A weak-scaling run
+    on N > 1 ranks is N slabs of that size, not the configuration itself."""
     key = (args.Nz, args.Nr, args.Nm, ppc[0] * ppc[1] * ppc[2], args.shape)
-    return {(1024, 128, 2, 32, 'linear'): 'C2', (2048, 512, 4, 64, 'cubic'): 'C5'}.get(key, 'custom')
+    name = {(1024, 128, 2, 32, 'linear'): 'C2', (2048, 512, 4, 64, 'cubic'): 'C5'}.get(key, 'custom')
+    if world > 1 and args.scaling == 'weak':
+        return '%s-per-rank x%d' % (name, world)
+    return name
 
 
 def main():
@@ -107,9 +143,18 @@ def main():
     from fbpic_amd.main import GpuMemoryManager
     ppc = tuple(int(v) for v in args.ppc.split(','))
     n_order = -1 if world == 1 else 32
-    # weak scaling: every rank owns args.Nz cells; the Simulation is given the global box
-    sim = helpers.uniform_plasma_sim(args.Nz * world, args.Nr, args.Nm, ppc, args.shape, seed=0,
+    # weak scaling: every rank owns args.Nz cells; strong: the args.Nz cells are divided.
+    # The Simulation is given the global box either way.
+    Nz_global = args.Nz * world if args.scaling == 'weak' else args.Nz
+    sim = helpers.uniform_plasma_sim(Nz_global, args.Nr, args.Nm, ppc, args.shape, seed=0,
                                      n_order=n_order, n_guard=(None if world == 1 else 64))
+    if args.reference_sequence:
+        sim.redeposit_rho_prev_every_step = True
+        sim.fuse_gather_push = False
+        sim.prerank_in_deposit = False
+        sim.reference_sequence = True
+        for sp in sim.ptcl:
+            sp.fuse_sort_deposit_rho = False
     if args.resort_fragmentation is not None:
         for sp in sim.ptcl:
             sp.resort_fragmentation = args.resort_fragmentation
@@ -154,23 +199,55 @@ def main():
         'metric': 'particle-updates/sec', 'value': value, 'unit': 'particle-updates/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * dt_wall / args.steps, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'ns_per_particle_step': 1e9 * dt_wall / (args.steps * n_total) * world,
         'config': {'workload': '%s uniform plasma %dx%d Nm=%d %d ppc %s shape, z-periodic, '
-                               'standard PSATD n_order=%d, curl-free correction, filtered'
-                               % (config_name(args, ppc), args.Nz * world, args.Nr, args.Nm,
-                                  ppc[0] * ppc[1] * ppc[2],
-                                  args.shape, n_order),
-                   'particles': n_total, 'parallelism': 'z-slab x%d' % world},
+                               'standard PSATD n_order=%d, curl-free correction, filtered; %s'
+                               % (config_name(args, ppc, world), Nz_global, args.Nr, args.Nm,
+                                  ppc[0] * ppc[1] * ppc[2], args.shape, n_order,
+                                  SEQUENCE_NOTE[bool(args.reference_sequence)]),
+                   'particles': n_total, 'parallelism': 'z-slab x%d' % world,
+                   'sequence': 'reference' if args.reference_sequence else 'fused'},
     }
     if kern:
-        out['roofline'], out['kernels'] = roofline(kern)
+        ceil = measured_ceilings(torch)
+        out['roofline'], out['kernels'] = roofline(kern, ceil)
+        out['measured_ceilings'] = ceil
     if cpu_base:
         out['cpu_baseline'] = cpu_base
     print(json.dumps(out))
 
 
-def roofline(kern):
+def measured_ceilings(torch):
+    """Ceilings of THIS box, measured next to the run (SURVEY.md 8d asks for the fraction of
+    both the datasheet and the measured ceiling): fp64 stream triad a = b + s*c over 3 x 256 MB
+    and a 4096^3 fp64 GEMM (rocBLAS through torch.mm)."""
+    n = 32 * 1024 * 1024
+    a = torch.empty(n, dtype=torch.float64, device='cuda')
+    b = torch.ones_like(a)
+    c = torch.ones_like(a)
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+    t_triad = timed(lambda: torch.add(b, c, alpha=1.5, out=a), 20)
+    del a, b, c
+    m = 4096
+    x = torch.randn(m, m, dtype=torch.float64, device='cuda')
+    y = torch.randn(m, m, dtype=torch.float64, device='cuda')
+    z = torch.empty_like(x)
+    t_gemm = timed(lambda: torch.mm(x, y, out=z), 5)
+    return {'triad_GBs': 3 * 8 * n / t_triad / 1e9, 'dgemm_4096_TFLOPs': 2. * m**3 / t_gemm / 1e12}
+
+
+def roofline(kern, ceil=None):
     """Per entry point: launches, mean device ms, achieved GB/s or TFLOP/s; the roofline
     object describes the entry point with the largest total device time (gather+push when it
     is within 5 % of it)."""
@@ -189,6 +266,9 @@ def roofline(kern):
                 ent.update(bound='mfma', achieved=work / (tot * 1e-3) / 1e12, unit='TFLOP/s',
                            peak=FP64_MFMA_PEAK_TFLOPS)
             ent['frac'] = ent['achieved'] / ent['peak']
+            if ceil:
+                meas = ceil['triad_GBs'] if bound == 'hbm' else ceil['dgemm_4096_TFLOPs']
+                ent['frac_of_measured'] = ent['achieved'] / meas
         table[name] = ent
     cand = sorted((n for n in table if 'frac' in table[n]), key=lambda n: -table[n]['total_ms'])
     dom = cand[0]
@@ -206,9 +286,22 @@ def roofline(kern):
     roof = {'kernel': dom, 'bound': d['bound'], 'achieved': d['achieved'], 'peak': d['peak'],
             'unit': d['unit'], 'frac': d['frac'], 'traffic': None,
             'mean_launch_ms': d['mean_ms']}
+    if 'frac_of_measured' in d:
+        roof['frac_of_measured'] = d['frac_of_measured']
     roof.update(pmc_traffic(dom))
+    # the Hankel GEMM (the MFMA-bound kernel of the path) next to it: all launches together
+    hk = [table[n] for n in table if n.startswith('fb_hankel') and 'achieved' in table[n]]
+    if hk:
+        tot_ms = sum(e['total_ms'] for e in hk)
+        flops = sum(e['achieved'] * 1e12 * e['total_ms'] * 1e-3 for e in hk)
+        roof['hankel'] = {'bound': 'mfma', 'achieved': flops / (tot_ms * 1e-3) / 1e12,
+                          'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                          'frac': flops / (tot_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                          'launches': sum(e['launches'] for e in hk)}
+        if ceil:
+            roof['hankel']['frac_of_measured'] = roof['hankel']['achieved'] / ceil['dgemm_4096_TFLOPs']
     compact = {n: {k: (round(v, 5) if isinstance(v, float) else v) for k, v in e.items()
-                   if k in ('launches', 'mean_ms', 'achieved', 'unit', 'frac')}
+                   if k in ('launches', 'mean_ms', 'achieved', 'unit', 'frac', 'frac_of_measured')}
                for n, e in table.items()}
     return roof, compact
 
@@ -219,6 +312,7 @@ _KERNEL_OF = {
     'fb_deposit_J_rank_next': ('k_deposit<', ', 3, ', 'true, true>'),
     'fb_deposit_J': ('k_deposit<', ', 3, '), 'fb_deposit_rho': ('k_deposit<', ', 1, '),
     'fb_push_x_bin_sort_particles': ('k_scatter<true>',), 'fb_push_x': ('k_push_x',),
+    'fb_push_x_sort_deposit_rho': ('k_deposit<', ', 1, ', 'false, true>'),
     'fb_push_p': ('k_push_p',),
 }
 
@@ -266,6 +360,16 @@ def available_cores():
     return n
 
 
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
 def cpu_baseline(sim, args):
     """CPU oracle (port of the reference's Numba-threaded CPU path) on the same workload:
     `cpu_steps` full PIC cycles at full size, one thread per available core."""
@@ -277,8 +381,15 @@ def cpu_baseline(sim, args):
     o.step(args.cpu_steps)
     dt = time.perf_counter() - t0
     n = sum(s['x'].size for s in o.species)
+    # single-thread figure: one more step of the same state on one core
+    orc.set_threads(1)
+    o.nthreads = 1
+    o.glob = [g[:1] for g in o.glob]
+    t1 = time.perf_counter()
+    o.step(1)
+    dt1 = time.perf_counter() - t1
     return {'value': n * args.cpu_steps / dt, 'unit': 'particle-updates/s', 'cores': nthreads,
-            'kind': 'port',
+            'single_thread': n / dt1, 'cpu_model': cpu_model(), 'kind': 'port',
             'sample': '%d full PIC steps of the same %dx%d Nm=%d %d-particle workload '
                       '(after 1 warm-up step), C/OpenMP oracle + NumPy FFT/dot'
                       % (args.cpu_steps, sim.fld.Nz, sim.fld.Nr, sim.fld.Nm, n),

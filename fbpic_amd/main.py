@@ -124,6 +124,11 @@ class Simulation(object):
         self._in_step = False
         # gather + push_p + push_x(dt/2) in one kernel when no hook sits between them
         self.fuse_gather_push = True
+        # True: launch every operation of the reference's step on its own, in the reference's
+        # order (no fused transforms / solver launch, no deferred push, identity FFT round trip
+        # of E, B kept): the baseline the fused sequence is measured against (bench.py
+        # --reference-sequence); results identical within the test tolerances
+        self.reference_sequence = False
 
     # -------------------------------------------------------------------- PIC cycle
     def step(self, N=1, correct_currents=True, correct_divE=False, use_true_rho=False,
@@ -212,7 +217,8 @@ class Simulation(object):
                 # (not with a Galilean grid: zmin moves between this deposit and that sort)
                 for species in ptcl:
                     species.push_after_deposit_J = (0.5 * dt, 1., 1., 1.)
-            self.deposit('J', exchange=(correct_currents is False), defer_transform=not cross)
+            self.deposit('J', exchange=(correct_currents is False),
+                         defer_transform=(not cross) and not self.reference_sequence)
             for species in ptcl:
                 species.push_after_deposit_J = None
             if cross:
@@ -220,7 +226,7 @@ class Simulation(object):
             if move_positions:
                 # deferred: the push is folded into the sort that deposit('rho_next') triggers
                 for species in ptcl:
-                    species.push_x(0.5 * dt, defer=True)
+                    species.push_x(0.5 * dt, defer=not self.reference_sequence)
             if self.use_galilean:
                 self.shift_galilean_boundaries(0.5 * dt)
             self.deposit('rho_next', exchange=(use_true_rho is True))
@@ -236,6 +242,11 @@ class Simulation(object):
                         fld.partial_interp2spect('J')
                     fld.exchanged_source['J'] = True
                 fld.push(use_true_rho, check_exchanges=(self.comm.size > 1))
+            elif self.comm.size == 1 and self.reference_sequence:
+                if correct_currents:
+                    fld.correct_currents()
+                    fld.exchanged_source['J'] = True
+                fld.push(use_true_rho)
             elif self.comm.size == 1:
                 # single domain: correction, push and rho shift are cell-local -> one launch
                 if cross:
@@ -332,7 +343,8 @@ class Simulation(object):
             kind = 'J'
         else:
             raise ValueError('Unknown fieldtype: %s' % fieldtype)
-        fused = self._in_step and update_spectral and not (exchange and self.comm.size > 1)
+        in_step = self._in_step and not self.reference_sequence
+        fused = in_step and update_spectral and not (exchange and self.comm.size > 1)
         records = False
         # node-major record target (one cache line per node): measured on MI355X, linear shape
         # deposit J 108 -> 88 us, rho 62 -> 57 us, against +10 us for the z-FFT that then
@@ -357,7 +369,7 @@ class Simulation(object):
         for species in species_list:
             species.deposit(fld, kind, records=records)
         fld.sum_reduce_deposition_array(kind)
-        if self._in_step and update_spectral and not (exchange and self.comm.size > 1):
+        if in_step and update_spectral and not (exchange and self.comm.size > 1):
             # inside step(): divide-by-volume and filter ride along in the Hankel GEMM
             # (the interpolation-grid J / rho are overwritten from spectral space before
             # anything reads them, main.py:572-577)
@@ -391,8 +403,9 @@ class Simulation(object):
         iFFT/FFT round trip of main.py:741-766 is the identity (nothing touches the
         partial-interp fields) and is skipped (difference ~1e-16 relative)."""
         fld = self.fld
-        needs_partial = (self.comm.size > 1) or (self.comm.nz_damp != 0) or len(self.mirrors) > 0
-        if needs_partial and not self.mirrors:
+        needs_partial = ((self.comm.size > 1) or (self.comm.nz_damp != 0) or len(self.mirrors) > 0
+                         or self.reference_sequence)
+        if needs_partial and not self.mirrors and not self.reference_sequence:
             # the (z-real, r-spectral) fields live in the scratch slab; after the exchange and
             # the damping, the interpolation grid follows from them by the inverse Hankel
             # transform alone: one 6*Nm-field FFT launch less than via the spectral fields

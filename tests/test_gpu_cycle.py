@@ -283,3 +283,43 @@ def test_empty_and_tiny_species_step():
             a, b = getattr(sim.fld.interp[m], k), getattr(ref.fld.interp[m], k)
             # two runs of the same input differ by the order of the deposition atomics only
             assert np.array_equal(a, b) or np.abs(a - b).max() <= 1e-11 * np.abs(b).max(), (m, k)
+
+
+@pytest.mark.parametrize('shape', ['linear', 'cubic'])
+def test_reference_sequence_equals_fused_sequence(oracle, shape):
+    """Simulation.reference_sequence (every operation of main.py:346-586 launched on its own, in
+    the reference's order, rho_prev re-deposited every step) against the default fused MI355X
+    sequence and against the oracle: the sanctioned orchestration differences (bench.py
+    config.workload) change the results at rounding level only."""
+    def build():
+        return helpers.uniform_plasma_sim(64, 32, 2, (2, 2, 8), shape, seed=9, u_th=0.05)
+    a, b = build(), build()
+    orc = helpers.oracle_from_sim(oracle, a, nthreads=2)
+    b.reference_sequence = True
+    b.redeposit_rho_prev_every_step = True
+    b.fuse_gather_push = False
+    b.prerank_in_deposit = False
+    for sp in b.ptcl:
+        sp.fuse_sort_deposit_rho = False
+    a.step(4)
+    b.step(4)
+    orc.step(4)
+    worst = 0.
+    for m in range(2):
+        for k in INTERP:
+            grp = [kk for kk in INTERP if kk[0] == k[0]]
+            scale = max(np.abs(orc.interp[mm][kk]).max() for mm in range(2) for kk in grp)
+            if scale == 0:
+                continue
+            ea = np.abs(getattr(a.fld.interp[m], k) - orc.interp[m][k]).max() / scale
+            eb = np.abs(getattr(b.fld.interp[m], k) - orc.interp[m][k]).max() / scale
+            worst = max(worst, ea, eb)
+            assert ea < 2e-11 and eb < 2e-11, (m, k, ea, eb)
+    for sa, sb in zip(a.ptcl, b.ptcl):
+        ga = np.array([getattr(sa, k) for k in PTCL[:8]])
+        gb = np.array([getattr(sb, k) for k in PTCL[:8]])
+        o1 = np.lexsort((ga[2], ga[1], ga[0], ga[7]))
+        o2 = np.lexsort((gb[2], gb[1], gb[0], gb[7]))
+        for j, k in enumerate(PTCL[:8]):
+            assert np.abs(ga[j][o1] - gb[j][o2]).max() < 1e-11 * np.abs(ga[j]).max(), k
+    print('reference vs fused sequence (%s): worst deviation from the oracle %.2e' % (shape, worst))

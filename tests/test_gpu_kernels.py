@@ -925,6 +925,41 @@ def test_push_sort_deposit_rho_fused(hip, oracle, shape, Nm, preranked, nattr, r
             assert rel_err(host(views[m]), red) < 1e-13, m
 
 
+def test_exchange_rccl_loopback(hip):
+    """fb_comm_unique_id / fb_comm_init / fb_exchange (RCCL send/recv inside the library) on a
+    1-rank communicator whose two neighbours are the rank itself - the 2-rank periodic ring
+    collapsed onto one GPU: what is sent to the left arrives from the right and vice versa,
+    stream-ordered after the kernel that produced the payload, without host synchronisation;
+    then an open boundary on one side (no message posted there)."""
+    import ctypes
+    t = hip.torch()
+    lib = hip.lib()
+    idbuf = ctypes.create_string_buffer(128)
+    hip.check(lib.fb_comm_unique_id(idbuf), 'fb_comm_unique_id')
+    comm = ctypes.c_void_p()
+    hip.check(lib.fb_comm_init(idbuf, 0, 1, ctypes.byref(comm)), 'fb_comm_init')
+    n = 6 * 2 * 64 * 128                       # E,B guard block of C2: 64 rows x 12 fields x 128
+    send_l = t.zeros(n, dtype=t.complex128, device='cuda')
+    send_r = t.zeros(n, dtype=t.complex128, device='cuda')
+    recv_l = t.full((n,), -1., dtype=t.complex128, device='cuda')
+    recv_r = t.full((n,), -1., dtype=t.complex128, device='cuda')
+    for it in range(3):
+        send_l.copy_(t.arange(n, device='cuda') + 1000. * it)          # enqueued, not synchronised
+        send_r.copy_(-(t.arange(n, device='cuda') + 1000. * it) * 1j)
+        nb = n * 16
+        hip.check(lib.fb_exchange(comm, 0, 0, hip.ptr(send_l), nb, hip.ptr(send_r), nb,
+                                  hip.ptr(recv_l), nb, hip.ptr(recv_r), nb, hip.stream()), 'fb_exchange')
+        # same-peer ring: my send-to-left is the peer's message from its right
+        assert t.equal(recv_r, send_l) and t.equal(recv_l, send_r)
+    # open boundary on the left: only the right pair is posted (to itself: send_right -> recv_right)
+    recv_l.fill_(-1.)
+    hip.check(lib.fb_exchange(comm, -1, 0, None, 0, hip.ptr(send_r), n * 16, None, 0,
+                              hip.ptr(recv_r), n * 16, hip.stream()), 'fb_exchange')
+    assert t.equal(recv_r, send_r) and bool((recv_l == -1.).all())
+    assert lib.fb_exchange(None, 0, 0, None, 0, None, 0, None, 0, None, 0, hip.stream()) != 0
+    hip.check(lib.fb_comm_destroy(comm), 'fb_comm_destroy')
+
+
 def test_guard_buffers_and_damping(hip):
     """fb_guard_buffers (pack / replace / add of the guard rows of a field group, both z ends
     in one launch; boundaries/cuda_methods.py:12-484) and fb_damp_rows (:486-640) against

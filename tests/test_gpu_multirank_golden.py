@@ -100,11 +100,19 @@ def _run_lwfa(rank, name, outdir):
     np.savez(os.path.join(outdir, 'r%d.npz' % rank), **out)
 
 
-def _worker(rank, world, port, kind, name, outdir, q):
+def _worker(rank, world, port, kind, name, outdir, q, backend='gloo'):
     try:
+        import torch
         import torch.distributed as dist
-        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank,
-                                world_size=world)
+        if backend == 'gloo':
+            dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank,
+                                    world_size=world)
+        else:       # 'nccl-torch' / 'nccl-rccl': one GPU per rank, RCCL over xGMI
+            os.environ['FBPIC_AMD_TRANSPORT'] = 'rccl' if backend == 'nccl-rccl' else 'torch'
+            os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+            torch.cuda.set_device(rank)
+            dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=rank,
+                                    world_size=world, device_id=torch.device('cuda', rank))
         (_run_periodic if kind == 'periodic' else _run_lwfa)(rank, name, outdir)
         dist.barrier()
         dist.destroy_process_group()
@@ -114,12 +122,12 @@ def _worker(rank, world, port, kind, name, outdir, q):
         q.put((rank, traceback.format_exc()))
 
 
-def _launch(kind, name, world):
+def _launch(kind, name, world, backend='gloo'):
     outdir = tempfile.mkdtemp()
     ctx = mp.get_context('spawn')
     port = _free_port()
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, name, outdir, q))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, name, outdir, q, backend))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -197,3 +205,23 @@ def test_decomposed_lwfa_vs_reference_ranks():
         for r in range(2):
             _compare(got[r], g, 's%d' % upto, r, 1e-9, 1e-9, ptcl=(upto == steps[-1]), worst=worst)
     print('%s: worst field error %.2e, worst particle error %.2e' % (name, worst[0], worst[1]))
+
+
+@pytest.mark.parametrize('backend', ['nccl-torch', 'nccl-rccl'])
+@pytest.mark.parametrize('kind,name,world', [('periodic', 'mr_periodic_lin_2r', 2),
+                                             ('periodic', 'mr_periodic_lin_4r', 4),
+                                             ('lwfa', 'mr_lwfa_lin_2r', 2)])
+def test_decomposed_on_real_gpus(kind, name, world, backend):
+    """The same reference-pinned decomposed runs with ONE GPU PER RANK and RCCL transport:
+    torch.distributed's nccl backend (batch_isend_irecv) and the library's own fb_exchange.
+    Needs `world` GPUs in the box: skipped on the single-GPU test boxes."""
+    import torch
+    if torch.cuda.device_count() < world:
+        pytest.skip('needs %d GPUs, %d visible' % (world, torch.cuda.device_count()))
+    g = golden(name)
+    got = _launch(kind, name, world, backend)
+    steps = [int(v) for v in g['nsteps']]
+    for upto in steps:
+        tol = (5e-13 if upto == 1 else 2e-11) if kind == 'periodic' else 1e-9
+        for r in range(world):
+            _compare(got[r], g, 's%d' % upto, r, tol, tol, ptcl=(upto == steps[-1]))
