@@ -63,9 +63,15 @@ struct HankelScales {
 // launch are resident at once (768 for E + B: every SIMD holds exactly 3 waves, no second
 // round), and two chunks of global traffic are in flight per workgroup: 27.1 -> 22.6 us for
 // the 12 transforms of E + B at 1024 x 128, 1080 -> 867 us for the 24 of 2048 x 512 (Nm = 4),
-// 283 -> 224 us at 4096 x 256.  Larger tiles (32 x 128 and 64 x 128 with 8 / 16 accumulator
-// chains per wave, which re-read the matrix 2-4x less often) are no faster at any of the three
-// sizes and lose at the headline size, where they leave whole SIMDs without a wave.
+// 283 -> 224 us at 4096 x 256.  The wave tile stays 16 x 32; the workgroup is WZ x WN waves.
+// For the large grids a 64 x 128 workgroup (16 waves, 128 VGPRs each, one per CU) re-reads the
+// matrix 4x less often: 867 -> 815 us at 2048 x 512.  At the headline size no tile shape
+// (16 x 128, 32 x 128, 64 x 128; 4 / 8 / 16 waves; wave tiles of 16 x 64 and 16 x 128) beats
+// 32 x 64: with only 4 MB per transform the launch is one "generation" of workgroups whose
+// first loads (nothing to compute yet) and final stores (nothing left to compute) do not
+// overlap any MFMA work - ~8 us of its ~21 us (MFMA pipe busy 42 % over the kernel's
+// duration; rocprofv3 MfmaUtil reads 29 % because GRBM_GUI_ACTIVE also counts ~7 us around
+// the dispatch).
 //
 // DUAL (backward transform of a vector field, (p, m) -> (r, t) folded into the GEMM,
 // spectral_transformer.py:89-155): a job with in2 != 0 computes BOTH p' = in . mat and
@@ -76,24 +82,26 @@ struct HankelScales {
 // plain transforms (the z components).
 constexpr int H2_KC = 16;
 constexpr int H2_RSA = 2 * H2_KC + 2;
-// 4 waves = WZ x WN (rows x columns) of wave tiles of 16 rows x WC columns
-template <int WC, int WN> struct H2Cfg {
-    static constexpr int WZ = 4 / WN;
+// WZ x WN waves (rows x columns) of wave tiles of 16 rows x WC columns
+template <int WC, int WN, int WZ> struct H2Cfg {
+    static constexpr int NTHR = 64 * WZ * WN;
     static constexpr int TZ = 16 * WZ, TN = WC * WN;        // rows / columns per workgroup
     static constexpr int RSB = TN + 16;
     static constexpr int ABUF = TZ * H2_RSA, BBUF = H2_KC * RSB;
     static constexpr size_t LDS_BYTES = (size_t)2 * (ABUF + BBUF) * 8;
 };
 
-template <bool SCALED, bool PAIRED, bool DUAL, int WC, int WN, int WPE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 4))) void k_hankel(HankelJobs J, HankelScales Sc, HankelPairs Pr, long irs,
-                                                 long ors, double alpha, int Nz, int Nr)
+template <bool SCALED, bool PAIRED, bool DUAL, int WC, int WN, int WZ, int WPE>
+__global__ __launch_bounds__(64 * WZ * WN) __attribute__((amdgpu_waves_per_eu(WPE, 4))) void k_hankel(HankelJobs J, HankelScales Sc, HankelPairs Pr,
+                                                         long irs, long ors, double alpha, int Nz, int Nr)
 {
-    using C = H2Cfg<WC, WN>;
+    using C = H2Cfg<WC, WN, WZ>;
     constexpr int TZ = C::TZ, TN = C::TN, NT = WC / 16;     // NT: column tiles per wave
+    constexpr int NTHR = C::NTHR;
     constexpr int H2_RSB = C::RSB;
-    constexpr int NA = TZ * H2_KC / 256;                    // complex A elements per thread and chunk
-    constexpr int NB = H2_KC * TN / 2 / 256;                // matrix element pairs per thread and chunk
+    constexpr int NAE = TZ * H2_KC, NBE = H2_KC * TN / 2;   // A elements / matrix pairs per chunk
+    constexpr int NA = (NAE + NTHR - 1) / NTHR;             // ... per thread
+    constexpr int NB = (NBE + NTHR - 1) / NTHR;
     extern __shared__ double hk_lds[];
     const int job = blockIdx.z;
     const cplx *__restrict__ in = J.in[job];
@@ -135,11 +143,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 4))) v
         const double *__restrict__ mm = second ? mat2 : mat;
 #pragma unroll
         for (int j = 0; j < NA; j++) {
-            const int idx = j * 256 + tid;
+            const int idx = j * NTHR + tid;
             const int row = idx >> 4, kk = idx & 15;        // 16 lanes = 256 contiguous bytes of a row
             const int zz = zb + row, k = k0 + kk;
             double2 v = make_double2(0., 0.);
-            if (zz < Nz && k < Nr) {
+            if ((NAE % NTHR == 0 || idx < NAE) && zz < Nz && k < Nr) {
                 v = *(const double2 *)(src + (long)zz * irs + k);
                 if (PAIRED && in2) {
                     // numba_rt_to_pm: p = 0.5 (r - i t), m = 0.5 (r + i t)
@@ -153,11 +161,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 4))) v
         }
 #pragma unroll
         for (int j = 0; j < NB; j++) {
-            const int idx = j * 256 + tid;                  // pair index: TN/2 pairs per k row
+            const int idx = j * NTHR + tid;                 // pair index: TN/2 pairs per k row
             const int kr = idx / (TN / 2), nn = 2 * (idx % (TN / 2));
             const int k = k0 + kr, n = n0 + nn;
             double2 v = make_double2(0., 0.);
-            if (k < Nr) {
+            if ((NBE % NTHR == 0 || idx < NBE) && k < Nr) {
                 const double *mrow = mm + (long)k * Nr;
                 if (n + 1 < Nr && ((Nr & 1) == 0)) v = *(const double2 *)(mrow + n);
                 else { if (n < Nr) v.x = mrow[n]; if (n + 1 < Nr) v.y = mrow[n + 1]; }
@@ -170,13 +178,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 4))) v
         double *B = A + C::ABUF;
 #pragma unroll
         for (int j = 0; j < NA; j++) {
-            const int idx = j * 256 + tid;
-            *(double2 *)(A + (idx >> 4) * H2_RSA + 2 * (idx & 15)) = ra[j];
+            const int idx = j * NTHR + tid;
+            if (NAE % NTHR == 0 || idx < NAE)
+                *(double2 *)(A + (idx >> 4) * H2_RSA + 2 * (idx & 15)) = ra[j];
         }
 #pragma unroll
         for (int j = 0; j < NB; j++) {
-            const int idx = j * 256 + tid;
-            *(double2 *)(B + (idx / (TN / 2)) * H2_RSB + 2 * (idx % (TN / 2))) = rb[j];
+            const int idx = j * NTHR + tid;
+            if (NBE % NTHR == 0 || idx < NBE)
+                *(double2 *)(B + (idx / (TN / 2)) * H2_RSB + 2 * (idx % (TN / 2))) = rb[j];
         }
     };
     const int ntot = (DUAL && in2) ? 2 * nchunks : nchunks;
@@ -247,12 +257,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 4))) v
     }
 }
 
-template <bool SCALED, bool PAIRED, bool DUAL, int WC, int WN, int WPE>
+template <bool SCALED, bool PAIRED, bool DUAL, int WC, int WN, int WZ, int WPE>
 static int launch_tile(const HankelJobs &J, const HankelScales &Sc, const HankelPairs &Pr, int nj, long irs,
                    long ors, double alpha, int Nz, int Nr, hipStream_t s)
 {
-    using C = H2Cfg<WC, WN>;
-    auto kern = k_hankel<SCALED, PAIRED, DUAL, WC, WN, WPE>;
+    using C = H2Cfg<WC, WN, WZ>;
+    auto kern = k_hankel<SCALED, PAIRED, DUAL, WC, WN, WZ, WPE>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e1 = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -261,7 +271,7 @@ static int launch_tile(const HankelJobs &J, const HankelScales &Sc, const Hankel
         attr_done = true;
     }
     dim3 grid((Nz + C::TZ - 1) / C::TZ, (Nr + C::TN - 1) / C::TN, nj);
-    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, s, J, Sc, Pr, irs, ors, alpha, Nz, Nr);
+    hipLaunchKernelGGL(kern, grid, dim3(C::NTHR), C::LDS_BYTES, s, J, Sc, Pr, irs, ors, alpha, Nz, Nr);
     return check(hipGetLastError(), "fb_hankel");
 }
 
@@ -293,11 +303,19 @@ static int launch(int njobs, const void *const *in, long irs, void *const *out, 
         // wave tile: 16 x 128 columns when that still gives every CU a workgroup, else 16 x 64
         // (twice the workgroups); the dual (two accumulator sets) variant always uses 16 x 64
         int r;
-#define H2(SC, PA, DU, WP) launch_tile<SC, PA, DU, 32, 2, WP>(J, Sc, Pr, nj, irs, ors, alpha, Nz, Nr, s)
-        if (dual) r = H2(false, false, true, 2);
-        else if (paired) r = H2(true, true, false, 3);
-        else if (scaled) r = H2(true, false, false, 3);
-        else r = H2(false, false, false, 3);
+        // Tile choice (measured, see the comment on top of k_hankel): 64 x 128 with 16 waves when
+        // that still gives every CU two workgroups' worth of tiles (2048 x 512, 4096 x 256: the
+        // matrix is re-read 4x less often), else 32 x 64 with 4 waves, three workgroups
+        // co-resident per CU (the headline size)
+        const long wg_big = (long)((Nz + 63) / 64) * ((Nr + 127) / 128) * nj;
+        const bool big = wg_big >= 2 * 256;
+#define H2(SC, PA, DU, WN_, WZ_, WP) launch_tile<SC, PA, DU, 32, WN_, WZ_, WP>(J, Sc, Pr, nj, irs, ors, alpha, Nz, Nr, s)
+#define H2V(SC, PA) (big ? H2(SC, PA, false, 4, 4, 4) : H2(SC, PA, false, 2, 2, 3))
+        if (dual) r = H2(false, false, true, 2, 2, 2);
+        else if (paired) r = H2V(true, true);
+        else if (scaled) r = H2V(true, false);
+        else r = H2V(false, false);
+#undef H2V
 #undef H2
         if (r) return r;
     }
