@@ -31,6 +31,8 @@ _SIGNATURES = {
     'fb_gather': (I, [I, I, L, P, P, P, D, D, D, I, D, D, I, _PP, L, P, P, P, P, P, P, P]),
     'fb_gather_push': (I, [I, I, L, P, P, P, P, P, P, P, D, D, D, I, D, D, I, _PP, L,
                            P, P, P, P, P, P, D, D, D, D, D, D, D, P]),
+    'fb_gather_push_rank_next': (I, [I, I, L, P, P, P, P, P, P, P, D, D, D, I, D, D, I, _PP, L,
+                                     P, P, P, P, P, P, D, D, D, D, D, D, D, D, D, D, D, I, P, Z, I, P]),
     'fb_cell_index': (I, [L, P, P, P, D, D, I, D, D, I, P, P, P]),
     'fb_sort_workspace_bytes': (Z, [L, I]),
     'fb_sort_by_cell': (I, [L, I, P, P, P, P, ctypes.POINTER(I), P, P, Z, P]),
@@ -42,6 +44,8 @@ _SIGNATURES = {
                                    D, D, D, D, I, P, Z, I, P]),
     'fb_push_x_sort_deposit_rho': (I, [L, I, P, P, P, P, P, P, P, D, D, D, D, D, D, D, I, D, D, I, I, _PP,
                                        _PP, P, P, P, P, Z, I, I, I, D, _PP, L, L, P, P, P]),
+    'fb_push_x_sort_deposit_J_rho': (I, [L, I, P, P, P, P, P, P, P, D, D, D, D, D, D, D, I, D, D, I, I, _PP,
+                                         _PP, P, P, P, P, Z, I, I, I, D, D, _PP, L, L, _PP, L, L, P, P, P]),
     'fb_permute': (I, [L, P, I, _PP, _PP, P]),
     'fb_deposit_rho': (I, [I, I, L, P, P, P, P, D, D, D, I, D, D, I, _PP, L, L, P, P, P, P, P]),
     'fb_deposit_J': (I, [I, I, L, P, P, P, P, D, P, P, P, P, D, D, D, I, D, D, I, _PP, L, L,

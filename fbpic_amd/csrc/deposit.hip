@@ -150,18 +150,6 @@ __device__ __forceinline__ double row_ror(double v)
     return __hiloint2double(hi, lo);
 }
 
-// Optional by-product of the J deposition (fb_deposit_J_rank_next): Simulation.step pushes
-// the positions by another half step right after depositing J and then re-sorts them
-// (main.py:519-528).  The deposition already holds x, y, z, u, inv_gamma in registers, so it
-// also evaluates the pushed position (same expression as k_push_x), its cell and the rank of
-// the particle inside that cell (one atomic per run of equal cells, as k_bin_rank in
-// sort.hip): the counting sort then needs neither its own pass over the particles nor the
-// 56 B / particle that pass reads.
-struct RankNext {
-    double chdt, px, py, pz;
-    int *cell, *rank, *count;
-};
-
 // Optional front end of the rho deposition (fb_push_x_sort_deposit_rho): the wave walks the
 // particles in DESTINATION order of the counting sort.  Lane ip reads its 8 attributes through
 // the inverse permutation sidx (nearly sequential: a particle moves at most a cell per step),
@@ -180,95 +168,101 @@ struct PermArgs {
     int *cell_sorted;             // optional output
 };
 
-// NCOMP = 1 (rho) or 3 (Jr,Jt,Jz); this launch handles modes m0 .. m0+NM-1; Z0 <=> m0 == 0
-template <int SHAPE, int NCOMP, int NM, bool Z0, bool RANK, bool PERM = false>
-__global__ __launch_bounds__(256) void k_deposit(long n,
-        const double *__restrict__ x, const double *__restrict__ y,
-        const double *__restrict__ z, const double *__restrict__ w, double q,
-        const double *__restrict__ ux, const double *__restrict__ uy,
-        const double *__restrict__ uz, const double *__restrict__ inv_gamma, double c_light,
-        double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
-        DepGrids G, long rs, int m0,
-        const double *__restrict__ beta0, const double *__restrict__ betah,
-        int chunks_per_wave, unsigned long long *__restrict__ nflush, RankNext RK, PermArgs PM)
-{
-    static_assert(!RANK || NCOMP == 3, "ranking needs the momenta");
-    static_assert(!PERM || NCOMP == 1, "the permuting front end belongs to the rho deposition");
-    using L = DepLayout<SHAPE, NCOMP, NM, Z0>;
-    constexpr int S = L::S, H = ShapeTraits<SHAPE>::H;
-    constexpr int NPT = L::NPT, RG = L::RG, NW = L::NW, NT = L::NT, T1 = L::T1;
-    constexpr bool NEED_W0 = Z0, NEED_WH = (!Z0) || (NM > 1);
-    extern __shared__ double lds[];
-    // wave index as a scalar: every loop bound below is then wave-uniform for the compiler
-    const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double *Wl = lds + (size_t)wave * L::WAVE_DOUBLES;
-    double *Al = Wl + NW * DEP_PAD;
+struct DepGeom { double invdz, zmin; int Nz; double invdr, rmin; int Nr; };
 
-    const int jl = lane & 3, bl = (lane >> 2) & 3, kl = lane >> 4;
-    const int poff = 4 * bl + kl;          // particle (within a group of 16) fed by this lane
+// One deposition "engine": the per-wave state and the two phases of the run-based deposition
+// of NCOMP components x NM modes (modes m0 .. m0+NM-1; Z0 <=> m0 == 0).  A kernel may run
+// several engines one after the other on the same LDS panel (k_perm_deposit_J_rho: J at the
+// position before the push, rho at the position after it).
+template <int SHAPE, int NCOMP, int NM, bool Z0>
+struct DepEngine {
+    using L = DepLayout<SHAPE, NCOMP, NM, Z0>;
+    static constexpr int S = L::S, H = ShapeTraits<SHAPE>::H;
+    static constexpr int NPT = L::NPT, RG = L::RG, NW = L::NW, NT = L::NT, T1 = L::T1;
+    static constexpr bool NEED_W0 = Z0, NEED_WH = (!Z0) || (NM > 1);
     // Accumulator tile u = rg * NT + t holds, in lane l, node rg*4 + kl x amplitude row 4t + jl
     // of block bl.  At a flush the 4 blocks are added (row rotations) and the lanes of block b
     // write tile 4 q + b in round q: one atomic instruction per 4 tiles.
-    constexpr int NTILE = RG * NT, NQ = (NTILE + 3) / 4;
-    double *f_ptr[NQ];          // grid base of this lane's amplitude (re or im part)
+    static constexpr int NTILE = RG * NT, NQ = (NTILE + 3) / 4;
+
+    double *Wl, *Al;
+    int lane, jl, bl, kl, poff;    // poff: particle (within a group of 16) fed by this lane
+    double *f_ptr[NQ];             // grid base of this lane's amplitude (re or im part)
+    double *f_ptrz[NQ];            // ... advanced to the lane's node row: f_ptr + 2 * f_jz * rs
     double f_sgn[NQ];
     int f_jz[NQ], f_jr[NQ];
     bool f_ok[NQ];
-#pragma unroll
-    for (int qq = 0; qq < NQ; qq++) {
-        const int u = 4 * qq + bl;
-        const int rg = u / NT, t = u % NT;
-        int k, mm, ri;
-        bool ok = u < NTILE;
-        if (t < T1) {
-            const int idx = 4 * t + jl;
-            ok = ok && idx < L::R1;
-            mm = 0;
-            if (Z0) { k = idx; ri = 0; } else { k = idx >> 1; ri = idx & 1; }
-        } else {
-            const int idx = 4 * (t - T1) + jl;
-            ok = ok && idx < L::RH;
-            ri = idx & 1;
-            k = (idx >> 1) % NCOMP;
-            mm = 1 + (idx >> 1) / NCOMP;
-        }
-        if (!ok) { k = 0; mm = 0; ri = 0; }
-        const int m = m0 + mm;
-        f_ok[qq] = ok;
-        f_ptr[qq] = (double *)G.g[k + NCOMP * m] + ri;
-        // rho, Jz: (-1)^m ; Jr, Jt: -(-1)^m (threading_methods.py:143-146, 289-302)
-        const double flip = m1pow(m);
-        f_sgn[qq] = (NCOMP == 1 || k == 2) ? flip : -flip;
-        const int pt = (rg % RG) * 4 + kl;
-        f_jz[qq] = pt / S; f_jr[qq] = pt % S;
-    }
-
+    long rs, cs, cs2;              // row / column stride in elements, column stride in doubles
+    int Nz, Nr, m0;
     double acc[RG][NT];
-    int aoff[NT];               // LDS offset of the amplitude row this lane feeds to tile t
-#pragma unroll
-    for (int t = 0; t < NT; t++) aoff[t] = L::tile_row(t, jl) * DEP_PAD;
-#pragma unroll
-    for (int rg = 0; rg < RG; rg++)
-#pragma unroll
-        for (int t = 0; t < NT; t++) acc[rg][t] = 0.;
-    int cur_z = DEP_NOKEY, cur_r = DEP_NOKEY, cur_nb = 0;
-    unsigned int my_flushes = 0;      // wave-uniform: runs of equal cells seen by this wave
-
+    int aoff[NT];                  // LDS offset of the amplitude row this lane feeds to tile t
+    int cur_z, cur_r, cur_nb;
+    unsigned int my_flushes;       // wave-uniform: runs of equal cells seen by this wave
     // Two cells that follow each other along r share S-1 of their S node columns.  The
     // partial sums of those columns are not flushed: their accumulator lanes simply take the
     // role of the next-lower column of the new cell (`off` rotates which radial weight feeds
     // which lane), and only the lowest column of the finished cell is written out - 1/S of
     // the atomics of an r-ordered stream (1/2 for the linear shape, 1/4 for the cubic one).
     // Logical column of a lane whose physical column index is j: (j - off) mod S.
-    int off = 0;
+    int off;
+
+    __device__ __forceinline__ void init(double *panel, int lane_, const DepGrids &G, long rs_, int m0_,
+                                         int Nz_, int Nr_)
+    {
+        Wl = panel;
+        Al = panel + NW * DEP_PAD;
+        lane = lane_;
+        jl = lane & 3; bl = (lane >> 2) & 3; kl = lane >> 4;
+        poff = 4 * bl + kl;
+        rs = rs_; cs = G.cs; cs2 = 2 * G.cs; Nz = Nz_; Nr = Nr_; m0 = m0_;
+#pragma unroll
+        for (int qq = 0; qq < NQ; qq++) {
+            const int u = 4 * qq + bl;
+            const int rg = u / NT, t = u % NT;
+            int k, mm, ri;
+            bool ok = u < NTILE;
+            if (t < T1) {
+                const int idx = 4 * t + jl;
+                ok = ok && idx < L::R1;
+                mm = 0;
+                if (Z0) { k = idx; ri = 0; } else { k = idx >> 1; ri = idx & 1; }
+            } else {
+                const int idx = 4 * (t - T1) + jl;
+                ok = ok && idx < L::RH;
+                ri = idx & 1;
+                k = (idx >> 1) % NCOMP;
+                mm = 1 + (idx >> 1) / NCOMP;
+            }
+            if (!ok) { k = 0; mm = 0; ri = 0; }
+            const int m = m0 + mm;
+            f_ok[qq] = ok;
+            f_ptr[qq] = (double *)G.g[k + NCOMP * m] + ri;
+            // rho, Jz: (-1)^m ; Jr, Jt: -(-1)^m (threading_methods.py:143-146, 289-302)
+            const double flip = m1pow(m);
+            f_sgn[qq] = (NCOMP == 1 || k == 2) ? flip : -flip;
+            const int pt = (rg % RG) * 4 + kl;
+            f_jz[qq] = pt / S; f_jr[qq] = pt % S;
+            f_ptrz[qq] = f_ptr[qq] + 2 * ((long)f_jz[qq] * rs);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; t++) aoff[t] = L::tile_row(t, jl) * DEP_PAD;
+#pragma unroll
+        for (int rg = 0; rg < RG; rg++)
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[rg][t] = 0.;
+        cur_z = DEP_NOKEY; cur_r = DEP_NOKEY; cur_nb = 0;
+        my_flushes = 0;
+        off = 0;
+    }
+
     // flush the finished cell; keep_upper: only its lowest node column (the others carry on)
-    auto flush = [&](bool keep_upper) {
+    __device__ __forceinline__ void flush(bool keep_upper)
+    {
         if (cur_z == DEP_NOKEY) return;
         my_flushes++;
         const bool interior = cur_z >= 0 && cur_z + S <= Nz && cur_r >= 0 && cur_r + S <= Nr;
-        const long cs = G.cs;
-        const long cell_base = (long)cur_z * rs + (long)cur_r * cs;
+        // offset of the cell's lowest node in doubles: wave-uniform, scalar arithmetic
+        const long cell_base2 = 2 * ((long)cur_z * rs + (long)cur_r * cs);
 #pragma unroll
         for (int qq = 0; qq < NQ; qq++) {
             // add the 4 blocks of each tile, then keep the tile this lane writes in this round
@@ -287,8 +281,14 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
             if (!f_ok[qq] || v == 0. || (keep_upper && jr != 0)) continue;
             if (interior) {
                 // all S x S nodes inside the grid (wave-uniform test): no guard folding, no
-                // axis sign; the cell's base offset is scalar arithmetic
-                atomicAdd(f_ptr[qq] + 2 * (cell_base + (long)f_jz[qq] * rs + (long)jr * cs), v);
+                // axis sign
+                long joff = (jr & 1) ? cs2 : 0;
+                if constexpr (S > 2) joff += (jr & 2) ? 2 * cs2 : 0;
+#ifndef FB_DEP_NO_ATOMICS
+                atomicAdd(f_ptrz[qq] + cell_base2 + joff, v);
+#else
+                if (v == 1.2345e300) f_ptrz[qq][cell_base2 + joff] = v;
+#endif
             } else {
                 int gz = cur_z + f_jz[qq], gr = cur_r + jr;
                 fold_node(gz, gr, Nz, Nr);
@@ -296,93 +296,41 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
                 atomicAdd(f_ptr[qq] + 2 * ((long)gz * rs + (long)gr * cs), v);
             }
         }
-    };
-
-    const long chunk0 = (xcd_block_id() * nwaves + wave) * chunks_per_wave;
-    // software pipeline: particle data of chunk ch+1 is requested before chunk ch is
-    // processed, hiding the HBM latency behind the staging + accumulation work
-    constexpr int NP = (NCOMP == 1 && !PERM) ? 4 : 8;
-    double pn[NP];
-    int idx_n = 0, idx_c = 0;        // PERM: source index of the next / current chunk's particle
-    auto prefetch = [&](long ip) {
-        if (ip < n) {
-            if constexpr (PERM) {
-#pragma unroll
-                for (int k = 0; k < 8; k++) pn[k] = PM.src.p[k][idx_n];
-            } else {
-                pn[0] = x[ip]; pn[1] = y[ip]; pn[2] = z[ip]; pn[3] = w[ip];
-                if constexpr (NCOMP == 3) { pn[4] = ux[ip]; pn[5] = uy[ip]; pn[6] = uz[ip]; pn[7] = inv_gamma[ip]; }
-            }
-        }
-    };
-    // PERM: two-stage pipeline - the index of chunk ch+2 is requested while the attributes
-    // of chunk ch+1 (through the index requested one iteration earlier) are in flight
-    if constexpr (PERM) { if (chunk0 * 64 + lane < n) idx_n = PM.sidx[chunk0 * 64 + lane]; }
-    prefetch(chunk0 * 64 + lane);
-    int idx_nn = 0;
-    if constexpr (PERM) {
-        idx_c = idx_n;
-        if (chunks_per_wave > 1 && (chunk0 + 1) * 64 + lane < n) idx_nn = PM.sidx[(chunk0 + 1) * 64 + lane];
     }
-    for (int ch = 0; ch < chunks_per_wave; ch++) {
-        const long base = (chunk0 + ch) * 64;
-        if (base >= n) break;
-        const long ip = base + lane;
-        // ---- phase 1: lane = particle; stage weights / amplitudes, keep the cell key
-        int my_kz = DEP_NOKEY, my_kr = DEP_NOKEY, my_nb = 0;
-        int rk_c = -1, rk_run0 = 0, rk_base = 0;
-        double pc[NP];
-#pragma unroll
-        for (int k = 0; k < NP; k++) pc[k] = pn[k];
-        if constexpr (PERM) {
-            if (ch > 0) idx_c = idx_n;
-            idx_n = idx_nn;
-        }
-        if (ch + 1 < chunks_per_wave) prefetch(ip + 64);
-        if constexpr (PERM) {
-            if (ch + 2 < chunks_per_wave && ip + 128 < n) idx_nn = PM.sidx[ip + 128];
-        }
-        if (ip < n) {
-            double xj = pc[0], yj = pc[1], zj = pc[2];
-            if constexpr (PERM) {
-                // pending push_x (numba_methods.py:25-30, expression of k_push_x), then every
-                // attribute is written once, at its sorted slot
-                const double g = pc[7];
-                xj = pc[0] + PM.chdt * g * PM.px * pc[3];
-                yj = pc[1] + PM.chdt * g * PM.py * pc[4];
-                zj = pc[2] + PM.chdt * g * PM.pz * pc[5];
-                PM.dst.p[0][ip] = xj; PM.dst.p[1][ip] = yj; PM.dst.p[2][ip] = zj;
-                PM.dst.p[3][ip] = pc[3]; PM.dst.p[4][ip] = pc[4]; PM.dst.p[5][ip] = pc[5];
-                PM.dst.p[6][ip] = pc[6]; PM.dst.p[7][ip] = g;
-                for (int k = 8; k < PM.nattr; k++) PM.dst.p[k][ip] = PM.src.p[k][idx_c];
-                if (PM.cell_sorted) PM.cell_sorted[ip] = PM.cell[idx_c];
-            }
-            const double wj = q * pc[PERM ? 6 : 3];
+
+    // ---- phase 1: lane = particle; stage weights / amplitudes, return the cell key.
+    // u[0..2], ig, c_light are only read for NCOMP == 3.
+    __device__ __forceinline__ void stage(bool act, double xj, double yj, double zj, double wj,
+            double ux, double uy, double uz, double ig, double c_light, const DepGeom &g,
+            const double *__restrict__ beta0, const double *__restrict__ betah,
+            int &my_kz, int &my_kr, int &my_nb)
+    {
+        my_kz = DEP_NOKEY; my_kr = DEP_NOKEY; my_nb = 0;
+        if (act) {
             const double rj = sqrt(xj * xj + yj * yj);
-            double cs, sn;
+            double cs_, sn;
             if (rj != 0.) {
                 // 1/r by hardware reciprocal + two Newton steps (< 1 ulp): the deposition is
                 // compared at 1e-13, only the cell index below needs the exactly rounded r
                 double r0 = __builtin_amdgcn_rcp(rj);
                 r0 = __builtin_fma(r0, __builtin_fma(-rj, r0, 1.), r0);
                 const double invr = __builtin_fma(r0, __builtin_fma(-rj, r0, 1.), r0);
-                cs = xj * invr; sn = yj * invr;
-            } else { cs = 1.; sn = 0.; }
+                cs_ = xj * invr; sn = yj * invr;
+            } else { cs_ = 1.; sn = 0.; }
             double are[NCOMP], aim[NCOMP];
             if constexpr (NCOMP == 1) {
                 are[0] = wj; aim[0] = 0.;
             } else {
-                const double ig = pc[7];
-                are[0] = wj * c_light * ig * (cs * pc[4] + sn * pc[5]); aim[0] = 0.;
-                are[1] = wj * c_light * ig * (cs * pc[5] - sn * pc[4]); aim[1] = 0.;
-                are[2] = wj * c_light * ig * pc[6]; aim[2] = 0.;
+                are[0] = wj * c_light * ig * (cs_ * ux + sn * uy); aim[0] = 0.;
+                are[1] = wj * c_light * ig * (cs_ * uy - sn * ux); aim[1] = 0.;
+                are[2] = wj * c_light * ig * uz; aim[2] = 0.;
             }
             // mode recurrence (cos + i sin)^m, threading_methods.py:119-121, 264-267
             if constexpr (!Z0) {
                 for (int m = 0; m < m0; m++) {
 #pragma unroll
                     for (int k = 0; k < NCOMP; k++) {
-                        double re = cs * are[k] - sn * aim[k], im = cs * aim[k] + sn * are[k];
+                        double re = cs_ * are[k] - sn * aim[k], im = cs_ * aim[k] + sn * are[k];
                         are[k] = re; aim[k] = im;
                     }
                 }
@@ -393,12 +341,12 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
                 for (int k = 0; k < NCOMP; k++) {
                     Al[L::row(k, mm, 0) * DEP_PAD + lane] = are[k];
                     if (!(Z0 && mm == 0)) Al[L::row(k, mm, 1) * DEP_PAD + lane] = aim[k];
-                    double re = cs * are[k] - sn * aim[k], im = cs * aim[k] + sn * are[k];
+                    double re = cs_ * are[k] - sn * aim[k], im = cs_ * aim[k] + sn * are[k];
                     are[k] = re; aim[k] = im;
                 }
             }
-            const double r_cell = invdr * (rj - rmin) - 0.5;
-            const double z_cell = invdz * (zj - zmin) - 0.5;
+            const double r_cell = g.invdr * (rj - g.rmin) - 0.5;
+            const double z_cell = g.invdz * (zj - g.zmin) - 0.5;
             const int icr = (int)ceil(r_cell), icz = (int)ceil(z_cell);
             // lowest node of the stencil (unfolded)
             if constexpr (SHAPE == FB_SHAPE_LINEAR) { my_kr = min(icr - 1, Nr); my_kz = icz - 1; }
@@ -417,47 +365,18 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
                 }
             // number of stencil columns below the axis: index + (icr - H) < 0
             my_nb = H - icr;
-            if constexpr (RANK) {
-                // position after the coming push_x, cell as in k_cell_index / k_bin_rank
-                const double g = pc[7];
-                const double xq = xj + RK.chdt * g * RK.px * pc[4];
-                const double yq = yj + RK.chdt * g * RK.py * pc[5];
-                const double zq = zj + RK.chdt * g * RK.pz * pc[6];
-                const double rq = sqrt(xq * xq + yq * yq);
-                int ir_upper = (int)ceil(invdr * (rq - rmin) - 0.5);
-                int iz_upper = (int)ceil(invdz * (zq - zmin) - 0.5);
-                if (ir_upper > Nr) ir_upper = Nr;
-                if (iz_upper < 0) iz_upper += Nz;
-                else if (iz_upper > Nz - 1) iz_upper -= Nz;
-                rk_c = ir_upper + iz_upper * (Nr + 1);
-            }
         } else {
             // tail of the stream: finite amplitudes for the (masked) matrix operands
 #pragma unroll
             for (int a = 0; a < L::NA; a++) Al[a * DEP_PAD + lane] = 0.;
         }
-        if constexpr (RANK) {
-            // one atomic per run of equal destination cells; its result is only needed at
-            // the end of the chunk, so the round trip hides behind phase 2
-            const bool act = ip < n;
-            const int prev = __shfl_up(rk_c, 1);
-            const bool rk_start = act && (lane == 0 || rk_c != prev);
-            const unsigned long long rstarts = __ballot(rk_start);
-            const int nact = __popcll(__ballot(act));
-            const unsigned long long below = rstarts & ((2ull << lane) - 1ull);
-            rk_run0 = 63 - __builtin_clzll(below | 1ull);
-            if (rk_start) {
-                const unsigned long long rest = (lane + 1 < 64) ? (rstarts >> (lane + 1)) : 0ull;
-                const int len = rest ? (__builtin_ctzll(rest) + 1) : (nact - lane);
-                rk_base = atomicAdd(RK.count + rk_c, len);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // ---- phase 2: runs of equal cells (boundaries found with one ballot) are reduced on
-        // the matrix cores, 16 staged particles per instruction; particles of a group that
-        // belong to another run are masked out of the weight operand.
-        const int cnt = (int)min((long)64, n - base);
+    }
+
+    // ---- phase 2: runs of equal cells (boundaries found with one ballot) are reduced on the
+    // matrix cores, 16 staged particles per instruction; particles of a group that belong to
+    // another run are masked out of the weight operand.
+    __device__ __forceinline__ void reduce(int cnt, int my_kz, int my_kr, int my_nb)
+    {
         const int prev_kz = __shfl_up(my_kz, 1), prev_kr = __shfl_up(my_kr, 1);
         bool is_start = (lane == 0) ? (my_kz != cur_z || my_kr != cur_r)
                                     : (my_kz != prev_kz || my_kr != prev_kr);
@@ -519,21 +438,237 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
             }
             p = e;
         }
+    }
+};
+
+__device__ __forceinline__ void wave_lds_release()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void wave_lds_acquire()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// NCOMP = 1 (rho) or 3 (Jr,Jt,Jz); this launch handles modes m0 .. m0+NM-1; Z0 <=> m0 == 0
+template <int SHAPE, int NCOMP, int NM, bool Z0, bool RANK, bool PERM = false>
+__global__ __launch_bounds__(256) void k_deposit(long n,
+        const double *__restrict__ x, const double *__restrict__ y,
+        const double *__restrict__ z, const double *__restrict__ w, double q,
+        const double *__restrict__ ux, const double *__restrict__ uy,
+        const double *__restrict__ uz, const double *__restrict__ inv_gamma, double c_light,
+        double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
+        DepGrids G, long rs, int m0,
+        const double *__restrict__ beta0, const double *__restrict__ betah,
+        int chunks_per_wave, unsigned long long *__restrict__ nflush, RankNext RK, PermArgs PM)
+{
+    static_assert(!RANK || NCOMP == 3, "ranking needs the momenta");
+    static_assert(!PERM || NCOMP == 1, "the permuting front end belongs to the rho deposition");
+    using E = DepEngine<SHAPE, NCOMP, NM, Z0>;
+    using L = typename E::L;
+    extern __shared__ double lds[];
+    // wave index as a scalar: every loop bound below is then wave-uniform for the compiler
+    const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    E eng;
+    eng.init(lds + (size_t)wave * L::WAVE_DOUBLES, lane, G, rs, m0, Nz, Nr);
+    const DepGeom geom = {invdz, zmin, Nz, invdr, rmin, Nr};
+
+    const long chunk0 = (xcd_block_id() * nwaves + wave) * chunks_per_wave;
+    // software pipeline: particle data of chunk ch+1 is requested before chunk ch is
+    // processed, hiding the HBM latency behind the staging + accumulation work
+    constexpr int NP = (NCOMP == 1 && !PERM) ? 4 : 8;
+    double pn[NP];
+    int idx_n = 0, idx_c = 0;        // PERM: source index of the next / current chunk's particle
+    auto prefetch = [&](long ip) {
+        if (ip < n) {
+            if constexpr (PERM) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) pn[k] = PM.src.p[k][idx_n];
+            } else {
+                pn[0] = x[ip]; pn[1] = y[ip]; pn[2] = z[ip]; pn[3] = w[ip];
+                if constexpr (NCOMP == 3) { pn[4] = ux[ip]; pn[5] = uy[ip]; pn[6] = uz[ip]; pn[7] = inv_gamma[ip]; }
+            }
+        }
+    };
+    // PERM: two-stage pipeline - the index of chunk ch+2 is requested while the attributes
+    // of chunk ch+1 (through the index requested one iteration earlier) are in flight
+    if constexpr (PERM) { if (chunk0 * 64 + lane < n) idx_n = PM.sidx[chunk0 * 64 + lane]; }
+    prefetch(chunk0 * 64 + lane);
+    int idx_nn = 0;
+    if constexpr (PERM) {
+        idx_c = idx_n;
+        if (chunks_per_wave > 1 && (chunk0 + 1) * 64 + lane < n) idx_nn = PM.sidx[(chunk0 + 1) * 64 + lane];
+    }
+    for (int ch = 0; ch < chunks_per_wave; ch++) {
+        const long base = (chunk0 + ch) * 64;
+        if (base >= n) break;
+        const long ip = base + lane;
+        const bool act = ip < n;
+        int my_kz, my_kr, my_nb;
+        int rk_c = -1, rk_run0 = 0, rk_base = 0;
+        double pc[NP];
+#pragma unroll
+        for (int k = 0; k < NP; k++) pc[k] = pn[k];
+        if constexpr (PERM) {
+            if (ch > 0) idx_c = idx_n;
+            idx_n = idx_nn;
+        }
+        if (ch + 1 < chunks_per_wave) prefetch(ip + 64);
+        if constexpr (PERM) {
+            if (ch + 2 < chunks_per_wave && ip + 128 < n) idx_nn = PM.sidx[ip + 128];
+        }
+        double xj = pc[0], yj = pc[1], zj = pc[2];
+        if constexpr (PERM) {
+            if (act) {
+                // pending push_x (numba_methods.py:25-30, expression of k_push_x), then every
+                // attribute is written once, at its sorted slot
+                const double g = pc[7];
+                xj = pc[0] + PM.chdt * g * PM.px * pc[3];
+                yj = pc[1] + PM.chdt * g * PM.py * pc[4];
+                zj = pc[2] + PM.chdt * g * PM.pz * pc[5];
+                PM.dst.p[0][ip] = xj; PM.dst.p[1][ip] = yj; PM.dst.p[2][ip] = zj;
+                PM.dst.p[3][ip] = pc[3]; PM.dst.p[4][ip] = pc[4]; PM.dst.p[5][ip] = pc[5];
+                PM.dst.p[6][ip] = pc[6]; PM.dst.p[7][ip] = g;
+                for (int k = 8; k < PM.nattr; k++) PM.dst.p[k][ip] = PM.src.p[k][idx_c];
+                if (PM.cell_sorted) PM.cell_sorted[ip] = PM.cell[idx_c];
+            }
+        }
+        const double wj = q * pc[PERM ? 6 : 3];
+        if constexpr (NCOMP == 3)
+            eng.stage(act, xj, yj, zj, wj, pc[4], pc[5], pc[6], pc[7], c_light, geom, beta0, betah,
+                      my_kz, my_kr, my_nb);
+        else
+            eng.stage(act, xj, yj, zj, wj, 0., 0., 0., 0., 0., geom, beta0, betah, my_kz, my_kr, my_nb);
+        if constexpr (RANK) {
+            if (act) {
+                // position after the coming push_x, cell as in k_cell_index / k_bin_rank
+                const double g = pc[7];
+                const double xq = xj + RK.chdt * g * RK.px * pc[4];
+                const double yq = yj + RK.chdt * g * RK.py * pc[5];
+                const double zq = zj + RK.chdt * g * RK.pz * pc[6];
+                const double rq = sqrt(xq * xq + yq * yq);
+                int ir_upper = (int)ceil(invdr * (rq - rmin) - 0.5);
+                int iz_upper = (int)ceil(invdz * (zq - zmin) - 0.5);
+                if (ir_upper > Nr) ir_upper = Nr;
+                if (iz_upper < 0) iz_upper += Nz;
+                else if (iz_upper > Nz - 1) iz_upper -= Nz;
+                rk_c = ir_upper + iz_upper * (Nr + 1);
+            }
+            // one atomic per run of equal destination cells; its result is only needed at
+            // the end of the chunk, so the round trip hides behind phase 2
+            const int prev = __shfl_up(rk_c, 1);
+            const bool rk_start = act && (lane == 0 || rk_c != prev);
+            const unsigned long long rstarts = __ballot(rk_start);
+            const int nact = __popcll(__ballot(act));
+            const unsigned long long below = rstarts & ((2ull << lane) - 1ull);
+            rk_run0 = 63 - __builtin_clzll(below | 1ull);
+            if (rk_start) {
+                const unsigned long long rest = (lane + 1 < 64) ? (rstarts >> (lane + 1)) : 0ull;
+                const int len = rest ? (__builtin_ctzll(rest) + 1) : (nact - lane);
+                rk_base = atomicAdd(RK.count + rk_c, len);
+            }
+        }
+        wave_lds_release();
+        eng.reduce((int)min((long)64, n - base), my_kz, my_kr, my_nb);
         if constexpr (RANK) {
             const int base_r = __shfl(rk_base, rk_run0);
-            if (ip < n) {
+            if (act) {
                 RK.cell[ip] = rk_c;
                 RK.rank[ip] = base_r + (lane - rk_run0);
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_acquire();
     }
-    flush(false);
+    eng.flush(false);
     // fragmentation statistic for the host's sort policy: 1024 counters (same-address
     // device atomics serialise at ~10 ns each; one shared counter would cost > 100 us)
     if (nflush && lane == 0)
-        atomicAdd(nflush + ((blockIdx.x * nwaves + wave) & 1023), (unsigned long long)my_flushes);
+        atomicAdd(nflush + ((blockIdx.x * nwaves + wave) & 1023), (unsigned long long)eng.my_flushes);
+}
+
+// push_x + counting sort + J AND rho deposition in one destination-ordered pass
+// (fb_push_x_sort_deposit_J_rho): the particles are read through the inverse permutation as in
+// k_deposit<.., PERM>; the current is deposited from the position BEFORE the pending push (where
+// Simulation.step deposits J, main.py:515-517), the charge from the position after it
+// (deposit('rho_next'), :528).  The two depositions run one after the other on the same LDS
+// panel; the arithmetic of both overlaps the memory stalls of the permutation, and the
+// stand-alone J pass (64 B per particle read again) disappears.  Modes 0 .. NM-1 (NM <= 4).
+template <int SHAPE, int NM>
+__global__ __launch_bounds__(256) void k_perm_deposit_J_rho(long n, double q, double c_light,
+        DepGeom gJ, DepGeom gR, DepGrids GJ, long rsJ, DepGrids GR, long rsR,
+        const double *__restrict__ beta0, const double *__restrict__ betah,
+        int chunks_per_wave, PermArgs PM)
+{
+    using EJ = DepEngine<SHAPE, 3, NM, true>;
+    using ER = DepEngine<SHAPE, 1, NM, true>;
+    constexpr int WAVE_DOUBLES = EJ::L::WAVE_DOUBLES > ER::L::WAVE_DOUBLES ? EJ::L::WAVE_DOUBLES
+                                                                           : ER::L::WAVE_DOUBLES;
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    EJ ej;
+    ER er;
+    ej.init(lds + (size_t)wave * WAVE_DOUBLES, lane, GJ, rsJ, 0, gJ.Nz, gJ.Nr);
+    er.init(lds + (size_t)wave * WAVE_DOUBLES, lane, GR, rsR, 0, gR.Nz, gR.Nr);
+
+    const long chunk0 = (xcd_block_id() * nwaves + wave) * chunks_per_wave;
+    double pn[8];
+    int idx_n = 0, idx_c = 0, idx_nn = 0;
+    auto prefetch = [&](long ip) {
+        if (ip < n) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) pn[k] = PM.src.p[k][idx_n];
+        }
+    };
+    if (chunk0 * 64 + lane < n) idx_n = PM.sidx[chunk0 * 64 + lane];
+    prefetch(chunk0 * 64 + lane);
+    idx_c = idx_n;
+    if (chunks_per_wave > 1 && (chunk0 + 1) * 64 + lane < n) idx_nn = PM.sidx[(chunk0 + 1) * 64 + lane];
+    for (int ch = 0; ch < chunks_per_wave; ch++) {
+        const long base = (chunk0 + ch) * 64;
+        if (base >= n) break;
+        const long ip = base + lane;
+        const bool act = ip < n;
+        const int cnt = (int)min((long)64, n - base);
+        double pc[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) pc[k] = pn[k];
+        if (ch > 0) idx_c = idx_n;
+        idx_n = idx_nn;
+        if (ch + 1 < chunks_per_wave) prefetch(ip + 64);
+        if (ch + 2 < chunks_per_wave && ip + 128 < n) idx_nn = PM.sidx[ip + 128];
+        const double wj = q * pc[6];
+        int kz, kr, nb;
+        // ---- J from the position before the push
+        ej.stage(act, pc[0], pc[1], pc[2], wj, pc[3], pc[4], pc[5], pc[7], c_light, gJ, beta0, betah,
+                 kz, kr, nb);
+        wave_lds_release();
+        ej.reduce(cnt, kz, kr, nb);
+        wave_lds_acquire();
+        // ---- pending push_x (expression of k_push_x), attributes written at the sorted slot
+        double xj = pc[0], yj = pc[1], zj = pc[2];
+        if (act) {
+            const double g = pc[7];
+            xj = pc[0] + PM.chdt * g * PM.px * pc[3];
+            yj = pc[1] + PM.chdt * g * PM.py * pc[4];
+            zj = pc[2] + PM.chdt * g * PM.pz * pc[5];
+            PM.dst.p[0][ip] = xj; PM.dst.p[1][ip] = yj; PM.dst.p[2][ip] = zj;
+            PM.dst.p[3][ip] = pc[3]; PM.dst.p[4][ip] = pc[4]; PM.dst.p[5][ip] = pc[5];
+            PM.dst.p[6][ip] = pc[6]; PM.dst.p[7][ip] = g;
+            for (int k = 8; k < PM.nattr; k++) PM.dst.p[k][ip] = PM.src.p[k][idx_c];
+            if (PM.cell_sorted) PM.cell_sorted[ip] = PM.cell[idx_c];
+        }
+        // ---- rho from the pushed position
+        er.stage(act, xj, yj, zj, wj, 0., 0., 0., 0., 0., gR, beta0, betah, kz, kr, nb);
+        wave_lds_release();
+        er.reduce(cnt, kz, kr, nb);
+        wave_lds_acquire();
+    }
+    ej.flush(false);
+    er.flush(false);
 }
 
 template <int SHAPE, int NCOMP, int NM, bool Z0, bool RANK, bool PERM = false>
@@ -748,4 +883,76 @@ extern "C" int fb_push_x_sort_deposit_rho(long n, int ncell, const double *x, co
     return launch_modes<FB_SHAPE_CUBIC, 1>(Nm, n, x, y, z, src[6], q, nullptr, nullptr, nullptr,
             nullptr, 0., invdz, zmin, Nz, invdr, rmin, Nr, G, row_stride, ruyten_m0,
             ruyten_mh, nullptr, nullptr, s, &PM);
+}
+
+template <int SHAPE, int NM>
+static int launch_perm_J_rho(long n, double q, double c, const DepGeom &gJ, const DepGeom &gR,
+                             const DepGrids &GJ, long rsJ, const DepGrids &GR, long rsR,
+                             const double *b0, const double *bh, const PermArgs &PM, hipStream_t s)
+{
+    using EJ = DepEngine<SHAPE, 3, NM, true>;
+    using ER = DepEngine<SHAPE, 1, NM, true>;
+    const size_t wave_bytes = 8 * (size_t)(EJ::L::WAVE_DOUBLES > ER::L::WAVE_DOUBLES ? EJ::L::WAVE_DOUBLES
+                                                                                      : ER::L::WAVE_DOUBLES);
+    int nwaves = 4;
+    while (nwaves > 1 && wave_bytes * nwaves > 64 * 1024) nwaves >>= 1;
+    const long nchunks = (n + 63) / 64;
+    const long target_waves = 256L * 64;
+    int cpw = (int)((nchunks + target_waves - 1) / target_waves);
+    if (cpw < 1) cpw = 1;
+    if (cpw > 64) cpw = 64;
+    const long total_waves = (nchunks + cpw - 1) / cpw;
+    const long nblocks = xcd_grid((total_waves + nwaves - 1) / nwaves);
+    hipLaunchKernelGGL((k_perm_deposit_J_rho<SHAPE, NM>), dim3((unsigned)nblocks), dim3(64 * nwaves),
+                       wave_bytes * nwaves, s, n, q, c, gJ, gR, GJ, rsJ, GR, rsR, b0, bh, cpw, PM);
+    return check(hipGetLastError(), "fb_push_x_sort_deposit_J_rho");
+}
+
+extern "C" int fb_push_x_sort_deposit_J_rho(long n, int ncell, const double *x, const double *y,
+        const double *z, const double *ux, const double *uy, const double *uz,
+        const double *inv_gamma, double c, double dt, double x_push, double y_push, double z_push,
+        double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
+        int nattr, const double *const *src, double *const *dst,
+        int *cell_idx_sorted, int *sorted_idx, int *prefix_sum,
+        void *workspace, size_t workspace_bytes, int preranked,
+        int shape, int Nm, double q, double zmin_J, void *const *J, long J_row_stride,
+        long J_col_stride, void *const *rho, long row_stride, long col_stride,
+        const double *ruyten_m0, const double *ruyten_mh, void *stream)
+{
+    const char *who = "fb_push_x_sort_deposit_J_rho";
+    hipStream_t s = (hipStream_t)stream;
+    if (Nm < 1 || Nm > 4) { set_error(who, "Nm must be 1..4 (use the separate entry points beyond)"); return -1; }
+    if (shape != FB_SHAPE_LINEAR && shape != FB_SHAPE_CUBIC) { set_error(who, "unknown shape"); return -1; }
+    if (!sorted_idx) { set_error(who, "sorted_idx (n ints) is required: it holds the permutation"); return -1; }
+    if (nattr < 8) { set_error(who, "src / dst must hold x, y, z, ux, uy, uz, w, inv_gamma"); return -1; }
+    const PushX P = {ux, uy, uz, inv_gamma, c * dt, x_push, y_push, z_push};
+    BinSortWs W;
+    int r = bin_sort_prepare(who, true, preranked != 0, P, n, ncell, x, y, z, invdz, zmin, Nz, invdr,
+                             rmin, Nr, nattr, src, prefix_sum, workspace, workspace_bytes, &W, s);
+    if (r) return r;
+    r = bin_sort_build_sidx(who, n, ncell, W, prefix_sum, sorted_idx, s);
+    if (r || n <= 0) return r;
+    PermArgs PM;
+    PM.sidx = sorted_idx;
+    for (int k = 0; k < 16; k++) { PM.src.p[k] = k < nattr ? src[k] : nullptr; PM.dst.p[k] = k < nattr ? dst[k] : nullptr; }
+    PM.nattr = nattr;
+    PM.chdt = P.chdt; PM.px = x_push; PM.py = y_push; PM.pz = z_push;
+    PM.cell = W.cell;
+    PM.cell_sorted = cell_idx_sorted;
+    DepGrids GJ, GR;
+    GJ.cs = J_col_stride > 0 ? J_col_stride : 1;
+    GR.cs = col_stride > 0 ? col_stride : 1;
+    for (int i = 0; i < 3 * FB_MAX_MODES; i++) {
+        GJ.g[i] = i < 3 * Nm ? (cplx *)J[i] : nullptr;
+        GR.g[i] = i < Nm ? (cplx *)rho[i] : nullptr;
+    }
+    const DepGeom gJ = {invdz, zmin_J, Nz, invdr, rmin, Nr}, gR = {invdz, zmin, Nz, invdr, rmin, Nr};
+#define LPJR(SH, NM_) launch_perm_J_rho<SH, NM_>(n, q, c, gJ, gR, GJ, J_row_stride, GR, row_stride, \
+                                                 ruyten_m0, ruyten_mh, PM, s)
+    if (shape == FB_SHAPE_LINEAR)
+        return Nm == 1 ? LPJR(FB_SHAPE_LINEAR, 1) : Nm == 2 ? LPJR(FB_SHAPE_LINEAR, 2)
+             : Nm == 3 ? LPJR(FB_SHAPE_LINEAR, 3) : LPJR(FB_SHAPE_LINEAR, 4);
+    return Nm == 1 ? LPJR(FB_SHAPE_CUBIC, 1) : Nm == 2 ? LPJR(FB_SHAPE_CUBIC, 2)
+         : Nm == 3 ? LPJR(FB_SHAPE_CUBIC, 3) : LPJR(FB_SHAPE_CUBIC, 4);
+#undef LPJR
 }

@@ -78,6 +78,18 @@ struct PushX {
     double chdt, px, py, pz;
 };
 
+// Optional by-product of a kernel that holds x, y, z, u, inv_gamma of every particle in
+// registers (fb_deposit_J_rank_next, fb_gather_push_rank_next): Simulation.step pushes the
+// positions by another half step and then re-sorts them (main.py:519-528).  The kernel also
+// evaluates that pushed position (same expression as k_push_x), its cell and the rank of the
+// particle inside that cell (one atomic per run of equal cells, as k_bin_rank in sort.hip): the
+// counting sort then needs neither its own pass over the particles nor the 56 B / particle
+// that pass reads.
+struct RankNext {
+    double chdt, px, py, pz;
+    int *cell, *rank, *count;
+};
+
 // sort.hip: rank pass (unless preranked) + scan of the counting sort, and the inverse
 // permutation sidx[destination] = source; used by the fused sort + push_x + rho deposition
 int bin_sort_prepare(const char *who, bool push, bool preranked, const PushX &P, long n, int ncell,

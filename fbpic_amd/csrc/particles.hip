@@ -135,6 +135,9 @@ struct PushArgs {
     // periodic wrap of z into [wzmin, wzmax) before the gather (k_shift_periodic folded in;
     // only with the position push, which rewrites z anyway); wzmax <= wzmin -> off
     double wzmin, wzmax;
+    // cell + rank of the position after the NEXT push_x, for the counting sort that follows it
+    // (fb_gather_push_rank_next); RK.count == null -> off
+    RankNext RK;
 };
 
 __device__ __forceinline__ double2 ldc(const cplx *p) { return *(const double2 *)p; }
@@ -403,6 +406,7 @@ __global__ __launch_bounds__(256) void k_gather(int Nm_arg, long n,
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
+        int rk_c = -1;
         if (act) {
             const double ex = cs * F[0] - sn * F[1], ey = sn * F[0] + cs * F[1], ez = F[2];
             const double bx = cs * F[3] - sn * F[4], by = sn * F[3] + cs * F[4], bz = F[5];
@@ -415,10 +419,44 @@ __global__ __launch_bounds__(256) void k_gather(int Nm_arg, long n,
                 PA.ux[i] = pux; PA.uy[i] = puy; PA.uz[i] = puz; PA.ig[i] = pig;
                 if (PA.chdt != 0.) {
                     // numba_methods.py:28-30 with push_x = push_y = push_z = 1
-                    PA.x[i] = xj + PA.chdt * pig * 1. * pux;
-                    PA.y[i] = yj + PA.chdt * pig * 1. * puy;
-                    PA.z[i] = zj + PA.chdt * pig * 1. * puz;
+                    const double xp = xj + PA.chdt * pig * 1. * pux;
+                    const double yp = yj + PA.chdt * pig * 1. * puy;
+                    const double zp = zj + PA.chdt * pig * 1. * puz;
+                    PA.x[i] = xp; PA.y[i] = yp; PA.z[i] = zp;
+                    if (PA.RK.count) {
+                        // position after the coming push_x, cell as in k_cell_index / k_bin_rank
+                        const double xq = xp + PA.RK.chdt * pig * PA.RK.px * pux;
+                        const double yq = yp + PA.RK.chdt * pig * PA.RK.py * puy;
+                        const double zq = zp + PA.RK.chdt * pig * PA.RK.pz * puz;
+                        const double rq = sqrt(xq * xq + yq * yq);
+                        int ir_upper = (int)ceil(invdr * (rq - rmin) - 0.5);
+                        int iz_upper = (int)ceil(invdz * (zq - zmin) - 0.5);
+                        if (ir_upper > Nr) ir_upper = Nr;
+                        if (iz_upper < 0) iz_upper += Nz;
+                        else if (iz_upper > Nz - 1) iz_upper -= Nz;
+                        rk_c = ir_upper + iz_upper * (Nr + 1);
+                    }
                 }
+            }
+        }
+        if (PA.RK.count) {
+            // one atomic per run of equal destination cells (wave-uniform branch)
+            const int prev = __shfl_up(rk_c, 1);
+            const bool rk_start = act && (lane == 0 || rk_c != prev);
+            const unsigned long long rstarts = __ballot(rk_start);
+            const int nact = __popcll(__ballot(act));
+            const unsigned long long below = rstarts & ((2ull << lane) - 1ull);
+            const int rk_run0 = 63 - __builtin_clzll(below | 1ull);
+            int rk_base = 0;
+            if (rk_start) {
+                const unsigned long long rest = (lane + 1 < 64) ? (rstarts >> (lane + 1)) : 0ull;
+                const int len = rest ? (__builtin_ctzll(rest) + 1) : (nact - lane);
+                rk_base = atomicAdd(PA.RK.count + rk_c, len);
+            }
+            rk_base = __shfl(rk_base, rk_run0);
+            if (act) {
+                PA.RK.cell[i] = rk_c;
+                PA.RK.rank[i] = rk_base + (lane - rk_run0);
             }
         }
     }
@@ -545,6 +583,31 @@ extern "C" int fb_gather(int shape, int Nm, long n, const double *x, const doubl
                          "fb_gather");
 }
 
+static int gather_push_impl(const char *who, int shape, int Nm, long n, double *x, double *y, double *z,
+        double *ux, double *uy, double *uz, double *inv_gamma,
+        double rmax_gather, double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
+        const void *const *grids, long row_stride,
+        double *Ex, double *Ey, double *Ez, double *Bx, double *By, double *Bz,
+        double q, double m, double c, double dt, double dt_x, double wrap_zmin, double wrap_zmax,
+        const RankNext &RK, void *stream)
+{
+    PushArgs PA;
+    PA.RK = RK;
+    PA.x = x; PA.y = y; PA.z = z;
+    PA.ux = ux; PA.uy = uy; PA.uz = uz; PA.ig = inv_gamma;
+    PA.econst = q * dt / (m * c);
+    PA.bconst = 0.5 * q * dt / m;
+    PA.chdt = c * dt_x;
+    PA.wzmin = wrap_zmin; PA.wzmax = wrap_zmax;
+    if (wrap_zmax > wrap_zmin && dt_x == 0.) {
+        set_error(who, "the periodic wrap needs the position push (dt_x != 0)");
+        return -1;
+    }
+    if (RK.count && dt_x == 0.) { set_error(who, "ranking needs the position push (dt_x != 0)"); return -1; }
+    return launch_gather(shape, Nm, n, x, y, z, rmax_gather, invdz, zmin, Nz, invdr, rmin, Nr,
+                         grids, row_stride, Ex, Ey, Ez, Bx, By, Bz, PA, (hipStream_t)stream, who);
+}
+
 extern "C" int fb_gather_push(int shape, int Nm, long n, double *x, double *y, double *z,
         double *ux, double *uy, double *uz, double *inv_gamma,
         double rmax_gather, double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
@@ -553,18 +616,34 @@ extern "C" int fb_gather_push(int shape, int Nm, long n, double *x, double *y, d
         double q, double m, double c, double dt, double dt_x, double wrap_zmin, double wrap_zmax,
         void *stream)
 {
-    PushArgs PA;
-    PA.x = x; PA.y = y; PA.z = z;
-    PA.ux = ux; PA.uy = uy; PA.uz = uz; PA.ig = inv_gamma;
-    PA.econst = q * dt / (m * c);
-    PA.bconst = 0.5 * q * dt / m;
-    PA.chdt = c * dt_x;
-    PA.wzmin = wrap_zmin; PA.wzmax = wrap_zmax;
-    if (wrap_zmax > wrap_zmin && dt_x == 0.) {
-        set_error("fb_gather_push", "the periodic wrap needs the position push (dt_x != 0)");
-        return -1;
+    const RankNext none = {0., 0., 0., 0., nullptr, nullptr, nullptr};
+    return gather_push_impl("fb_gather_push", shape, Nm, n, x, y, z, ux, uy, uz, inv_gamma, rmax_gather,
+                            invdz, zmin, Nz, invdr, rmin, Nr, grids, row_stride, Ex, Ey, Ez, Bx, By, Bz,
+                            q, m, c, dt, dt_x, wrap_zmin, wrap_zmax, none, stream);
+}
+
+extern "C" int fb_gather_push_rank_next(int shape, int Nm, long n, double *x, double *y, double *z,
+        double *ux, double *uy, double *uz, double *inv_gamma,
+        double rmax_gather, double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
+        const void *const *grids, long row_stride,
+        double *Ex, double *Ey, double *Ez, double *Bx, double *By, double *Bz,
+        double q, double m, double c, double dt, double dt_x, double wrap_zmin, double wrap_zmax,
+        double dt_push, double x_push, double y_push, double z_push, int ncell,
+        void *sort_workspace, size_t workspace_bytes, int counts_are_zero, void *stream)
+{
+    const char *who = "fb_gather_push_rank_next";
+    hipStream_t s = (hipStream_t)stream;
+    if (ncell != Nz * (Nr + 1)) { set_error(who, "ncell != Nz*(Nr+1)"); return -1; }
+    if (workspace_bytes < fb_bin_sort_workspace_bytes(n, ncell)) { set_error(who, "workspace too small"); return -1; }
+    const BinSortWs W = carve_bin_sort_ws(sort_workspace, workspace_bytes, n, ncell);
+    if (!counts_are_zero) {
+        hipError_t e = hipMemsetAsync(W.count, 0, (size_t)ncell * sizeof(int), s);
+        if (e != hipSuccess) return check(e, who);
     }
-    return launch_gather(shape, Nm, n, x, y, z, rmax_gather, invdz, zmin, Nz, invdr, rmin, Nr,
-                         grids, row_stride, Ex, Ey, Ez, Bx, By, Bz, PA, (hipStream_t)stream,
-                         "fb_gather_push");
+    if (n <= 0) return 0;
+    // fbpic/particles/push/numba_methods.py:24-30: chdt = c * dt
+    const RankNext RK = {c * dt_push, x_push, y_push, z_push, W.cell, W.rank, W.count};
+    return gather_push_impl(who, shape, Nm, n, x, y, z, ux, uy, uz, inv_gamma, rmax_gather,
+                            invdz, zmin, Nz, invdr, rmin, Nr, grids, row_stride, Ex, Ey, Ez, Bx, By, Bz,
+                            q, m, c, dt, dt_x, wrap_zmin, wrap_zmax, RK, stream);
 }

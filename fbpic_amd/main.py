@@ -129,6 +129,10 @@ class Simulation(object):
         # of E, B kept): the baseline the fused sequence is measured against (bench.py
         # --reference-sequence); results identical within the test tolerances
         self.reference_sequence = False
+        # deposit('J') + push_x(dt/2) + re-sort + deposit('rho_next') as ONE pass over the
+        # particles (fb_push_x_sort_deposit_J_rho) when nothing sits between them in step()
+        self.fuse_J_into_rho = os.environ.get('FBPIC_AMD_FUSE_J', '1') != '0'
+        self._defer_J_ok = False
 
     # -------------------------------------------------------------------- PIC cycle
     def step(self, N=1, correct_currents=True, correct_divE=False, use_true_rho=False,
@@ -189,9 +193,15 @@ class Simulation(object):
                 # are only materialised where something can observe them: on the last
                 # iteration of this call (they then hold the fields of that gather, as after
                 # the reference's step) - diagnostics take the unfused branch below
+                # ... and ranks the particles for the sort after the second half push (not with a
+                # Galilean grid: zmin moves in between; not with cross-deposition: other pushes)
+                cross_ = bool(correct_currents) and fld.current_correction == 'cross-deposition'
+                hint = (0.5 * dt, 1., 1., 1.) if (self.prerank_in_deposit and not self.use_galilean
+                                                  and not cross_) else None
                 for species in ptcl:
                     species.gather_push(fld.interp, self.comm, 0.5 * dt,
-                                        store_fields=(i_step == N - 1), wrap_z=wrap_z)
+                                        store_fields=(i_step == N - 1), wrap_z=wrap_z,
+                                        rank_next=hint)
             else:
                 for species in ptcl:
                     species.gather(fld.interp, self.comm)
@@ -217,8 +227,11 @@ class Simulation(object):
                 # (not with a Galilean grid: zmin moves between this deposit and that sort)
                 for species in ptcl:
                     species.push_after_deposit_J = (0.5 * dt, 1., 1., 1.)
+            self._defer_J_ok = (move_positions and not self.use_galilean and not cross
+                                and self.fuse_J_into_rho)
             self.deposit('J', exchange=(correct_currents is False),
                          defer_transform=(not cross) and not self.reference_sequence)
+            self._defer_J_ok = False
             for species in ptcl:
                 species.push_after_deposit_J = None
             if cross:
@@ -359,6 +372,10 @@ class Simulation(object):
                 records = True
             else:
                 fld.erase('J+rho')
+            # the deposition itself may ride along in the pass that pushes, sorts and deposits
+            # rho_next (Particles.deposit decides; anything in between launches it first)
+            for species in species_list:
+                species.defer_J_deposit = self._defer_J_ok
         elif fused and kind == 'rho' and self._rho_already_erased and fieldtype == 'rho_next':
             self._rho_already_erased = False
             records = use_records

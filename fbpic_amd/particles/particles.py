@@ -89,6 +89,13 @@ class Particles(object):
         # push_x + counting sort + deposit('rho') as one destination-ordered pass
         # (fb_push_x_sort_deposit_rho) when a deferred push and a re-sort precede a rho deposit
         self.fuse_sort_deposit_rho = os.environ.get('FBPIC_AMD_FUSE_RHO', '1') != '0'
+        # Set by Simulation.step before deposit('J') when push_x + deposit('rho_next') follow
+        # with nothing in between: the J deposition is then not launched on its own but rides
+        # along in that pass (fb_push_x_sort_deposit_J_rho).  `_pending_J` remembers the target;
+        # anything that needs J on the grid or touches the particles first launches it
+        # (flush_pending_J).
+        self.defer_J_deposit = False
+        self._pending_J = None
         # the counting sort only materialises `cell_idx` / `sorted_idx` (sorted cell of every
         # particle, permutation) when asked: nothing on the hot path reads them
         self.keep_sort_outputs = False
@@ -224,7 +231,8 @@ class Particles(object):
         whichever comes first.  Simulation.step uses it for the half push that precedes
         deposit('rho_next'), main.py:519-528."""
         self._need_gpu()
-        self.flush_pending_push()
+        if not (defer and self.use_bin_sort and self._pending_push is None):
+            self.flush_pending_push()
         if defer and self.use_bin_sort:
             self._pending_push = (dt, x_push, y_push, z_push)
             if self._prerank != self._pending_push:
@@ -234,8 +242,23 @@ class Particles(object):
         self._launch_push_x(dt, x_push, y_push, z_push)
         self._note_push(dt, max(abs(x_push), abs(y_push), abs(z_push)))
 
+    def flush_pending_J(self):
+        """Launch a deferred J deposition now (no-op if none is pending)."""
+        pj, self._pending_J = self._pending_J, None
+        if pj is not None:
+            self.defer_J_deposit = False
+            # J belongs to the positions BEFORE a deferred push: hide the push from the sort
+            # that this deposit may trigger, and count it again if that sort happened
+            pend, self._pending_push = self._pending_push, None
+            self.deposit(pj[0], 'J', records=pj[1])
+            self._pending_push = pend
+            if pend is not None and self._moved_since_sort == 0.:
+                self._note_push(pend[0], max(abs(pend[1]), abs(pend[2]), abs(pend[3])))
+
     def flush_pending_push(self):
-        """Launch a deferred push_x now (no-op if none is pending)."""
+        """Launch a deferred push_x now (no-op if none is pending); a deferred J deposition
+        belongs to the positions before it and goes first."""
+        self.flush_pending_J()
         pend = self._pending_push
         if pend is not None:
             self._pending_push = None
@@ -276,10 +299,12 @@ class Particles(object):
                                    p(self.Bz), _capi.stream())
         _capi.check(rc, 'fb_gather')
 
-    def gather_push(self, grid, comm, dt_x, store_fields=True, wrap_z=None):
+    def gather_push(self, grid, comm, dt_x, store_fields=True, wrap_z=None, rank_next=None):
         """gather -> push_p -> push_x(dt_x) in one pass (fb_gather_push): the fused form of
         the three consecutive calls of Simulation.step (main.py:469-490).  Results are
-        identical to calling gather(), push_p(), push_x(dt_x) one after the other."""
+        identical to calling gather(), push_p(), push_x(dt_x) one after the other.
+        `rank_next` = (dt, x_push, y_push, z_push) of the push_x that will follow: the pass also
+        ranks the particles for the sort after that push (fb_gather_push_rank_next)."""
         self._need_gpu()
         self.flush_pending_push()
         if self.q == 0:
@@ -298,14 +323,28 @@ class Particles(object):
         eb = [p(getattr(self, k)) if store_fields else None for k in _FIELDS]
         # wrap_z = (zmin, zmax): the periodic wrap of comm.exchange_particles folded in
         wz = (0., 0.) if wrap_z is None else (float(wrap_z[0]), float(wrap_z[1]))
-        rc = _capi.lib().fb_gather_push(
-            _SHAPE[self.particle_shape], Nm, self.Ntot, p(self.x), p(self.y), p(self.z),
-            p(self.ux), p(self.uy), p(self.uz), p(self.inv_gamma),
-            comm.get_rmax(with_damp=False), g0.invdz, g0.zmin, g0.Nz, g0.invdr, g0.rmin, g0.Nr,
-            _capi.ptr_array(views), _capi.row_stride(views[0]), *eb,
-            self.q, self.m, c, self.dt, dt_x, wz[0], wz[1], _capi.stream())
-        _capi.check(rc, 'fb_gather_push')
-        self._prerank = None
+        ranked = (rank_next is not None and self.use_bin_sort and self.Ntot > 0 and dt_x != 0.
+                  and g0.Nz * (g0.Nr + 1) == self.prefix_sum.shape[0])
+        if ranked:
+            rc = _capi.lib().fb_gather_push_rank_next(
+                _SHAPE[self.particle_shape], Nm, self.Ntot, p(self.x), p(self.y), p(self.z),
+                p(self.ux), p(self.uy), p(self.uz), p(self.inv_gamma),
+                comm.get_rmax(with_damp=False), g0.invdz, g0.zmin, g0.Nz, g0.invdr, g0.rmin, g0.Nr,
+                _capi.ptr_array(views), _capi.row_stride(views[0]), *eb,
+                self.q, self.m, c, self.dt, dt_x, wz[0], wz[1],
+                rank_next[0], rank_next[1], rank_next[2], rank_next[3], self.prefix_sum.shape[0],
+                p(self._sort_ws), self._sort_ws.shape[0], int(self._counts_clean), _capi.stream())
+            self._counts_clean = False
+            _capi.check(rc, 'fb_gather_push_rank_next')
+        else:
+            rc = _capi.lib().fb_gather_push(
+                _SHAPE[self.particle_shape], Nm, self.Ntot, p(self.x), p(self.y), p(self.z),
+                p(self.ux), p(self.uy), p(self.uz), p(self.inv_gamma),
+                comm.get_rmax(with_damp=False), g0.invdz, g0.zmin, g0.Nz, g0.invdr, g0.rmin, g0.Nr,
+                _capi.ptr_array(views), _capi.row_stride(views[0]), *eb,
+                self.q, self.m, c, self.dt, dt_x, wz[0], wz[1], _capi.stream())
+            _capi.check(rc, 'fb_gather_push')
+        self._prerank = tuple(rank_next) if ranked else None
         self.sorted = False
         dmin = min(self._cell_size) if self._cell_size else 0.
         self._moved_since_sort += (c * abs(dt_x) / dmin if dmin > 0 else np.inf)
@@ -315,6 +354,7 @@ class Particles(object):
         """Cell index -> stable radix sort -> per-cell prefix sum -> permutation
         (reference :1049-1094)."""
         self._need_gpu()
+        self.flush_pending_J()          # a deferred J deposition belongs to the unsorted state
         g0 = fld.interp[0]
         lib = _capi.lib()
         p = _capi.ptr
@@ -394,16 +434,40 @@ class Particles(object):
         ruy0 = getattr(grid[0], 'd_ruyten_%s_coef' % suffix)
         ruyh = getattr(grid[1 if Nm > 1 else 0], 'd_ruyten_%s_coef' % suffix)
         views = fld.record_views('rho') if records else [grid[m].rho for m in range(Nm)]
-        rc = lib.fb_push_x_sort_deposit_rho(
-            self.Ntot, self.prefix_sum.shape[0], p(self.x), p(self.y), p(self.z),
-            p(self.ux), p(self.uy), p(self.uz), p(self.inv_gamma), c, pend[0], pend[1], pend[2],
-            pend[3], g0.invdz, g0.zmin, g0.Nz, g0.invdr, g0.rmin, g0.Nr,
-            len(names), _capi.ptr_array(src), _capi.ptr_array(dst),
-            p(self.cell_idx) if self.keep_sort_outputs else None, p(self.sorted_idx),
-            p(self.prefix_sum), p(self._sort_ws), self._sort_ws.shape[0], preranked,
-            _SHAPE[self.particle_shape], Nm, self.q, _capi.ptr_array(views),
-            views[0].stride(0), views[0].stride(1), p(ruy0), p(ruyh), st)
-        _capi.check(rc, 'fb_push_x_sort_deposit_rho')
+        pj = self._pending_J
+        if pj is not None and (pj[0] is not fld or pj[1] != records):
+            self.flush_pending_J()              # different target: J on its own, then as usual
+            pj = None
+        self._pending_J = None
+        if pj is not None:
+            if records:
+                jviews = fld.record_views('J')
+            else:
+                jviews = []
+                for m in range(Nm):
+                    jviews += [grid[m].Jr, grid[m].Jt, grid[m].Jz]
+            rc = lib.fb_push_x_sort_deposit_J_rho(
+                self.Ntot, self.prefix_sum.shape[0], p(self.x), p(self.y), p(self.z),
+                p(self.ux), p(self.uy), p(self.uz), p(self.inv_gamma), c, pend[0], pend[1], pend[2],
+                pend[3], g0.invdz, g0.zmin, g0.Nz, g0.invdr, g0.rmin, g0.Nr,
+                len(names), _capi.ptr_array(src), _capi.ptr_array(dst),
+                p(self.cell_idx) if self.keep_sort_outputs else None, p(self.sorted_idx),
+                p(self.prefix_sum), p(self._sort_ws), self._sort_ws.shape[0], preranked,
+                _SHAPE[self.particle_shape], Nm, self.q, g0.zmin, _capi.ptr_array(jviews),
+                jviews[0].stride(0), jviews[0].stride(1), _capi.ptr_array(views),
+                views[0].stride(0), views[0].stride(1), p(ruy0), p(ruyh), st)
+            _capi.check(rc, 'fb_push_x_sort_deposit_J_rho')
+        else:
+            rc = lib.fb_push_x_sort_deposit_rho(
+                self.Ntot, self.prefix_sum.shape[0], p(self.x), p(self.y), p(self.z),
+                p(self.ux), p(self.uy), p(self.uz), p(self.inv_gamma), c, pend[0], pend[1], pend[2],
+                pend[3], g0.invdz, g0.zmin, g0.Nz, g0.invdr, g0.rmin, g0.Nr,
+                len(names), _capi.ptr_array(src), _capi.ptr_array(dst),
+                p(self.cell_idx) if self.keep_sort_outputs else None, p(self.sorted_idx),
+                p(self.prefix_sum), p(self._sort_ws), self._sort_ws.shape[0], preranked,
+                _SHAPE[self.particle_shape], Nm, self.q, _capi.ptr_array(views),
+                views[0].stride(0), views[0].stride(1), p(ruy0), p(ruyh), st)
+            _capi.check(rc, 'fb_push_x_sort_deposit_rho')
         self._counts_clean = True
         for i, k in enumerate(names):
             setattr(self, k, dst[i])
@@ -476,12 +540,24 @@ class Particles(object):
             return
         assert fieldtype in ['rho', 'J']
         self._need_gpu()
+        if fieldtype == 'J':
+            defer, self.defer_J_deposit = self.defer_J_deposit, False
+            # (linear shape only: with the cubic shape the two depositions together need 176-264
+            # VGPRs - one or two waves per SIMD - and the fused pass is no faster than two)
+            if (defer and self.fuse_sort_deposit_rho and self.use_bin_sort and self.Ntot > 0
+                    and len(fld.interp) <= 4 and self._pending_push is None
+                    and self.particle_shape == 'linear'):
+                self._pending_J = (fld, records)          # rides along in the rho deposition
+                self.push_after_deposit_J = None
+                return
         if (fieldtype == 'rho' and self.fuse_sort_deposit_rho and self.use_bin_sort
                 and self._pending_push is not None and not self.sorted and self._needs_sort()
                 and self.Ntot > 0):
             # the step's push_x(dt/2) -> re-sort -> deposit('rho_next'): one pass
             self._push_sort_deposit_rho(fld, records)
             return
+        if fieldtype == 'rho':
+            self.flush_pending_J()
         if not self.sorted and self._needs_sort():
             self.sort_particles(fld=fld)
             self.sorted = True
@@ -514,6 +590,8 @@ class Particles(object):
             if records:
                 views = fld.record_views('J')
             hint, self.push_after_deposit_J = self.push_after_deposit_J, None
+            if hint is not None and self._prerank == tuple(hint):
+                hint = None                 # already ranked for that push (gather_push)
             if hint is not None and self.use_bin_sort and self.Ntot > 0:
                 # the deposition also ranks the particles for the sort that follows `hint`
                 rc = lib.fb_deposit_J_rank_next(

@@ -111,6 +111,24 @@ int fb_gather_push(int shape, int Nm, long n, double *x, double *y, double *z,
                    double q, double m, double c, double dt, double dt_x,
                    double wrap_zmin, double wrap_zmax, void *stream);
 
+/* fb_gather_push that also prepares the counting sort which Simulation.step runs after the NEXT
+ * push_x (main.py:519-528): for every particle, the cell of the position pushed once more by
+ * (dt_push, x_push, y_push, z_push) - from the momenta this call has just updated - and its
+ * rank in that cell go to `sort_workspace` (layout of fb_bin_sort_workspace_bytes), exactly as
+ * fb_deposit_J_rank_next does.  Follow with fb_push_x_bin_sort_particles /
+ * fb_push_x_sort_deposit_rho / fb_push_x_sort_deposit_J_rho(..., preranked = 1) for that push.
+ * The particle arrays must not be modified in between.  Needs dt_x != 0. */
+int fb_gather_push_rank_next(int shape, int Nm, long n, double *x, double *y, double *z,
+                             double *ux, double *uy, double *uz, double *inv_gamma,
+                             double rmax_gather, double invdz, double zmin, int Nz, double invdr,
+                             double rmin, int Nr, const void *const *grids, long row_stride,
+                             double *Ex, double *Ey, double *Ez, double *Bx, double *By, double *Bz,
+                             double q, double m, double c, double dt, double dt_x,
+                             double wrap_zmin, double wrap_zmax,
+                             double dt_push, double x_push, double y_push, double z_push, int ncell,
+                             void *sort_workspace, size_t workspace_bytes, int counts_are_zero,
+                             void *stream);
+
 /* ---- cell sort ---------------------------------------------------------------- */
 /* particles/particles.py:1075-1081 -> get_cell_idx_per_particle
  * (utilities/cuda_sorting.py:21-88): cell_idx = ir_upper + iz_upper*(Nr+1);
@@ -233,6 +251,31 @@ int fb_push_x_sort_deposit_rho(long n, int ncell, const double *x, const double 
                                int shape, int Nm, double q, void *const *rho, long row_stride,
                                long col_stride, const double *ruyten_m0, const double *ruyten_mh,
                                void *stream);
+
+/* The whole tail of Simulation.step's particle work in ONE pass: deposit('J') from the
+ * positions at t = n+1/2 (main.py:515-517), push_x(dt/2) (:519-522), the re-sort and
+ * deposit('rho_next') from the positions at t = n+1 (:528).  Identical result to
+ *   fb_deposit_J(shape, Nm, n, x, ..., zmin = zmin_J, J, ...)   then
+ *   fb_push_x_sort_deposit_rho(...)
+ * (per-particle arithmetic unchanged; the deposited sums differ by summation order only).  The
+ * particles are walked in destination order as in fb_push_x_sort_deposit_rho; every lane holds
+ * x, y, z, u, w, inv_gamma in registers, deposits its current from the position it read, pushes
+ * it, stores all attributes at the sorted slot and deposits its charge from the pushed position:
+ * the stand-alone J pass (64 B per particle read again) disappears and the arithmetic of both
+ * depositions overlaps the memory stalls of the permutation.  zmin_J: grid position for the J
+ * deposit (= zmin unless the grid moved in between).  Nm <= 4. */
+int fb_push_x_sort_deposit_J_rho(long n, int ncell, const double *x, const double *y,
+                                 const double *z, const double *ux, const double *uy,
+                                 const double *uz, const double *inv_gamma, double c, double dt,
+                                 double x_push, double y_push, double z_push,
+                                 double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
+                                 int nattr, const double *const *src, double *const *dst,
+                                 int *cell_idx_sorted, int *sorted_idx, int *prefix_sum,
+                                 void *workspace, size_t workspace_bytes, int preranked,
+                                 int shape, int Nm, double q, double zmin_J, void *const *J,
+                                 long J_row_stride, long J_col_stride, void *const *rho,
+                                 long row_stride, long col_stride, const double *ruyten_m0,
+                                 const double *ruyten_mh, void *stream);
 
 /* fb_deposit_J that also prepares the counting sort which Simulation.step runs after the
  * next push_x (main.py:515-528: deposit J, push_x(dt/2), re-sort for deposit rho_next): for

@@ -691,6 +691,77 @@ def test_gather_push_fused_is_bit_identical_to_sequence(hip, shape):
         assert np.array_equal(g[k], host(b))
 
 
+@pytest.mark.parametrize('shape', ['linear', 'cubic'])
+def test_gather_push_rank_next(hip, oracle, shape):
+    """fb_gather_push_rank_next == fb_gather_push (bit-identical particle arrays) + the cell /
+    rank by-product for the NEXT push_x: followed by fb_push_x_bin_sort_particles(preranked = 1)
+    it gives the same sorted arrays, cells and prefix sums as the un-preranked sort of the
+    fb_gather_push result (cells bit-identical to the oracle's index of the oracle-pushed
+    positions)."""
+    g = golden('gather')
+    Nz, Nr, nm = int(g['Nz']), int(g['Nr']), 2
+    n = g['x'].size
+    t = hip.torch()
+    rng = np.random.default_rng(22)
+    views = [dev(hip, g['grids'][m, k] * 1e9) for m in range(nm) for k in range(6)]
+    u0 = [rng.normal(size=n) for _ in range(3)]
+    ig0 = 1. / np.sqrt(1 + u0[0]**2 + u0[1]**2 + u0[2]**2)
+    w0 = rng.uniform(0.5, 1.5, n)
+    dt = 6.67e-16
+    invdz, zmin, invdr = 1. / float(g['dz']), float(g['zmin']), 1. / float(g['dr'])
+    geom = (float(g['rmax_gather']), invdz, zmin, Nz, invdr, 0., Nr)
+    cgeom = (invdz, zmin, Nz, invdr, 0., Nr)
+    p = hip.ptr
+    sh = 1 if shape == 'linear' else 3
+    ncell = Nz * (Nr + 1)
+    nb = int(hip.lib().fb_bin_sort_workspace_bytes(n, ncell))
+
+    def fresh():
+        pos = [dev(hip, g[k]) for k in ('x', 'y', 'z')]
+        mom = [dev(hip, a) for a in u0] + [dev(hip, ig0)]
+        return pos, mom
+    posA, momA = fresh()
+    hip.check(hip.lib().fb_gather_push(sh, nm, n, *[p(a) for a in posA], *[p(a) for a in momA], *geom,
+                                       hip.ptr_array(views), Nr, *([None] * 6), -e, m_e, c, dt,
+                                       0.5 * dt, 0., 0., hip.stream()), 'gather_push')
+    posB, momB = fresh()
+    ws = t.empty(nb, dtype=t.uint8, device='cuda')
+    hip.check(hip.lib().fb_gather_push_rank_next(
+        sh, nm, n, *[p(a) for a in posB], *[p(a) for a in momB], *geom, hip.ptr_array(views), Nr,
+        *([None] * 6), -e, m_e, c, dt, 0.5 * dt, 0., 0., 0.5 * dt, 1., 1., 1., ncell, p(ws), nb, 0,
+        hip.stream()), 'gather_push_rank_next')
+    for a, b in zip(posA + momA, posB + momB):
+        assert np.array_equal(host(a), host(b))
+    wdev = dev(hip, w0)
+
+    def sort(pos, mom, work, preranked):
+        src = [pos[0], pos[1], pos[2], mom[0], mom[1], mom[2], wdev, mom[3]]
+        dst = [t.empty_like(a) for a in src]
+        ci = t.empty(n, dtype=t.int32, device='cuda')
+        si = t.empty(n, dtype=t.int32, device='cuda')
+        pre = t.empty(ncell, dtype=t.int32, device='cuda')
+        hip.check(hip.lib().fb_push_x_bin_sort_particles(
+            n, ncell, p(src[0]), p(src[1]), p(src[2]), p(src[3]), p(src[4]), p(src[5]), p(src[7]),
+            c, 0.5 * dt, 1., 1., 1., *cgeom, 8, hip.ptr_array(src), hip.ptr_array(dst), p(ci), p(si),
+            p(pre), p(work), nb, preranked, hip.stream()), 'push_x_bin_sort')
+        return [host(a) for a in dst], host(ci), host(si), host(pre)
+    dA, ciA, siA, preA = sort(posA, momA, t.empty(nb, dtype=t.uint8, device='cuda'), 0)
+    dB, ciB, siB, preB = sort(posB, momB, ws, 1)
+    assert np.array_equal(preA, preB) and np.array_equal(ciA, ciB)
+    assert np.array_equal(np.sort(siB), np.arange(n, dtype=np.int32))
+    # same multiset of particles per cell (the order inside a cell is free): compare after a
+    # canonical sort by (cell, x, y, z)
+    oA = np.lexsort((dA[2], dA[1], dA[0], ciA))
+    oB = np.lexsort((dB[2], dB[1], dB[0], ciB))
+    for a, b in zip(dA, dB):
+        assert np.array_equal(a[oA], b[oB])
+    # cells of the twice-pushed positions, oracle arithmetic
+    xr, yr, zr = (host(a).copy() for a in posA)
+    oracle.push_x(xr, yr, zr, host(momA[0]), host(momA[1]), host(momA[2]), host(momA[3]), 0.5 * dt)
+    ref = oracle.cell_index(xr, yr, zr, *cgeom)
+    assert np.array_equal(ciB, ref[siB])
+
+
 @pytest.mark.parametrize('presorted', [True, False])
 def test_bin_sort_particles(hip, oracle, presorted):
     """Counting-sort fast path: cells sorted, a valid permutation, prefix sums and cell
@@ -923,6 +994,104 @@ def test_push_sort_deposit_rho_fused(hip, oracle, shape, Nm, preranked, nattr, r
             red = np.zeros((Nz, Nr), dtype=np.complex128)
             oracle.sum_reduce(glob, m, red)
             assert rel_err(host(views[m]), red) < 1e-13, m
+
+
+@pytest.mark.parametrize('shape,Nm,records', [(1, 2, True), (1, 1, False), (3, 2, False), (3, 4, False),
+                                              (1, 3, True)])
+def test_push_sort_deposit_J_rho_fused(hip, oracle, shape, Nm, records):
+    """fb_push_x_sort_deposit_J_rho == fb_deposit_J (positions before the push, its own zmin) then
+    fb_push_x_sort_deposit_rho: same sorted particle arrays (bit-identical pushed positions), J
+    and rho equal to the separate launches and to the oracle depositions (1e-13)."""
+    from scipy.constants import c
+    rng = np.random.default_rng(51 + Nm)
+    n, Nz, Nr = 120001, 40, 24
+    dzc = 0.2e-6
+    r = rng.uniform(0, 1.02 * Nr * dzc, n)
+    th = rng.uniform(0, 2 * np.pi, n)
+    x, y = r * np.cos(th), r * np.sin(th)
+    z = rng.uniform(0., Nz * dzc, n)
+    geom = (1. / dzc, 0., Nz, 1. / dzc, 0., Nr)
+    o = np.argsort(oracle.cell_index(x, y, z, *geom), kind='stable')
+    x, y, z = x[o], y[o], z[o]
+    ux, uy, uz = (rng.normal(size=n) * 0.3 for _ in range(3))
+    ig = 1. / np.sqrt(1. + ux**2 + uy**2 + uz**2)
+    w = rng.uniform(0.5, 1.5, n)
+    dt = 0.5 * dzc / c
+    q = -1.6e-19
+    xr, yr, zr = x.copy(), y.copy(), z.copy()
+    oracle.push_x(xr, yr, zr, ux, uy, uz, ig, dt, 1., 1., 1.)
+    ref_cell = oracle.cell_index(xr, yr, zr, *geom)
+    t = hip.torch()
+    p = hip.ptr
+    ncell = Nz * (Nr + 1)
+    host_attrs = [x, y, z, ux, uy, uz, w, ig]
+    src = [dev(hip, a) for a in host_attrs]
+    ruy0 = dev(hip, rng.uniform(-0.05, 0.05, Nr + 1))
+    ruyh = dev(hip, rng.uniform(-0.05, 0.05, Nr + 1))
+    nb = int(hip.lib().fb_bin_sort_workspace_bytes(n, ncell))
+
+    def target():
+        if records:      # node-major records: (Nz, Nr, 4 Nm): Jr, Jt, Jz, rho of mode m at 4m..4m+3
+            rec = t.zeros((Nz, Nr, 4 * Nm), dtype=t.complex128, device='cuda')
+            return rec, [rec[:, :, 4 * m + k] for m in range(Nm) for k in range(3)], \
+                [rec[:, :, 4 * m + 3] for m in range(Nm)]
+        g = t.zeros((Nz, 4 * Nm, Nr), dtype=t.complex128, device='cuda')
+        return g, [g[:, 4 * m + k, :] for m in range(Nm) for k in range(3)], \
+            [g[:, 4 * m + 3, :] for m in range(Nm)]
+    # ---- fused
+    ws = t.empty(nb, dtype=t.uint8, device='cuda')
+    dst = [t.empty_like(a) for a in src]
+    si = t.empty(n, dtype=t.int32, device='cuda')
+    pre = t.empty(ncell, dtype=t.int32, device='cuda')
+    base, jv, rv = target()
+    hip.check(hip.lib().fb_push_x_sort_deposit_J_rho(
+        n, ncell, p(src[0]), p(src[1]), p(src[2]), p(src[3]), p(src[4]), p(src[5]), p(src[7]),
+        c, dt, 1., 1., 1., *geom, 8, hip.ptr_array(src), hip.ptr_array(dst), None, p(si), p(pre),
+        p(ws), nb, 0, shape, Nm, q, 0., hip.ptr_array(jv), jv[0].stride(0), jv[0].stride(1),
+        hip.ptr_array(rv), rv[0].stride(0), rv[0].stride(1), p(ruy0), p(ruyh), hip.stream()),
+        'push_x_sort_deposit_J_rho')
+    sidx, prefix = host(si), host(pre)
+    assert np.array_equal(np.sort(sidx), np.arange(n, dtype=np.int32))
+    assert np.all(np.diff(ref_cell[sidx]) >= 0)
+    assert np.array_equal(prefix, np.cumsum(np.bincount(ref_cell, minlength=ncell)).astype(np.int32))
+    for a, b in zip([xr, yr, zr, ux, uy, uz, w, ig], dst):
+        assert np.array_equal(host(b), a[sidx])
+    # ---- separate launches
+    base2, jv2, rv2 = target()
+    hip.check(hip.lib().fb_deposit_J(
+        shape, Nm, n, p(src[0]), p(src[1]), p(src[2]), p(src[6]), q, p(src[3]), p(src[4]),
+        p(src[5]), p(src[7]), c, *geom, hip.ptr_array(jv2), jv2[0].stride(0), jv2[0].stride(1), None,
+        p(ruy0), p(ruyh), None, hip.stream()), 'deposit_J')
+    ws2 = t.empty(nb, dtype=t.uint8, device='cuda')
+    dst2 = [t.empty_like(a) for a in src]
+    hip.check(hip.lib().fb_push_x_sort_deposit_rho(
+        n, ncell, p(src[0]), p(src[1]), p(src[2]), p(src[3]), p(src[4]), p(src[5]), p(src[7]),
+        c, dt, 1., 1., 1., *geom, 8, hip.ptr_array(src), hip.ptr_array(dst2), None, p(si), p(pre),
+        p(ws2), nb, 0, shape, Nm, q, hip.ptr_array(rv2), rv2[0].stride(0), rv2[0].stride(1),
+        p(ruy0), p(ruyh), hip.stream()), 'push_x_sort_deposit_rho')
+    a1, a2 = host(base), host(base2)
+    for m in range(Nm):
+        for k, nm in enumerate(('Jr', 'Jt', 'Jz')):
+            g1, g2 = host(jv[3 * m + k]), host(jv2[3 * m + k])
+            sc = max(np.abs(host(jv2[3 * mm + kk])).max() for mm in range(Nm) for kk in range(3))
+            assert np.abs(g1 - g2).max() <= 1e-13 * sc, (m, nm)
+        g1, g2 = host(rv[m]), host(rv2[m])
+        sc = max(np.abs(host(rv2[mm])).max() for mm in range(Nm))
+        assert np.abs(g1 - g2).max() <= 1e-13 * sc, (m, 'rho')
+    # ---- oracle: J from the unpushed, rho from the pushed particles
+    sh = 'linear' if shape == 1 else 'cubic'
+    gl = oracle.deposit_J_global(sh, Nm, x, y, z, w, q, ux, uy, uz, ig, *geom, host(ruy0), host(ruyh), 1)
+    gr = np.zeros((1, Nm, Nz + 4, Nr + 4), dtype=np.complex128)
+    oracle.deposit_rho_global(sh, Nm, xr, yr, zr, w, q, *geom, host(ruy0), host(ruyh), 1, gr)
+    for m in range(Nm):
+        for k in range(3):
+            red = np.zeros((Nz, Nr), dtype=np.complex128)
+            oracle.sum_reduce(gl[k], m, red)
+            sc = max(np.abs(gl[kk]).max() for kk in range(3))
+            assert np.abs(host(jv[3 * m + k]) - red).max() <= 1e-13 * sc, (m, k)
+        red = np.zeros((Nz, Nr), dtype=np.complex128)
+        oracle.sum_reduce(gr, m, red)
+        assert rel_err(host(rv[m]), red) < 1e-13 * max(1., np.abs(gr).max() / max(np.abs(red).max(), 1e-300)), m
 
 
 def test_exchange_rccl_loopback(hip):
