@@ -284,11 +284,7 @@ struct DepEngine {
                 // axis sign
                 long joff = (jr & 1) ? cs2 : 0;
                 if constexpr (S > 2) joff += (jr & 2) ? 2 * cs2 : 0;
-#ifndef FB_DEP_NO_ATOMICS
                 atomicAdd(f_ptrz[qq] + cell_base2 + joff, v);
-#else
-                if (v == 1.2345e300) f_ptrz[qq][cell_base2 + joff] = v;
-#endif
             } else {
                 int gz = cur_z + f_jz[qq], gr = cur_r + jr;
                 fold_node(gz, gr, Nz, Nr);
@@ -375,6 +371,11 @@ struct DepEngine {
     // ---- phase 2: runs of equal cells (boundaries found with one ballot) are reduced on the
     // matrix cores, 16 staged particles per instruction; particles of a group that belong to
     // another run are masked out of the weight operand.
+    // (Measured with knock-out builds of the fused J + rho pass, 181 us: without phase 2 123 us,
+    // without phase 1 as well 119 us = the permutation alone; without the atomics -11 us.
+    // Phase 2 is a chain of short dependent steps per run that the other waves of the SIMD
+    // only partly cover.  Requesting all LDS operands of a chunk up front costs 24 VGPRs, i.e.
+    // one wave per SIMD, and loses: 208 -> 233 us.)
     __device__ __forceinline__ void reduce(int cnt, int my_kz, int my_kr, int my_nb)
     {
         const int prev_kz = __shfl_up(my_kz, 1), prev_kr = __shfl_up(my_kr, 1);
