@@ -81,6 +81,7 @@ _SIGNATURES = {
     'fb_hankel_pm_to_rt': (I, [I, _PP, _PP, L, _PP, _PP, L, _PP, _PP, D, I, I, P]),
     'fb_hankel_rt_to_pm_scaled': (I, [I, _PP, _PP, P, L, _PP, L, _PP, _PP, _PP, _PP, D, I, I, P]),
     'fb_psatd_step_standard': (I, [I, _PP, L, _PP, D, I, I, D, D, D, I, I, P]),
+    'fb_psatd_step_standard_shift': (I, [I, _PP, L, _PP, D, I, I, D, D, D, I, I, P, I, P]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

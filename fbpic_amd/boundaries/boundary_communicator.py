@@ -215,9 +215,9 @@ class BoundaryCommunicator(object):
     def shift_global_domain_positions(self, z_shift):
         self._zmin_global_domain += z_shift
 
-    def move_grids(self, fld, ptcl, dt, time):
+    def move_grids(self, fld, ptcl, dt, time, spect_shifted_by=None):
         """Advance the moving window (boundary_communicator.py:533-553)."""
-        self.moving_win.move_grids(fld, ptcl, self, time)
+        self.moving_win.move_grids(fld, ptcl, self, time, spect_shifted_by)
 
     # ---------------------------------------------------------------- damping (open z)
     def generate_damp_array(self, n_guard, nz_damp, n_inject):

@@ -23,17 +23,30 @@ class MovingWindow(object):
         # identically on all ranks instead of being broadcast (moving_window.py:89-98)
         self.zmin = zmin_global
 
-    def move_grids(self, fld, ptcl, comm, time):
+    def peek_n_move(self, comm, time):
+        """Number of cells by which the next move_grids(.., time) will shift the grids (same
+        arithmetic, nothing modified): lets Simulation.step fold the spectral translation
+        into the field push that precedes it."""
+        zmin = self.zmin + self.v * (time - self.t_last_move)
+        zmin_global, _ = comm.get_zmin_zmax(local=False, with_damp=False, with_guard=False)
+        return int((zmin - zmin_global) / comm.dz)
+
+    def move_grids(self, fld, ptcl, comm, time, spect_shifted_by=None):
+        """`spect_shifted_by`: the spectral fields have already been translated by that many
+        cells (by the field push, fb_psatd_step_standard_shift)."""
         dz = comm.dz
         self.zmin += self.v * (time - self.t_last_move)
         zmin_global, _ = comm.get_zmin_zmax(local=False, with_damp=False, with_guard=False)
         n_move = int((self.zmin - zmin_global) / dz)
+        if spect_shifted_by is not None:
+            assert spect_shifted_by == n_move, (spect_shifted_by, n_move)
         if n_move != 0:
             comm.shift_global_domain_positions(n_move * dz)
             for m in range(len(fld.interp)):
                 fld.interp[m].zmin += n_move * fld.interp[m].dz
                 fld.interp[m].zmax += n_move * fld.interp[m].dz
-            self.shift_spect_grids(fld, n_move)
+            if spect_shifted_by is None:
+                self.shift_spect_grids(fld, n_move)
         for species in ptcl:
             species.prefix_sum_shift += n_move
         if comm.rank == comm.size - 1:

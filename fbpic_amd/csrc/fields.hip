@@ -169,14 +169,31 @@ struct PsatdModes {
     const double *t[8 * FB_MAX_MODES];   // rho_prev_coef, rho_next_coef, j_coef, C, S_w, kr, kz, inv_k2
 };
 
+// shift != null and n_move != 0: the moving window's translation of the grid by n_move cells
+// (fb_shift_spect: E, B, rho_prev and J times shift[iz]^n_move, moving_window.py:176-239) is
+// applied to the values this kernel writes anyway - one sweep over the spectral slab less per
+// step of a moving-window run.
 __global__ __launch_bounds__(256) void k_psatd_step(PsatdModes M, long rs, double dt, double inv_dt,
-        int correct, int use_true_rho, double c2, double eps0, double mu0, int Nz, int Nr)
+        int correct, int use_true_rho, double c2, double eps0, double mu0, int Nz, int Nr,
+        const cplx *__restrict__ shift, int n_move)
 {
     const int m = blockIdx.y;
     cplx *const *f = M.f + 11 * m;
     const double *const *t = M.t + 8 * m;
+    const bool moving = shift != nullptr && n_move != 0;
     FB_GRID_LOOP(idx, iz, ir) {
         const long o = (long)iz * rs + ir;
+        cplx pw = {1., 0.};
+        if (moving) {
+            const cplx sh = ld(shift + iz);
+            const int na = n_move < 0 ? -n_move : n_move;
+            for (int i = 0; i < na; i++) pw = {pw.re * sh.re - pw.im * sh.im, pw.re * sh.im + pw.im * sh.re};
+            if (n_move < 0) pw.im = -pw.im;
+        }
+        auto stw = [&](cplx *p, cplx a) {      // store, translated when the window moves
+            if (moving) a = {a.re * pw.re - a.im * pw.im, a.re * pw.im + a.im * pw.re};
+            st(p, a);
+        };
         const double rpc = t[0][idx], rnc = t[1][idx], jc = t[2][idx], Cc = t[3][idx], Sw = t[4][idx];
         const double krr = t[5][idx], kzz = t[6][idx];
         const cplx ep = ld(f[0] + o), em = ld(f[1] + o), ez = ld(f[2] + o);
@@ -191,8 +208,13 @@ __global__ __launch_bounds__(256) void k_psatd_step(PsatdModes M, long rs, doubl
             jp = cadd(jp, rmul(0.5 * krr, F));
             jm = cadd(jm, rmul(-0.5 * krr, F));
             jz = cadd(jz, rmul(kzz, imul(rmul(-1., F))));
-            st(f[6] + o, jp); st(f[7] + o, jm); st(f[8] + o, jz);
-            if (correct == 2) continue;          // correction only (the J guard exchange follows)
+            if (correct == 2) {                  // correction only (the J guard exchange follows)
+                st(f[6] + o, jp); st(f[7] + o, jm); st(f[8] + o, jz);
+                continue;
+            }
+            stw(f[6] + o, jp); stw(f[7] + o, jm); stw(f[8] + o, jz);
+        } else if (moving) {
+            stw(f[6] + o, jp); stw(f[7] + o, jm); stw(f[8] + o, jz);
         }
         cplx rho_diff;
         if (use_true_rho) {
@@ -203,22 +225,22 @@ __global__ __launch_bounds__(256) void k_psatd_step(PsatdModes M, long rs, doubl
             rho_diff = csub(rmul((rnc - rpc) * eps0, divE), rmul(rnc * dt, divJ));
         }
         const cplx mihkBz = rmul(0.5 * krr, imul(rmul(-1., bz)));
-        st(f[0] + o, cadd(cadd(rmul(Cc, ep), rmul(0.5 * krr, rho_diff)),
+        stw(f[0] + o, cadd(cadd(rmul(Cc, ep), rmul(0.5 * krr, rho_diff)),
                           rmul(c2 * Sw, csub(cadd(mihkBz, rmul(kzz, bp)), rmul(mu0, jp)))));
-        st(f[1] + o, cadd(csub(rmul(Cc, em), rmul(0.5 * krr, rho_diff)),
+        stw(f[1] + o, cadd(csub(rmul(Cc, em), rmul(0.5 * krr, rho_diff)),
                           rmul(c2 * Sw, csub(csub(mihkBz, rmul(kzz, bm)), rmul(mu0, jm)))));
-        st(f[2] + o, cadd(csub(rmul(Cc, ez), rmul(kzz, imul(rho_diff))),
+        stw(f[2] + o, cadd(csub(rmul(Cc, ez), rmul(kzz, imul(rho_diff))),
                           rmul(c2 * Sw, csub(cadd(rmul(krr, imul(bp)), rmul(krr, imul(bm))),
                                              rmul(mu0, jz)))));
         const cplx mihkEz = rmul(0.5 * krr, imul(rmul(-1., ez)));
         const cplx mihkJz = rmul(0.5 * krr, imul(rmul(-1., jz)));
-        st(f[3] + o, cadd(csub(rmul(Cc, bp), rmul(Sw, cadd(mihkEz, rmul(kzz, ep)))),
+        stw(f[3] + o, cadd(csub(rmul(Cc, bp), rmul(Sw, cadd(mihkEz, rmul(kzz, ep)))),
                           rmul(jc, cadd(mihkJz, rmul(kzz, jp)))));
-        st(f[4] + o, cadd(csub(rmul(Cc, bm), rmul(Sw, csub(mihkEz, rmul(kzz, em)))),
+        stw(f[4] + o, cadd(csub(rmul(Cc, bm), rmul(Sw, csub(mihkEz, rmul(kzz, em)))),
                           rmul(jc, csub(mihkJz, rmul(kzz, jm)))));
-        st(f[5] + o, cadd(csub(rmul(Cc, bz), rmul(Sw, cadd(rmul(krr, imul(ep)), rmul(krr, imul(em))))),
+        stw(f[5] + o, cadd(csub(rmul(Cc, bz), rmul(Sw, cadd(rmul(krr, imul(ep)), rmul(krr, imul(em))))),
                           rmul(jc, cadd(rmul(krr, imul(jp)), rmul(krr, imul(jm))))));
-        st(f[9] + o, rn);
+        stw(f[9] + o, rn);
         st(f[10] + o, {0., 0.});
     }
 }
@@ -549,18 +571,32 @@ extern "C" int fb_push_rho(void *rho_prev, void *rho_next, long rs, int Nz, int 
     FB_CHECK_LAUNCH("fb_push_rho");
 }
 
-extern "C" int fb_psatd_step_standard(int Nm, void *const *fields, long rs,
+extern "C" int fb_psatd_step_standard_shift(int Nm, void *const *fields, long rs,
         const double *const *tables, double dt, int correct_currents, int use_true_rho,
-        double c, double epsilon_0, double mu_0, int Nz, int Nr, void *stream)
+        double c, double epsilon_0, double mu_0, int Nz, int Nr, const void *shift, int n_move,
+        void *stream)
 {
     if (Nm < 1 || Nm > FB_MAX_MODES) { set_error("fb_psatd_step_standard", "Nm out of range"); return -1; }
+    if (n_move != 0 && correct_currents == 2) {
+        set_error("fb_psatd_step_standard_shift", "the window shift belongs to the push, not to the correction-only call");
+        return -1;
+    }
     PsatdModes M;
     for (int i = 0; i < 11 * FB_MAX_MODES; i++) M.f[i] = i < 11 * Nm ? (cplx *)fields[i] : nullptr;
     for (int i = 0; i < 8 * FB_MAX_MODES; i++) M.t[i] = i < 8 * Nm ? tables[i] : nullptr;
     dim3 grid(stream_grid((long)Nz * Nr, 256, 256 * 4), Nm);
     hipLaunchKernelGGL(k_psatd_step, grid, dim3(256), 0, (hipStream_t)stream, M, rs, dt, 1. / dt,
-                       correct_currents, use_true_rho, c * c, epsilon_0, mu_0, Nz, Nr);
+                       correct_currents, use_true_rho, c * c, epsilon_0, mu_0, Nz, Nr,
+                       (const cplx *)shift, n_move);
     FB_CHECK_LAUNCH("fb_psatd_step_standard");
+}
+
+extern "C" int fb_psatd_step_standard(int Nm, void *const *fields, long rs,
+        const double *const *tables, double dt, int correct_currents, int use_true_rho,
+        double c, double epsilon_0, double mu_0, int Nz, int Nr, void *stream)
+{
+    return fb_psatd_step_standard_shift(Nm, fields, rs, tables, dt, correct_currents, use_true_rho, c,
+                                        epsilon_0, mu_0, Nz, Nr, nullptr, 0, stream);
 }
 
 extern "C" int fb_shift_spect(int nf, void *const *ptrs, long rs, const void *shift, int n_move,

@@ -188,6 +188,11 @@ typedef ZCfg<4096, 1, 256, 16, 16, 16, 1, 1> ZC4096;
 typedef ZCfg<576, 8, 192, 6, 6, 4, 4, 1> ZC576;
 typedef ZCfg<1152, 4, 192, 6, 6, 8, 4, 1> ZC1152;
 typedef ZCfg<2304, 2, 192, 6, 6, 8, 8, 1> ZC2304;
+// (4608 = 9 x 512 - the 4096-cell laser-wakefield window with 2 x 256 guard / damping /
+// injection cells - was tried as ZCfg<4608, 1, 192, 6, 6, 8, 4, 4>: one column per workgroup
+// means 16-B pieces of 4608 different rows per pass; 0.99 ms per step for the 32 transforms of
+// that configuration against 0.80 ms for the three global passes of fb_fft_generic at 4416
+// rows.  Lengths beyond 4096 stay with the generic pass-per-launch FFT.)
 
 // One Stockham pass of radix R over the tile (NS = product of the previous radices):
 //   butterfly jj in [0, N/R): inputs rows jj + t N/R, twiddled by W_{NS R}^{t (jj mod NS)},

@@ -399,13 +399,14 @@ class Fields(object):
             self.spect[m].push_eb_with(self.psatd[m], use_true_rho)
             self.spect[m].push_rho()
 
-    def psatd_step(self, correct_currents=True, use_true_rho=False, only_correct=False):
+    def psatd_step(self, correct_currents=True, use_true_rho=False, only_correct=False, n_move=0):
         """correct_currents() + push() for all modes in ONE launch (the three updates are
         cell-local).  Used by Simulation.step on a single domain, where no guard-cell
         exchange of J separates the correction from the push (main.py:530-542).  On a
         decomposed domain the step calls it twice around that exchange: `only_correct`
         (correction of all modes, one launch), then correct_currents=False (push + rho
-        shift of all modes, one launch)."""
+        shift of all modes, one launch).  `n_move` != 0: the moving window's translation of
+        E, B, rho_prev and J by n_move cells rides along (fb_psatd_step_standard_shift)."""
         self._need_gpu()
         from scipy.constants import c, epsilon_0, mu_0
         fields, tables = [], []
@@ -414,6 +415,13 @@ class Fields(object):
             fields += [getattr(sp, k) for k in SPECT_FIELDS]
             tables += [tb['rho_prev_coef'], tb['rho_next_coef'], tb['j_coef'], tb['C'], tb['S_w'],
                        sp.d_kr, sp.d_kz, sp.d_inv_k2]
+        if n_move:
+            rc = _capi.lib().fb_psatd_step_standard_shift(
+                self.Nm, _capi.ptr_array(fields), self.d_spect.stride(0), _capi.ptr_array(tables),
+                self.dt, int(bool(correct_currents)), int(bool(use_true_rho)), c, epsilon_0, mu_0,
+                self.Nz, self.Nr, _capi.ptr(self.spect[0].d_field_shift), int(n_move), _capi.stream())
+            _capi.check(rc, 'fb_psatd_step_standard_shift')
+            return
         rc = _capi.lib().fb_psatd_step_standard(
             self.Nm, _capi.ptr_array(fields), self.d_spect.stride(0), _capi.ptr_array(tables),
             self.dt, 2 if only_correct else int(bool(correct_currents)), int(bool(use_true_rho)),

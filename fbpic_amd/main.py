@@ -222,6 +222,7 @@ class Simulation(object):
             for species in ptcl:
                 species.keep_fields_sorted = False
             cross = bool(correct_currents) and fld.current_correction == 'cross-deposition'
+            shifted_by = None       # cells by which the field push has already moved the window
             if move_positions and not self.use_galilean and not cross and self.prerank_in_deposit:
                 # the J deposition also ranks the particles for the sort after the push below
                 # (not with a Galilean grid: zmin moves between this deposit and that sort)
@@ -261,10 +262,14 @@ class Simulation(object):
                     fld.exchanged_source['J'] = True
                 fld.push(use_true_rho)
             elif self.comm.size == 1:
-                # single domain: correction, push and rho shift are cell-local -> one launch
+                # single domain: correction, push and rho shift are cell-local -> one launch,
+                # which also translates the fields when the moving window advances right after
                 if cross:
                     fld.correct_currents()
-                fld.psatd_step(correct_currents and not cross, use_true_rho)
+                if self.comm.moving_win is not None:
+                    shifted_by = self.comm.moving_win.peek_n_move(self.comm, self.time)
+                fld.psatd_step(correct_currents and not cross, use_true_rho,
+                               n_move=(shifted_by or 0))
                 if correct_currents:
                     fld.exchanged_source['J'] = True
             else:
@@ -281,7 +286,7 @@ class Simulation(object):
                 assert fld.exchanged_source['J'] is True
                 fld.psatd_step(correct_currents=False, use_true_rho=use_true_rho)
             if self.comm.moving_win is not None:
-                self.comm.move_grids(fld, ptcl, dt, self.time)
+                self.comm.move_grids(fld, ptcl, dt, self.time, spect_shifted_by=shifted_by)
             self.exchange_and_damp_EB()
             self.time += dt
             self.iteration += 1

@@ -364,6 +364,15 @@ int fb_push_eb_comoving(void *Ep, void *Em, void *Ez, void *Bp, void *Bm, void *
 int fb_psatd_step_standard(int Nm, void *const *fields, long row_stride,
         const double *const *tables, double dt, int correct_currents, int use_true_rho,
         double c, double epsilon_0, double mu_0, int Nz, int Nr, void *stream);
+/* fb_psatd_step_standard followed by fb_shift_spect(E, B, rho_prev, J; shift, n_move) in the
+ * same launch: the translation of the moving window (boundaries/moving_window.py:176-239, which
+ * Simulation.step applies right after the field push, main.py:546-549) multiplies the values
+ * the push writes anyway.  shift: complex128[Nz] = exp(i kz_true dz) (SpectralGrid.field_shift);
+ * n_move = 0 or shift = NULL: identical to fb_psatd_step_standard.  Not with correct_currents = 2. */
+int fb_psatd_step_standard_shift(int Nm, void *const *fields, long row_stride,
+                                 const double *const *tables, double dt, int correct_currents,
+                                 int use_true_rho, double c, double epsilon_0, double mu_0, int Nz,
+                                 int Nr, const void *shift, int n_move, void *stream);
 /* fields/spectral_grid.py:416-417 -> cuda_push_rho (:443) */
 int fb_push_rho(void *rho_prev, void *rho_next, long row_stride, int Nz, int Nr, void *stream);
 /* fields/spectral_transform/spectral_transformer.py:140-142, 208-210 ->

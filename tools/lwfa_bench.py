@@ -20,6 +20,8 @@ def main():
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--shape', default='linear')
+    ap.add_argument('--nz-damp', type=int, default=64, help='damping cells in z (160: local length 4608 = 9 * 2^9, LDS FFT)')
+    ap.add_argument('--filled', action='store_true', help='plasma profile starts inside the initial box (> 8 M particles from step 0)')
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -32,17 +34,17 @@ def main():
     zmin, zmax, rmax = -10.e-6, 30.e-6, 20.e-6
     Nz, Nr, Nm = a.Nz, a.Nr, 2
     dt = (zmax - zmin) / Nz / c
-    ramp_start, ramp_length = 30.e-6, 40.e-6
+    ramp_start, ramp_length = (5.e-6, 10.e-6) if a.filled else (30.e-6, 40.e-6)
 
     def dens_func(z, r):
         n = np.ones_like(z)
         n = np.where(z < ramp_start + ramp_length, (z - ramp_start) / ramp_length, n)
         return np.where(z < ramp_start, 0., n)
     np.random.seed(0)
-    sim = Simulation(Nz, zmax, Nr, rmax, Nm, dt, zmin=zmin, p_zmin=30.e-6, p_zmax=500.e-6,
+    sim = Simulation(Nz, zmax, Nr, rmax, Nm, dt, zmin=zmin, p_zmin=ramp_start, p_zmax=500.e-6,
                      p_rmin=0., p_rmax=18.e-6, p_nz=2, p_nr=2, p_nt=4, n_e=4.e24,
                      dens_func=dens_func, n_order=-1, particle_shape=a.shape,
-                     boundaries={'z': 'open', 'r': 'reflective'})
+                     boundaries={'z': 'open', 'r': 'reflective'}, n_damp={'z': a.nz_damp, 'r': 32})
     add_laser_pulse(sim, GaussianLaser(a0=4., waist=5.e-6, tau=16.e-15, z0=15.e-6))
     sim.set_moving_window(v=c)
     t_total = 0.
