@@ -74,6 +74,67 @@ WORK = {
 }
 
 
+def bench_c3(args, torch, world, rank):
+    """BASELINE configs[2]: docs/source/example_input/lwfa_script.py at 4096 x 256, Nm = 2, 16 ppc,
+    open z boundary with damping, moving window at c, continuous injection, a0 = 4 laser; the
+    density ramp starts inside the initial box so that the window is full of plasma (> 9 M
+    macroparticles) from the first timed step."""
+    import numpy as np
+    from scipy.constants import c
+    from fbpic_amd import _capi
+    from fbpic_amd.main import Simulation, GpuMemoryManager
+    from fbpic_amd.lpa_utils.laser import add_laser_pulse, GaussianLaser
+    assert world == 1, 'C4 (the decomposed run) is launched like the default bench: --gpus N'
+    zmin, zmax, rmax = -10.e-6, 30.e-6, 20.e-6
+    Nz, Nr, Nm = 4096, 256, 2
+    dt = (zmax - zmin) / Nz / c
+    ramp_start, ramp_length = 5.e-6, 10.e-6
+
+    def dens_func(z, r):
+        n = np.ones_like(z)
+        n = np.where(z < ramp_start + ramp_length, (z - ramp_start) / ramp_length, n)
+        return np.where(z < ramp_start, 0., n)
+    np.random.seed(0)
+    sim = Simulation(Nz, zmax, Nr, rmax, Nm, dt, zmin=zmin, p_zmin=ramp_start, p_zmax=500.e-6,
+                     p_rmin=0., p_rmax=18.e-6, p_nz=2, p_nr=2, p_nt=4, n_e=4.e24,
+                     dens_func=dens_func, n_order=-1, particle_shape='linear',
+                     boundaries={'z': 'open', 'r': 'reflective'})
+    add_laser_pulse(sim, GaussianLaser(a0=4., waist=5.e-6, tau=16.e-15, z0=15.e-6))
+    sim.set_moving_window(v=c)
+    with GpuMemoryManager(sim):
+        sim.step(args.warmup)
+        torch.cuda.synchronize()
+        n0 = sum(s.Ntot for s in sim.ptcl)
+        t0 = time.perf_counter()
+        sim.step(args.steps)
+        torch.cuda.synchronize()
+        dt_wall = time.perf_counter() - t0
+        n1 = sum(s.Ntot for s in sim.ptcl)
+        kern = None
+        if not args.no_kernel_timing:
+            _capi.enable_timing()
+            sim.step(10)
+            kern = _capi.collect_timing()
+    npart = 0.5 * (n0 + n1)
+    out = {
+        'metric': 'particle-updates/sec', 'value': npart * args.steps / dt_wall,
+        'unit': 'particle-updates/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * dt_wall / args.steps, 'higher_is_better': True, 'scaling': args.scaling,
+        'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': 'C3 laser-wakefield 4096x256 Nm=2 16 ppc linear shape, open z (n_guard 64, '
+                               'n_damp 64, n_inject 32: %d local rows), moving window at c, continuous '
+                               'injection, a0=4 Gaussian laser, standard PSATD n_order=-1; window '
+                               'filled with plasma' % sim.fld.Nz,
+                   'particles': int(npart), 'particles_start': n0, 'particles_end': n1,
+                   'parallelism': 'z-slab x1', 'sequence': 'fused'},
+    }
+    if kern:
+        ceil = measured_ceilings(torch)
+        out['roofline'], out['kernels'] = roofline(kern, ceil)
+        out['measured_ceilings'] = ceil
+    print(json.dumps(out))
+
+
 SEQUENCE_NOTE = {
     False: 'fused MI355X sequence: gather+push_p+push_x one pass, J deposit pre-ranks the sort, '
            'push_x+sort+rho deposit one pass; sanctioned skips inside the timed region: rho_prev '
@@ -100,6 +161,10 @@ def parse():
     ap.add_argument('--resort-fragmentation', type=float, default=None,
                     help='override Particles.resort_fragmentation (adaptive sort policy)')
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
+    ap.add_argument('--config', choices=('C2', 'C3', 'C5'), default='C2',
+                    help='BASELINE.json configuration: C2 = configs[1] (the one the metric is quoted '
+                         'on), C5 = configs[4] (2048x512 Nm=4 cubic 64 ppc), C3 = configs[2] (laser-'
+                         'wakefield 4096x256, moving window, window filled with plasma)')
     ap.add_argument('--reference-sequence', action='store_true',
                     help="the reference's launch sequence: no fusion, rho_prev re-deposited every step")
     return ap.parse_args()
@@ -141,8 +206,12 @@ def main():
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node == --gpus'
     from fbpic_amd import _capi
     from fbpic_amd.main import GpuMemoryManager
+    if args.config == 'C5':
+        args.Nz, args.Nr, args.Nm, args.shape, args.ppc = 2048, 512, 4, 'cubic', '2,2,16'
     ppc = tuple(int(v) for v in args.ppc.split(','))
     n_order = -1 if world == 1 else 32
+    if args.config == 'C3':
+        return bench_c3(args, torch, world, rank)
     # weak scaling: every rank owns args.Nz cells; strong: the args.Nz cells are divided.
     # The Simulation is given the global box either way.
     Nz_global = args.Nz * world if args.scaling == 'weak' else args.Nz

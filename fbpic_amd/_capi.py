@@ -74,6 +74,7 @@ _SIGNATURES = {
     'fb_zfft': (I, [I, L, P, L, P, L, I, P]),
     'fb_zfft_pm_to_rt': (I, [I, L, P, L, P, L, I, P]),
     'fb_zfft_from_records': (I, [I, I, I, P, L, I, P, L, P]),
+    'fb_zfft_from_records_consume': (I, [I, I, I, P, L, I, P, L, P]),
     'fb_fft_generic_supported': (I, [I]),
     'fb_fft_generic': (I, [I, L, P, L, P, L, P, L, I, P]),
     'fb_hankel': (I, [I, _PP, L, _PP, L, _PP, D, I, I, P]),

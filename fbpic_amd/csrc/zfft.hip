@@ -205,7 +205,8 @@ typedef ZCfg<2304, 2, 192, 6, 6, 8, 8, 1> ZC2304;
 template <class Z, int R, int NS, bool FWD, bool FIRST, bool LAST>
 __device__ __forceinline__ void zf_pass(cx *lds, const cx *__restrict__ tw,
         const cx *gin, long in_stride, cx *gout, long out_stride,
-        int c, int jj0, bool col_ok, double scale, int pm = 0, const cx *gin2 = nullptr)
+        int c, int jj0, bool col_ok, double scale, int pm = 0, const cx *gin2 = nullptr,
+        cx *gclear = nullptr)
 {
     constexpr int N = Z::N, C = Z::C, NB = Z::E / R, JSTEP = Z::NTHR / C;
     constexpr int NR = N / R;
@@ -220,6 +221,9 @@ __device__ __forceinline__ void zf_pass(cx *lds, const cx *__restrict__ tw,
             const int row = jj + t * NR;
             if (FIRST) {
                 cx a = col_ok ? gin[(long)row * in_stride] : make_double2(0., 0.);
+                // consume-and-clear (fb_zfft_from_records_consume): every element of the record
+                // array is read by exactly one lane of one workgroup
+                if (gclear && col_ok) gclear[(long)row * in_stride] = make_double2(0., 0.);
                 if (pm != 0 && col_ok) {
                     const cx o = gin2[(long)row * in_stride];
                     if (pm == 1) a = cadd(a, o);                               // p + m
@@ -266,7 +270,7 @@ __device__ __forceinline__ void zf_pass(cx *lds, const cx *__restrict__ tw,
 template <class Z, bool FWD>
 __global__ __launch_bounds__(Z::NTHR) void k_zfft(long ncols, const cx *in, long in_stride,
         cx *out, long out_stride, const cx *__restrict__ tw, double scale, int ntiles, int pm_Nr,
-        int aos_Nr, int aos_rec)
+        int aos_Nr, int aos_rec, int aos_clear)
 {
     constexpr int C = Z::C;
     extern __shared__ double2 zf_lds[];
@@ -301,7 +305,8 @@ __global__ __launch_bounds__(Z::NTHR) void k_zfft(long ncols, const cx *in, long
     constexpr int R0 = Z::R0, R1 = Z::R1, R2 = Z::R2, R3 = Z::R3, R4 = Z::R4;
     constexpr int NPASS = (R1 == 1) ? 1 : (R2 == 1) ? 2 : (R3 == 1) ? 3 : (R4 == 1) ? 4 : 5;
 #define ZF_ARGS zf_lds, tw, gin, in_stride, gout, out_stride, c, jj0, col_ok, scale
-    zf_pass<Z, R0, 1, FWD, true, NPASS == 1>(ZF_ARGS, pm, gin2);
+    zf_pass<Z, R0, 1, FWD, true, NPASS == 1>(ZF_ARGS, pm, gin2,
+                                             (aos_clear && aos_Nr > 0) ? const_cast<cx *>(gin) : nullptr);
     if constexpr (NPASS >= 2) zf_pass<Z, R1, R0, FWD, false, NPASS == 2>(ZF_ARGS);
     if constexpr (NPASS >= 3) zf_pass<Z, R2, R0 * R1, FWD, false, NPASS == 3>(ZF_ARGS);
     if constexpr (NPASS >= 4) zf_pass<Z, R3, R0 * R1 * R2, FWD, false, NPASS == 4>(ZF_ARGS);
@@ -336,7 +341,8 @@ static int get_twiddles(int N, const cx **out)
 
 template <class Z>
 static int zfft_launch(long ncols, const cx *in, long is, cx *out, long os, int direction,
-                       const cx *tw, hipStream_t s, int pm_Nr = 0, int aos_Nr = 0, int aos_rec = 0)
+                       const cx *tw, hipStream_t s, int pm_Nr = 0, int aos_Nr = 0, int aos_rec = 0,
+                       int aos_clear = 0)
 {
     constexpr int N = Z::N, C = Z::C;
     const int ntiles = (int)((ncols + C - 1) / C);
@@ -354,10 +360,10 @@ static int zfft_launch(long ncols, const cx *in, long is, cx *out, long os, int 
     const int nblocks = (ntiles + 7) & ~7;             // multiple of 8 for the XCD mapping
     if (direction < 0)
         hipLaunchKernelGGL((k_zfft<Z, true>), dim3(nblocks), dim3(Z::NTHR), lds_bytes, s, ncols, in,
-                           is, out, os, tw, 1.0, ntiles, pm_Nr, aos_Nr, aos_rec);
+                           is, out, os, tw, 1.0, ntiles, pm_Nr, aos_Nr, aos_rec, aos_clear);
     else
         hipLaunchKernelGGL((k_zfft<Z, false>), dim3(nblocks), dim3(Z::NTHR), lds_bytes, s, ncols, in,
-                           is, out, os, tw, 1.0 / (double)N, ntiles, pm_Nr, aos_Nr, aos_rec);
+                           is, out, os, tw, 1.0 / (double)N, ntiles, pm_Nr, aos_Nr, aos_rec, aos_clear);
     return check(hipGetLastError(), "fb_zfft");
 }
 
@@ -593,7 +599,7 @@ extern "C" int fb_zfft_supported(int Nz)
 
 static int zfft_dispatch(const char *who, int Nz, long ncols, const void *in, long in_stride, void *out,
                          long out_stride, int direction, int pm_Nr, void *stream, int aos_Nr = 0,
-                         int aos_rec = 0);
+                         int aos_rec = 0, int aos_clear = 0);
 
 extern "C" int fb_zfft_from_records(int Nz, int nfields, int Nr, const void *in, long in_stride,
                                     int record, void *out, long out_stride, void *stream)
@@ -605,6 +611,18 @@ extern "C" int fb_zfft_from_records(int Nz, int nfields, int Nr, const void *in,
     if (in == out) { set_error("fb_zfft_from_records", "out of place only"); return -1; }
     return zfft_dispatch("fb_zfft_from_records", Nz, (long)nfields * Nr, in, in_stride, out, out_stride,
                          -1, 0, stream, Nr, record);
+}
+
+extern "C" int fb_zfft_from_records_consume(int Nz, int nfields, int Nr, void *in, long in_stride,
+                                            int record, void *out, long out_stride, void *stream)
+{
+    if (nfields != record || Nr <= 0) {
+        set_error("fb_zfft_from_records_consume", "the whole record must be transformed (nfields == record)");
+        return -1;
+    }
+    if (in == out) { set_error("fb_zfft_from_records_consume", "out of place only"); return -1; }
+    return zfft_dispatch("fb_zfft_from_records_consume", Nz, (long)nfields * Nr, in, in_stride, out,
+                         out_stride, -1, 0, stream, Nr, record, 1);
 }
 
 extern "C" int fb_zfft_pm_to_rt(int Nz, long ncols, const void *in, long in_stride, void *out,
@@ -625,7 +643,8 @@ extern "C" int fb_zfft(int Nz, long ncols, const void *in, long in_stride, void 
 }
 
 static int zfft_dispatch(const char *who, int Nz, long ncols, const void *in, long in_stride, void *out,
-                         long out_stride, int direction, int pm_Nr, void *stream, int aos_Nr, int aos_rec)
+                         long out_stride, int direction, int pm_Nr, void *stream, int aos_Nr, int aos_rec,
+                         int aos_clear)
 {
     if (!fb_zfft_supported(Nz)) {
         set_error(who, "unsupported Nz (2^k in [64, 4096] or 9 * 2^k in [576, 2304])");
@@ -639,7 +658,7 @@ static int zfft_dispatch(const char *who, int Nz, long ncols, const void *in, lo
     hipStream_t s = (hipStream_t)stream;
     const cx *a = (const cx *)in;
     cx *b = (cx *)out;
-#define ZF_CASE(n, Z) case n: return zfft_launch<Z>(ncols, a, in_stride, b, out_stride, direction, tw, s, pm_Nr, aos_Nr, aos_rec)
+#define ZF_CASE(n, Z) case n: return zfft_launch<Z>(ncols, a, in_stride, b, out_stride, direction, tw, s, pm_Nr, aos_Nr, aos_rec, aos_clear)
     switch (Nz) {
     ZF_CASE(64, ZC64); ZF_CASE(128, ZC128); ZF_CASE(256, ZC256); ZF_CASE(512, ZC512);
     ZF_CASE(1024, ZC1024); ZF_CASE(2048, ZC2048); ZF_CASE(4096, ZC4096);

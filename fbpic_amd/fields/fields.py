@@ -264,10 +264,18 @@ class Fields(object):
             rs = self.Nr * rec + SLAB_PAD
             base = t.zeros(self.Nz * rs, dtype=t.complex128, device=_capi.require_device())
             self.d_src_rec = base.as_strided((self.Nz, self.Nr, rec), (rs, rec, 1))
+            self._records_clean = True
         return self.d_src_rec
 
     def erase_source_records(self):
+        """Zero the records for a new deposition; a no-op when the transform that consumed
+        them left them zeroed (fb_zfft_from_records_consume).  They count as dirty from here
+        on: the caller is about to deposit into them."""
         S = self.source_records()
+        if self._records_clean:
+            self._records_clean = False
+            return
+        self._records_clean = False
         row = _capi.torch().as_strided(S, (self.Nz, self.Nr * S.shape[2]), (S.stride(0), 1))
         _capi.check(_capi.lib().fb_erase(1, _capi.ptr_array([row]), S.stride(0), self.Nz,
                                          self.Nr * S.shape[2], _capi.stream()), 'fb_erase')
@@ -285,6 +293,7 @@ class Fields(object):
         when something other than interp2spect_J_and_rho_next wants them)."""
         S, Nm = self.source_records(), self.Nm
         self.d_interp[:, 6 * Nm:10 * Nm, :].copy_(S.permute(0, 2, 1))
+        self._records_clean = False
 
     def interp2spect_J_and_rho_next(self, fuse_filter=False, from_records=False):
         """interp2spect('J') and interp2spect('rho_next') of freshly deposited (un-normalised)
@@ -298,9 +307,10 @@ class Fields(object):
         if from_records and lib.fb_zfft_supported(Nz):
             # the z-FFT gathers its columns straight from the deposition's records
             S = self.source_records()
-            _capi.check(lib.fb_zfft_from_records(Nz, nf, Nr, S.data_ptr(), S.stride(0), S.shape[2],
-                                                 self.d_scratch[:, 0, :].data_ptr(),
-                                                 self.d_scratch.stride(0), st), 'fb_zfft_from_records')
+            _capi.check(lib.fb_zfft_from_records_consume(
+                Nz, nf, Nr, S.data_ptr(), S.stride(0), S.shape[2], self.d_scratch[:, 0, :].data_ptr(),
+                self.d_scratch.stride(0), st), 'fb_zfft_from_records_consume')
+            self._records_clean = True
         else:
             if from_records:
                 self.unpack_source_records()

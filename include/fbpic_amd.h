@@ -445,6 +445,12 @@ int fb_zfft_pm_to_rt(int Nz, long ncols, const void *in, long in_stride, void *o
  * columns.  Out of place only; lengths as fb_zfft. */
 int fb_zfft_from_records(int Nz, int nfields, int Nr, const void *in, long in_stride, int record,
                          void *out, long out_stride, void *stream);
+/* fb_zfft_from_records that also zeroes the record array it has read (nfields == record: every
+ * element is read by exactly one lane): the array is then ready for the next step's deposition
+ * and the erase launch before it (fields/fields.py erase -> interpolation_grid.py:236-263)
+ * disappears. */
+int fb_zfft_from_records_consume(int Nz, int nfields, int Nr, void *in, long in_stride, int record,
+                                 void *out, long out_stride, void *stream);
 
 /* Self-contained fallback for every other length whose prime factors are <= 31 (rocFFT of
  * ROCm 7.2 refuses some, e.g. Nz = 4416): one Stockham pass per launch through global
