@@ -49,6 +49,9 @@ WORK = {
     # fused gather+push_p+push_x: 56 B read + 56 B written (+ 48 B when E,B are stored for an
     # observer: last iteration of a step() call), union rule of SURVEY.md 8d
     'fb_gather_push': ('hbm', lambda a: (160.0 if a[19] is not None else 112.0) * a[2]),
+    # ... + cell and rank of the next sort written (8 B): 120 B, the first pass of the two-pass
+    # step of SURVEY.md 8d
+    'fb_gather_push_rank_next': ('hbm', lambda a: (168.0 if a[19] is not None else 120.0) * a[2]),
     'fb_deposit_rho': ('hbm', lambda a: 32.0 * a[2]),
     'fb_deposit_J': ('hbm', lambda a: 64.0 * a[2]),
     # J deposition + cell/rank of the pushed position for the next sort: 64 B read + 8 B written
@@ -59,6 +62,9 @@ WORK = {
     # destination-ordered push_x + sort + rho deposition: permutation (4 B) + 8 arrays read,
     # 8 arrays written (union rule; building the permutation is sort overhead, as above)
     'fb_push_x_sort_deposit_rho': ('hbm', lambda a: 132.0 * a[0]),
+    # the same pass with the J deposition riding along: same bytes (the second pass of the
+    # two-pass step: 4 B permutation + 8 arrays read, 8 arrays written)
+    'fb_push_x_sort_deposit_J_rho': ('hbm', lambda a: 132.0 * a[0]),
     'fb_zfft': ('hbm', lambda a: 32.0 * a[0] * a[1]),
     'fb_cell_index': ('hbm', lambda a: 32.0 * a[0]),
     'fb_sort_by_cell': ('hbm', lambda a: 16.0 * a[0]),          # one read+write of (key, value)
@@ -136,8 +142,8 @@ def bench_c3(args, torch, world, rank):
 
 
 SEQUENCE_NOTE = {
-    False: 'fused MI355X sequence: gather+push_p+push_x one pass, J deposit pre-ranks the sort, '
-           'push_x+sort+rho deposit one pass; sanctioned skips inside the timed region: rho_prev '
+    False: 'two-pass MI355X sequence: gather+push_p+push_x(+rank for the sort) one pass, '
+           'J deposit+push_x+sort+rho deposit one pass; sanctioned skips inside the timed region: rho_prev '
            're-deposit after the first step of a call, identity iFFT/FFT of E,B on the single '
            'periodic domain, gathered E,B stored on the last step only',
     True: "reference sequence (fbpic/main.py:346-586): every operation its own launch, rho_prev "
@@ -346,7 +352,7 @@ def roofline(kern, ceil=None):
     # of the longest entry point, it is the one described: it is the kernel the target names
     # (">= 70 % of the HBM roofline on gather/push"), and the line stays comparable run to run.
     # All three are in `kernels` either way.
-    for n in ('fb_gather_push', 'fb_gather'):
+    for n in ('fb_gather_push_rank_next', 'fb_gather_push', 'fb_gather'):
         if n in table and 'frac' in table[n] and \
                 table[n]['total_ms'] >= 0.95 * table[cand[0]]['total_ms']:
             dom = n
@@ -378,6 +384,8 @@ def roofline(kern, ceil=None):
 # entry point -> substrings identifying its dominant device kernel in the rocprofv3 summaries
 _KERNEL_OF = {
     'fb_gather_push': ('k_gather<',), 'fb_gather': ('k_gather<',),
+    'fb_gather_push_rank_next': ('k_gather<',),
+    'fb_push_x_sort_deposit_J_rho': ('k_perm_deposit_J_rho<',),
     'fb_deposit_J_rank_next': ('k_deposit<', ', 3, ', 'true, true>'),
     'fb_deposit_J': ('k_deposit<', ', 3, '), 'fb_deposit_rho': ('k_deposit<', ', 1, '),
     'fb_push_x_bin_sort_particles': ('k_scatter<true>',), 'fb_push_x': ('k_push_x',),

@@ -114,7 +114,11 @@ struct DepLayout {
     static constexpr int S = ShapeTraits<SHAPE>::S;
     static constexpr int NPT = S * S;                 // nodes of one cell
     static constexpr int RG = NPT / 4;                // row groups of 4 nodes
-    static constexpr int NW = 2 * NPT;                // weights: [mode0 | modes>=1][jz][jr]
+    // shape-factor rows of the panel: Sz[jz] | Sr of mode 0 [jr] | Sr of modes >= 1 [jr]; the
+    // node weights Sz[jz] * Sr[jr] are formed when the matrix operand is read (12 rows instead
+    // of 2 x 16 products for the cubic shape: the panel of J, Nm = 4 shrinks from 27.5 to
+    // 17 KB per wave and twice as many waves fit a CU; 6 instead of 8 for the linear shape)
+    static constexpr int NW = 3 * S;
     static constexpr int R1 = Z0 ? NCOMP : 2 * NCOMP; // amplitude rows of the first mode
     static constexpr int T1 = (R1 + 3) / 4;
     static constexpr int RH = (NM - 1) * NCOMP * 2;   // rows of the other modes
@@ -353,12 +357,11 @@ struct DepEngine {
             if constexpr (NEED_W0) shape_r<SHAPE>(r_cell, beta0[ir_ruy], Sr0);
             if constexpr (NEED_WH) shape_r<SHAPE>(r_cell, betah[ir_ruy], Srh);
 #pragma unroll
-            for (int jz = 0; jz < S; jz++)
-#pragma unroll
-                for (int jr = 0; jr < S; jr++) {
-                    if constexpr (NEED_W0) Wl[(jz * S + jr) * DEP_PAD + lane] = Sz[jz] * Sr0[jr];
-                    if constexpr (NEED_WH) Wl[(NPT + jz * S + jr) * DEP_PAD + lane] = Sz[jz] * Srh[jr];
-                }
+            for (int j = 0; j < S; j++) {
+                Wl[j * DEP_PAD + lane] = Sz[j];
+                if constexpr (NEED_W0) Wl[(S + j) * DEP_PAD + lane] = Sr0[j];
+                if constexpr (NEED_WH) Wl[(2 * S + j) * DEP_PAD + lane] = Srh[j];
+            }
             // number of stencil columns below the axis: index + (icr - H) < 0
             my_nb = H - icr;
         } else {
@@ -412,17 +415,22 @@ struct DepEngine {
             int e = rest ? p + 1 + __builtin_ctzll(rest) : cnt;
             if (e > cnt) e = cnt;
             const int g1 = (e - 1) >> 4;
-            // weight rows fed by this lane: node rg*4 + (its logical column); for the linear
-            // shape jl = jz*2 + jr and only the jr bit rotates
+            // node fed by this lane in row group rg: rg*4 + (its logical column).  Linear shape:
+            // jl = jz*2 + jr and only the jr bit rotates; cubic: jz = rg, jr = (jl - off) mod 4
             const int wrow = (S == 2) ? (jl ^ off) : ((jl - off) & 3);
+            const int jr_row = (S == 2) ? (wrow & 1) : wrow;
             for (int g = p >> 4; g <= g1; g++) {
                 const int pi = 16 * g + poff;
                 const bool in = (pi >= p) && (pi < e);
                 double w0[RG], wh[RG];
+                double sr0 = 0., srh = 0.;
+                if constexpr (NEED_W0) { const double v = Wl[(S + jr_row) * DEP_PAD + pi]; sr0 = in ? v : 0.; }
+                if constexpr (NEED_WH) { const double v = Wl[(2 * S + jr_row) * DEP_PAD + pi]; srh = in ? v : 0.; }
 #pragma unroll
                 for (int rg = 0; rg < RG; rg++) {
-                    if constexpr (NEED_W0) { const double v = Wl[(rg * 4 + wrow) * DEP_PAD + pi]; w0[rg] = in ? v : 0.; }
-                    if constexpr (NEED_WH) { const double v = Wl[(NPT + rg * 4 + wrow) * DEP_PAD + pi]; wh[rg] = in ? v : 0.; }
+                    const double sz = Wl[((S == 2) ? (wrow >> 1) : rg) * DEP_PAD + pi];
+                    if constexpr (NEED_W0) w0[rg] = sz * sr0;
+                    if constexpr (NEED_WH) wh[rg] = sz * srh;
                 }
 #pragma unroll
                 for (int t = 0; t < NT; t++) {
@@ -737,6 +745,8 @@ static int launch_modes(int Nm, long n, const double *x, const double *y, const 
     while (m0 < Nm) {
         int left = Nm - m0, r;
 #define ARGS n, x, y, z, w, q, ux, uy, uz, ig, c, invdz, zmin, Nz, invdr, rmin, Nr, G, rs, m0, b0, bh, nflush, RK, s, PM
+        // (splitting a cubic 4-mode J launch into 2 + 2 or 1 + 1 + 1 + 1 modes for more waves per
+        // SIMD changes nothing: 3.38 / 3.44 / 3.64 ms at 2048 x 512, 16 ppc)
         if (left >= 4) { r = launch_one<SHAPE, NCOMP, 4>(ARGS); m0 += 4; }
         else if (left == 3) { r = launch_one<SHAPE, NCOMP, 3>(ARGS); m0 += 3; }
         else if (left == 2) { r = launch_one<SHAPE, NCOMP, 2>(ARGS); m0 += 2; }
