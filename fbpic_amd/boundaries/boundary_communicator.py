@@ -152,10 +152,15 @@ class BoundaryCommunicator(object):
         self.d_left_damp = None
         self.d_right_damp = None
         self._guard_bufs = {}
-        # transport of device buffers between ranks: 'torch' = torch.distributed point-to-point
-        # (backend nccl = RCCL; gloo stages through the host), 'rccl' = fb_exchange, RCCL
-        # send/recv inside the library on the compute stream (no host synchronisation)
-        self.transport = os.environ.get('FBPIC_AMD_TRANSPORT', 'torch')
+        # transport of device buffers between ranks: 'rccl' = fb_exchange, RCCL send/recv inside
+        # the library on the compute stream (one ctypes call per exchange, no host
+        # synchronisation; default when torch.distributed runs on the nccl backend, i.e. one GPU
+        # per rank), 'torch' = torch.distributed point-to-point (batch_isend_irecv; the only
+        # choice under gloo, which stages through the host)
+        default = 'torch'
+        if self.size > 1 and dist.is_initialized() and dist.get_backend() == 'nccl':
+            default = 'rccl'
+        self.transport = os.environ.get('FBPIC_AMD_TRANSPORT', default)
         self._rccl_comm = None
 
     # ---------------------------------------------------------------- decomposition

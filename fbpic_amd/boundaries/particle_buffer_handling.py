@@ -36,29 +36,26 @@ def _prime_device_ops(t, dev):
     t.tensor([3], dtype=t.int64, device=dev).item()
 
 
-def _select_leaving(t, species, fld, ng, zbox_min, zbox_max):
-    """Index description of the particles that leave to the left / stay / leave to the right,
-    by the rule of the reference's CPU path (particle_buffer_handling.py:58-172): left if
-    z < zbox_min, right if z > zbox_max.  Returns a function `pick(array) -> (left, stay,
-    right)` and the flag `nothing_leaves`.
+def _leaving_indices(t, species, fld, ng, zbox_min, zbox_max):
+    """int64 index tensors of the particles that leave to the left / to the right, by the rule
+    of the reference's CPU path (particle_buffer_handling.py:58-172): left if z < zbox_min,
+    right if z > zbox_max.
 
     Cell-sorted device arrays: only the particles of the cell rows next to the two box edges
     can be on either side; everything before / after those rows is known from the per-cell
-    prefix sum (two host reads in all), so the three boolean selections of the whole arrays
-    (130 us per step at the headline size, amortised) shrink to two selections of a few cell
-    rows.  Unlike the cell-based cut of the reference's GPU path (:177-236), which hands a
-    particle over half a cell late, the result is identical to the CPU rule on every rank."""
+    prefix sum, so the comparison runs on a few cell rows instead of the whole arrays.
+    Unlike the cell-based cut of the reference's GPU path (:177-236), which hands a particle
+    over half a cell late, the result is identical to the CPU rule on every rank."""
     z = species.z
     n = species.Ntot
+    dev = z.device
     fast = (z.is_cuda and getattr(species, 'use_bin_sort', False) and n > 0)
     if not fast:
-        sel_l = z < zbox_min
-        sel_r = z > zbox_max
-        stay = ~(sel_l | sel_r)
-        return (lambda a: (a[sel_l], a[stay], a[sel_r])), False
+        return (t.nonzero(z < zbox_min).reshape(-1), t.nonzero(z > zbox_max).reshape(-1))
     if not species.sorted:
         species.sort_particles(fld=fld)
         species.sorted = True
+        z = species.z
     Nz, Nr = fld.Nz, fld.Nr
     shift = species.prefix_sum_shift            # window moves since the sort
     ps = species.prefix_sum
@@ -72,21 +69,25 @@ def _select_leaving(t, species, fld, ng, zbox_min, zbox_max):
     offs = t.stack([ps[i] for i in idx]).tolist()
     o = [0 if r == 0 else int(v) for r, v in zip(rows, offs)]
     o0, o1, o2, o3 = o[0], max(o[1], o[0]), max(o[2], o[1], o[0]), max(o[3], o[2], o[1], o[0])
-    go_l = z[o0:o1] < zbox_min
-    go_r = z[o2:o3] > zbox_max
-    n_l, n_r = t.stack((go_l.sum(), go_r.sum())).tolist()
-    nothing_leaves = (o0 == 0 and o3 == n and n_l == 0 and n_r == 0)
-    keep_l, keep_r = ~go_l, ~go_r
+    left = [t.arange(0, o0, device=dev)] if o0 > 0 else []
+    left.append(o0 + t.nonzero(z[o0:o1] < zbox_min).reshape(-1))
+    right = [o2 + t.nonzero(z[o2:o3] > zbox_max).reshape(-1)]
+    if o3 < n:
+        right.append(t.arange(o3, n, device=dev))
+    return (t.cat(left) if len(left) > 1 else left[0], t.cat(right) if len(right) > 1 else right[0])
 
-    def pick(a):
-        left = t.cat((a[:o0], a[o0:o1][go_l])) if n_l else a[:o0]
-        right = t.cat((a[o2:o3][go_r], a[o3:])) if n_r else a[o3:]
-        if n_l or n_r:
-            stay = t.cat((a[o0:o1][keep_l], a[o1:o2], a[o2:o3][keep_r]))
-        else:
-            stay = a[o0:o3]
-        return left, stay, right
-    return pick, nothing_leaves
+
+def _resized(t, a, n_keep, n_new):
+    """Length-n_new tensor holding a[:n_keep]: a view of a's own storage when that is large
+    enough (the particle arrays are kept with some headroom), else a new allocation with
+    ~6 % of headroom."""
+    cap = a.untyped_storage().nbytes() // a.element_size() - a.storage_offset()
+    if cap >= n_new:
+        return t.empty(0, dtype=a.dtype, device=a.device).set_(a.untyped_storage(), a.storage_offset(),
+                                                               (n_new,))
+    b = t.empty(n_new + n_new // 16 + 1024, dtype=a.dtype, device=a.device)[:n_new]
+    b[:n_keep] = a[:n_keep]
+    return b
 
 
 def exchange_particles_between_ranks(comm, species, fld, time):
@@ -97,16 +98,16 @@ def exchange_particles_between_ranks(comm, species, fld, time):
     zbox_min = g0.zmin + ng * g0.dz
     zbox_max = g0.zmax - ng * g0.dz
     dev = species.z.device
-    pick, nothing_leaves = _select_leaving(t, species, fld, ng, zbox_min, zbox_max)
+    idx_l, idx_r = _leaving_indices(t, species, fld, ng, zbox_min, zbox_max)
     arrs = [getattr(species, k) for k in _STATE]
-    parts = [pick(a) for a in arrs]
+    n = species.Ntot
 
-    def pack(side, proc):
-        if proc is None:
+    def pack(idx, proc):
+        if proc is None or idx.numel() == 0:
             return t.empty((len(_STATE), 0), dtype=t.float64, device=dev)
-        return t.stack([p[side] for p in parts]).contiguous()
-    send_l = pack(0, comm.left_proc)
-    send_r = pack(2, comm.right_proc)
+        return t.stack([a.index_select(0, idx) for a in arrs]).contiguous()
+    send_l = pack(idx_l, comm.left_proc)
+    send_r = pack(idx_r, comm.right_proc)
     # 1) counts, 2) payloads (boundary_communicator.py:782-801)
     n_sl = t.tensor([send_l.shape[1]], dtype=t.int64, device=dev)
     n_sr = t.tensor([send_r.shape[1]], dtype=t.int64, device=dev)
@@ -130,12 +131,41 @@ def exchange_particles_between_ranks(comm, species, fld, time):
         recv_r[2] += Ltot
     if comm.left_proc == comm.size - 1 and n_rl:
         recv_l[2] -= Ltot
-    if nothing_leaves and n_rl == 0 and n_rr == 0:
+    n_leave = int(idx_l.numel() + idx_r.numel())
+    if n_leave == 0 and n_rl == 0 and n_rr == 0:
         return                       # nobody crossed a boundary: arrays (and their sort) stay
+    # Compaction in O(number of movers): the holes left in the first n - n_leave slots are filled
+    # with the survivors of the last n_leave slots, the arrivals are appended; nothing else is
+    # copied (the reference rebuilds every array as from-left | stayed | from-right, :289-417;
+    # only the order of the particles differs, and they are re-sorted before the next deposit)
+    m = n - n_leave
+    n_new = m + n_rl + n_rr
+    src = dst = None
+    if n_leave:
+        leave = t.cat((idx_l, idx_r))
+        in_tail = leave >= m
+        tail_free = t.ones(n - m, dtype=t.bool, device=dev)
+        tail_free[leave[in_tail] - m] = False
+        src = m + t.nonzero(tail_free).reshape(-1)       # survivors sitting in the tail
+        dst = leave[~in_tail]                             # holes in the head
     for i, k in enumerate(_STATE):
-        setattr(species, k, t.cat((recv_l[i], parts[i][1], recv_r[i])).contiguous())
-    species.Ntot = int(species.x.shape[0])
+        a = arrs[i]
+        if src is not None and src.numel():
+            a[dst] = a.index_select(0, src)
+        b = _resized(t, a, m, n_new)
+        if n_rl:
+            b[m:m + n_rl] = recv_l[i]
+        if n_rr:
+            b[m + n_rl:n_new] = recv_r[i]
+        setattr(species, k, b)
+    species.Ntot = n_new
     for k in _FIELDS:
-        setattr(species, k, t.zeros(species.Ntot, dtype=t.float64, device=dev))
+        f = getattr(species, k, None)
+        if hasattr(f, 'untyped_storage') and f.device == dev:
+            f = _resized(t, f, 0, n_new)
+        else:
+            f = t.empty(n_new, dtype=t.float64, device=dev)
+        f.zero_()
+        setattr(species, k, f)
     species.sorted = False
     species.on_particle_number_changed()

@@ -24,6 +24,10 @@ class FakeDist:
     get_world_size = staticmethod(lambda: 2)
     get_backend = staticmethod(lambda: 'nccl')
 
+    @staticmethod
+    def all_gather_object(out, obj):        # the (host, gpu) uniqueness check of the communicator
+        out[:] = [(obj[0], i) for i in range(len(out))]
+
 
 def main():
     ap = argparse.ArgumentParser()
