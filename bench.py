@@ -136,16 +136,20 @@ def bench_c3(args, torch, world, rank):
     }
     if kern:
         ceil = measured_ceilings(torch)
-        out['roofline'], out['kernels'] = roofline(kern, ceil)
+        out['roofline'], out['kernels'] = roofline(kern, ceil, False)
         out['measured_ceilings'] = ceil
     print(json.dumps(out))
 
 
+_TWO_PASS = ('two-pass MI355X sequence: gather+push_p+push_x(+rank for the sort) one pass, '
+             'J deposit+push_x+sort+rho deposit one pass; sanctioned skips inside the timed region: rho_prev '
+             're-deposit after the first step of a call, ')
 SEQUENCE_NOTE = {
-    False: 'two-pass MI355X sequence: gather+push_p+push_x(+rank for the sort) one pass, '
-           'J deposit+push_x+sort+rho deposit one pass; sanctioned skips inside the timed region: rho_prev '
-           're-deposit after the first step of a call, identity iFFT/FFT of E,B on the single '
-           'periodic domain, gathered E,B stored on the last step only',
+    False: _TWO_PASS + 'identity iFFT/FFT of E,B on the single periodic domain, gathered E,B '
+                       'stored on the last step only',
+    # z-slab decomposition: the guard exchange of E,B needs the interpolation grid each step
+    'decomposed': _TWO_PASS + 'gathered E,B stored on the last step only (the E,B round trip '
+                              'through the interpolation grid is NOT skipped: its guard cells are exchanged)',
     True: "reference sequence (fbpic/main.py:346-586): every operation its own launch, rho_prev "
           "re-deposited every step, E,B stored by every gather",
 }
@@ -280,13 +284,13 @@ def main():
                                'standard PSATD n_order=%d, curl-free correction, filtered; %s'
                                % (config_name(args, ppc, world), Nz_global, args.Nr, args.Nm,
                                   ppc[0] * ppc[1] * ppc[2], args.shape, n_order,
-                                  SEQUENCE_NOTE[bool(args.reference_sequence)]),
+                                  SEQUENCE_NOTE[True if args.reference_sequence else ('decomposed' if world > 1 else False)]),
                    'particles': n_total, 'parallelism': 'z-slab x%d' % world,
                    'sequence': 'reference' if args.reference_sequence else 'fused'},
     }
     if kern:
         ceil = measured_ceilings(torch)
-        out['roofline'], out['kernels'] = roofline(kern, ceil)
+        out['roofline'], out['kernels'] = roofline(kern, ceil, config_name(args, ppc, world) == 'C2')
         out['measured_ceilings'] = ceil
     if cpu_base:
         out['cpu_baseline'] = cpu_base
@@ -322,7 +326,7 @@ def measured_ceilings(torch):
     return {'triad_GBs': 3 * 8 * n / t_triad / 1e9, 'dgemm_4096_TFLOPs': 2. * m**3 / t_gemm / 1e12}
 
 
-def roofline(kern, ceil=None):
+def roofline(kern, ceil=None, profiled_workload=True):
     """Per entry point: launches, mean device ms, achieved GB/s or TFLOP/s; the roofline
     object describes the entry point with the largest total device time (gather+push when it
     is within 5 % of it)."""
@@ -347,11 +351,11 @@ def roofline(kern, ceil=None):
         table[name] = ent
     cand = sorted((n for n in table if 'frac' in table[n]), key=lambda n: -table[n]['total_ms'])
     dom = cand[0]
-    # gather+push, the J deposition and the sort take the same time to within the run-to-run
-    # and box-to-box noise (rocprofv3: 126 / 120 / 101-126 us).  When gather+push is within 5 %
-    # of the longest entry point, it is the one described: it is the kernel the target names
-    # (">= 70 % of the HBM roofline on gather/push"), and the line stays comparable run to run.
-    # All three are in `kernels` either way.
+    # When gather+push is within 5 % of the longest entry point (the unfused sequence: gather,
+    # J deposition and sort take the same time to within box-to-box noise), it is the one
+    # described: it is the kernel the target names (">= 70 % of the HBM roofline on
+    # gather/push"), and the line stays comparable run to run.  In the two-pass sequence the
+    # deposition pass is the longest and is the one described.  All are in `kernels` either way.
     for n in ('fb_gather_push_rank_next', 'fb_gather_push', 'fb_gather'):
         if n in table and 'frac' in table[n] and \
                 table[n]['total_ms'] >= 0.95 * table[cand[0]]['total_ms']:
@@ -363,7 +367,8 @@ def roofline(kern, ceil=None):
             'mean_launch_ms': d['mean_ms']}
     if 'frac_of_measured' in d:
         roof['frac_of_measured'] = d['frac_of_measured']
-    roof.update(pmc_traffic(dom))
+    if profiled_workload:   # the PMC passes under profiles/ are of the default (C2) command
+        roof.update(pmc_traffic(dom))
     # the Hankel GEMM (the MFMA-bound kernel of the path) next to it: all launches together
     hk = [table[n] for n in table if n.startswith('fb_hankel') and 'achieved' in table[n]]
     if hk:

@@ -19,21 +19,35 @@ _PRIMED = set()
 
 
 def _prime_device_ops(t, dev):
-    """Run the tensor operations of the hand-over once on a few dummy values.  The device code
-    of an operation is loaded the first time it runs (tens of ms); without this, that cost
-    lands on the first step in which a particle really crosses a boundary - typically
-    `exchange_period` steps into a run - instead of on the first (warm-up) step."""
+    """Rehearse the hand-over once on a few dummy values, through the same functions.  The
+    device code of a tensor operation is loaded the first time it runs (tens of ms each, 0.1 s
+    and more for the whole hand-over); without this, that cost lands on the first step in which
+    particles really cross a boundary - `exchange_period` steps into a run, inside whatever is
+    being timed - instead of on the first (warm-up) step."""
     if dev in _PRIMED or dev.type != 'cuda':
         return
     _PRIMED.add(dev)
-    a = t.arange(16, dtype=t.float64, device=dev)
-    b = t.stack([a[2:5], a[3:6]]).contiguous()
-    c = t.cat((b[0], a[1:9], b[1])).contiguous()
-    b[1] += 1.
-    m = a > 3.
-    t.cat((a[m], c[~m[:14]])).sum().item()
-    t.zeros(4, dtype=t.float64, device=dev)
-    t.tensor([3], dtype=t.int64, device=dev).item()
+    n = 48
+    arrs = [t.arange(n, dtype=t.float64, device=dev) + i for i in range(2)]
+    ps = t.arange(n, dtype=t.int32, device=dev)
+    offs = t.stack([ps[i] for i in (2, 5, 40, 44)]).tolist()
+    z = arrs[0]
+    idx_l = t.cat((t.arange(0, offs[0], device=dev),
+                   offs[0] + t.nonzero(z[offs[0]:offs[1]] < 4.).reshape(-1)))
+    idx_r = t.cat((offs[2] + t.nonzero(z[offs[2]:offs[3]] > 41.).reshape(-1),
+                   t.arange(offs[3], n, device=dev)))
+    send = t.stack([a.index_select(0, idx_l) for a in arrs]).contiguous()
+    cnt = t.tensor([send.shape[1]], dtype=t.int64, device=dev)
+    got = t.zeros(1, dtype=t.int64, device=dev)
+    got.copy_(cnt)
+    recv = t.empty((2, int(got.item())), dtype=t.float64, device=dev)
+    recv.copy_(send)
+    recv[1] += 1.
+    out, n_new = _compact_and_append(t, arrs, n, idx_l, idx_r, recv, recv[:, :2].contiguous())
+    f = _resized(t, out[0], 0, n_new)
+    f.zero_()
+    _resized(t, out[1], n_new, 4 * n)
+    float(out[1].sum().item())
 
 
 def _leaving_indices(t, species, fld, ng, zbox_min, zbox_max):
@@ -90,6 +104,40 @@ def _resized(t, a, n_keep, n_new):
     return b
 
 
+def _compact_and_append(t, arrs, n, idx_l, idx_r, recv_l, recv_r):
+    """Remove the particles idx_l, idx_r from the length-n arrays `arrs` and append the rows of
+    recv_l, recv_r (one row per array); returns (new arrays, new length).
+
+    Compaction in O(number of movers): the holes left in the first n - n_leave slots are filled
+    with the survivors of the last n_leave slots, the arrivals are appended; nothing else is
+    copied (the reference rebuilds every array as from-left | stayed | from-right, :289-417;
+    only the order of the particles differs, and they are re-sorted before the next deposit)."""
+    dev = arrs[0].device
+    n_rl, n_rr = recv_l.shape[1], recv_r.shape[1]
+    n_leave = int(idx_l.numel() + idx_r.numel())
+    m = n - n_leave
+    n_new = m + n_rl + n_rr
+    src = dst = None
+    if n_leave:
+        leave = t.cat((idx_l, idx_r))
+        in_tail = leave >= m
+        tail_free = t.ones(n - m, dtype=t.bool, device=dev)
+        tail_free[leave[in_tail] - m] = False
+        src = m + t.nonzero(tail_free).reshape(-1)       # survivors sitting in the tail
+        dst = leave[~in_tail]                             # holes in the head
+    out = []
+    for i, a in enumerate(arrs):
+        if src is not None and src.numel():
+            a[dst] = a.index_select(0, src)
+        b = _resized(t, a, m, n_new)
+        if n_rl:
+            b[m:m + n_rl] = recv_l[i]
+        if n_rr:
+            b[m + n_rl:n_new] = recv_r[i]
+        out.append(b)
+    return out, n_new
+
+
 def exchange_particles_between_ranks(comm, species, fld, time):
     t = _capi.torch()
     _prime_device_ops(t, species.z.device)
@@ -131,32 +179,10 @@ def exchange_particles_between_ranks(comm, species, fld, time):
         recv_r[2] += Ltot
     if comm.left_proc == comm.size - 1 and n_rl:
         recv_l[2] -= Ltot
-    n_leave = int(idx_l.numel() + idx_r.numel())
-    if n_leave == 0 and n_rl == 0 and n_rr == 0:
+    if idx_l.numel() + idx_r.numel() == 0 and n_rl == 0 and n_rr == 0:
         return                       # nobody crossed a boundary: arrays (and their sort) stay
-    # Compaction in O(number of movers): the holes left in the first n - n_leave slots are filled
-    # with the survivors of the last n_leave slots, the arrivals are appended; nothing else is
-    # copied (the reference rebuilds every array as from-left | stayed | from-right, :289-417;
-    # only the order of the particles differs, and they are re-sorted before the next deposit)
-    m = n - n_leave
-    n_new = m + n_rl + n_rr
-    src = dst = None
-    if n_leave:
-        leave = t.cat((idx_l, idx_r))
-        in_tail = leave >= m
-        tail_free = t.ones(n - m, dtype=t.bool, device=dev)
-        tail_free[leave[in_tail] - m] = False
-        src = m + t.nonzero(tail_free).reshape(-1)       # survivors sitting in the tail
-        dst = leave[~in_tail]                             # holes in the head
-    for i, k in enumerate(_STATE):
-        a = arrs[i]
-        if src is not None and src.numel():
-            a[dst] = a.index_select(0, src)
-        b = _resized(t, a, m, n_new)
-        if n_rl:
-            b[m:m + n_rl] = recv_l[i]
-        if n_rr:
-            b[m + n_rl:n_new] = recv_r[i]
+    new_arrs, n_new = _compact_and_append(t, arrs, n, idx_l, idx_r, recv_l, recv_r)
+    for k, b in zip(_STATE, new_arrs):
         setattr(species, k, b)
     species.Ntot = n_new
     for k in _FIELDS:
