@@ -1,6 +1,7 @@
 // Particle kernels for gfx950: position/momentum push, periodic shift, field gather.
 // One lane = one (or two, 16-byte vectorised) macroparticle(s); structure-of-arrays
 // float64 streams, coalesced; grid-stride over a capped grid (256 CUs x 8 blocks).
+#include <cstdlib>
 #include "fb_common.h"
 
 namespace fb {
@@ -147,6 +148,74 @@ template <> struct GShape<FB_SHAPE_LINEAR> { static constexpr int S = 2, OFF = 0
 template <> struct GShape<FB_SHAPE_CUBIC> { static constexpr int S = 4, OFF = 1; };
 
 constexpr int G_NOKEY = -0x40000000;
+
+// Tail of a gather chunk, shared by the gather kernels: (r,t) -> (x,y) rotation of the gathered
+// fields, optional store, Vay push_p with the fields still in registers, push_x, and the cell /
+// rank of the position after the NEXT push_x (see PushArgs).
+__device__ __forceinline__ void gather_finish(bool act, long i, int lane, double xj, double yj,
+        double zj, double cs, double sn, const double *F,
+        double *__restrict__ Ex, double *__restrict__ Ey, double *__restrict__ Ez,
+        double *__restrict__ Bx, double *__restrict__ By, double *__restrict__ Bz,
+        const PushArgs &PA, double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
+        const double *pre = nullptr)     // ux, uy, uz, inv_gamma already in registers
+{
+    int rk_c = -1;
+    if (act) {
+        const double ex = cs * F[0] - sn * F[1], ey = sn * F[0] + cs * F[1], ez = F[2];
+        const double bx = cs * F[3] - sn * F[4], by = sn * F[3] + cs * F[4], bz = F[5];
+        if (Ex) { Ex[i] = ex; Ey[i] = ey; Ez[i] = ez; Bx[i] = bx; By[i] = by; Bz[i] = bz; }
+        if (PA.ux) {
+            // momenta are loaded here, not at the top of the chunk: 8 VGPRs less across the
+            // stencil phase; the other waves of the SIMD cover the latency (measured: -3 %)
+            double pux, puy, puz, pig;
+            if (pre) { pux = pre[0]; puy = pre[1]; puz = pre[2]; pig = pre[3]; }
+            else { pux = PA.ux[i]; puy = PA.uy[i]; puz = PA.uz[i]; pig = PA.ig[i]; }
+            vay(pux, puy, puz, pig, ex, ey, ez, bx, by, bz, PA.econst, PA.bconst);
+            PA.ux[i] = pux; PA.uy[i] = puy; PA.uz[i] = puz; PA.ig[i] = pig;
+            if (PA.chdt != 0.) {
+                // numba_methods.py:28-30 with push_x = push_y = push_z = 1
+                const double xp = xj + PA.chdt * pig * 1. * pux;
+                const double yp = yj + PA.chdt * pig * 1. * puy;
+                const double zp = zj + PA.chdt * pig * 1. * puz;
+                PA.x[i] = xp; PA.y[i] = yp; PA.z[i] = zp;
+                if (PA.RK.count) {
+                    // position after the coming push_x, cell as in k_cell_index / k_bin_rank
+                    const double xq = xp + PA.RK.chdt * pig * PA.RK.px * pux;
+                    const double yq = yp + PA.RK.chdt * pig * PA.RK.py * puy;
+                    const double zq = zp + PA.RK.chdt * pig * PA.RK.pz * puz;
+                    const double rq = sqrt(xq * xq + yq * yq);
+                    int ir_upper = (int)ceil(invdr * (rq - rmin) - 0.5);
+                    int iz_upper = (int)ceil(invdz * (zq - zmin) - 0.5);
+                    if (ir_upper > Nr) ir_upper = Nr;
+                    if (iz_upper < 0) iz_upper += Nz;
+                    else if (iz_upper > Nz - 1) iz_upper -= Nz;
+                    rk_c = ir_upper + iz_upper * (Nr + 1);
+                }
+            }
+        }
+    }
+    if (PA.RK.count) {
+        // one atomic per run of equal destination cells (wave-uniform branch)
+        const int prev = __shfl_up(rk_c, 1);
+        const bool rk_start = act && (lane == 0 || rk_c != prev);
+        const unsigned long long rstarts = __ballot(rk_start);
+        const int nact = __popcll(__ballot(act));
+        const unsigned long long below = rstarts & ((2ull << lane) - 1ull);
+        const int rk_run0 = 63 - __builtin_clzll(below | 1ull);
+        int rk_base = 0;
+        if (rk_start) {
+            const unsigned long long rest = (lane + 1 < 64) ? (rstarts >> (lane + 1)) : 0ull;
+            const int len = rest ? (__builtin_ctzll(rest) + 1) : (nact - lane);
+            rk_base = atomicAdd(PA.RK.count + rk_c, len);
+        }
+        rk_base = __shfl(rk_base, rk_run0);
+        if (act) {
+            PA.RK.cell[i] = rk_c;
+            PA.RK.rank[i] = rk_base + (lane - rk_run0);
+        }
+    }
+}
+
 
 // NMT > 0: number of modes known at compile time (mode loop unrolled, exptheta_0 = 1 folded
 // away); NMT = 0: run-time Nm.
@@ -406,59 +475,311 @@ __global__ __launch_bounds__(256) void k_gather(int Nm_arg, long n,
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
-        int rk_c = -1;
+        gather_finish(act, i, lane, xj, yj, zj, cs, sn, F, Ex, Ey, Ez, Bx, By, Bz, PA,
+                      invdz, zmin, Nz, invdr, rmin, Nr);
+    }
+}
+
+// ------------------------------------------------------------------ cubic gather on the matrix cores
+// With the cubic shape every particle reads 16 nodes x 6 Nm complex node values: evaluated lane by
+// lane from the LDS panel (k_gather) that is 384 ds_read_b128 per particle for Nm = 4, and the LDS
+// return path (128 B / clk / CU) is what bounds the kernel (SQ counters, 2048 x 512 x 64 ppc:
+// 371 M LDS instructions in 5.5 ms = the LDS pipe ~ 100 % busy, VALU 48 %).  The particles of a
+// segment (same stencil origin) all multiply the SAME node values, so the stencil sum is a small
+// matrix product per segment,
+//     D[column c][particle p] = sum over the 16 nodes of G[node][c] * W[node][p],
+// with c = the 12 Nm real columns (field, mode, re / im) and W = Sz[jz] * Sr[jr]: it runs on
+// v_mfma_f64_16x16x4_f64 with the node values as the A operand (read from the LDS panel, XOR-
+// swizzled so that neither the staging writes nor the fragment reads conflict) and the weights
+// of 16 particles as the B operand: 12 Nt ds_read_b64 per (segment, group of 16) instead of
+// 96 Nm ds_read_b128 per particle.
+// Measured (2048 x 512, 64 ppc, gather + push + rank): Nm = 4 5.56 -> 5.10 ms, Nm = 2 3.72 ->
+// 3.37 ms.  Not more, because fp64 MFMA and fp64 VALU instructions do NOT overlap on gfx950
+// (tools/overlap_probe.hip: one MFMA wave + one FMA wave per SIMD take the SUM of their solo
+// times; both run on the same DP units, and both peak at 78.6 TFLOP/s): the matrix form saves
+// the LDS traffic, not issue cycles - per chunk of 64 particles ~55 MFMAs x 64 cycles (groups
+// that straddle a segment boundary are multiplied twice) + ~1100 VALU instructions (phase 1,
+// staging, fold, push) = 8.0 k DP-pipe cycles, of which the kernel achieves 75 %.
+//
+// Column order: D row (l >> 4) + 4 r of tile t belongs to lane quarter a = l >> 4.  A quarter is
+// given all the columns of ONE azimuthal mode (Nm = 3, 4: 6 complex fields, 3 tiles) or of one
+// mode and one of E / B (Nm = 2: 3 complex fields, 2 tiles): lane (a, j) then holds, for particle
+// j of the group, fr / fi of its fields in its own accumulator registers, multiplies by its mode's
+// exptheta (staged per particle by phase 1) and the sum over the modes is two cross-quarter
+// shuffles.  The quarter that holds particle 16 g + j as its OWN particle keeps the result, so
+// the (r,t) -> (x,y) rotation, the push and the ranking continue lane = particle as in k_gather.
+// sums over the lane quarters (lanes 16 / 32 apart) with the gfx950 row swaps: no LDS round trip
+__device__ __forceinline__ double sum_xor32(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+__device__ __forceinline__ double sum_xor16(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+// value of the lane 16 further / nearer (quarter a <-> a ^ 1)
+__device__ __forceinline__ double other_xor16(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    // vdst keeps its even rows and receives the even rows of src in its odd rows; src the reverse
+    const bool odd = (threadIdx.x >> 4) & 1;
+    return odd ? __hiloint2double(b[0], a[0]) : __hiloint2double(b[1], a[1]);
+}
+
+template <int NMT> struct GMX {
+    static_assert(NMT >= 2 && NMT <= 4, "matrix-core gather: 2 <= Nm <= 4");
+    static constexpr int QM = (NMT == 2) ? 2 : 1;      // lane quarters per mode
+    static constexpr int FPL = 6 / QM;                 // complex fields per lane
+    static constexpr int NT = (2 * FPL + 3) / 4;       // 16-column tiles
+    static constexpr int RS = 48;                      // panel row stride (doubles): rows of a
+                                                       // fragment alternate between the bank halves
+    static constexpr int NV = 16 * 6 * NMT;            // complex node values of a segment
+    static constexpr int NVL = (NV + 63) / 64;         // ... per lane
+    static constexpr int WROWS = 8 + 2 * (NMT - 1);    // Sz[4] | Sr[4] | (er, ei) of modes 1..
+    static constexpr int WPAD = 65;
+    static constexpr int WAVE_DOUBLES = 16 * RS + WROWS * WPAD + 1;
+    // Panel element (node, column): the column is XOR-swizzled with node / 2 so that both access
+    // patterns are free of bank conflicts - the staging writes (one column, 16 nodes per lane
+    // quarter: with a plain row stride of 48 doubles every second node falls on the same bank,
+    // measured 65 % of the LDS cycles lost) and the fragment reads (one node per quarter, 16
+    // consecutive columns: the swizzle permutes them within their aligned block of 16).
+    __host__ __device__ static constexpr int phys(int node, int col)
+    {
+        return node * RS + (col ^ (node >> 1));
+    }
+    // panel column of (mode m, component k, re / im)
+    __host__ __device__ static constexpr int column(int m, int k, int ri)
+    {
+        const int a = (QM == 2) ? 2 * m + k / 3 : m;
+        const int kk = (QM == 2) ? k % 3 : k;
+        return 16 * (kk >> 1) + 4 * (2 * (kk & 1) + ri) + a;
+    }
+};
+
+template <int NMT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_gather_cubic_mx(long n,
+        const double *__restrict__ x, const double *__restrict__ y,
+        const double *__restrict__ z, double rmax_gather,
+        double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
+        GatherGrids G, long rs,
+        double *__restrict__ Ex, double *__restrict__ Ey, double *__restrict__ Ez,
+        double *__restrict__ Bx, double *__restrict__ By, double *__restrict__ Bz,
+        int chunks_per_wave, PushArgs PA)
+{
+    using C = GMX<NMT>;
+    constexpr int NT = C::NT, FPL = C::FPL, RS = C::RS, NVL = C::NVL, WPAD = C::WPAD;
+    typedef double double4_t __attribute__((ext_vector_type(4)));
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double *panel = lds + (size_t)wave * C::WAVE_DOUBLES;      // G[node][column]
+    double *Wp = panel + 16 * RS;                              // per-particle rows
+    const int qa = lane >> 4, qj = lane & 15;
+    // mode / field block of this lane's quarter (fold) ...
+    const int q_m = (C::QM == 2) ? (qa >> 1) : qa;
+    const int q_h = (C::QM == 2) ? (qa & 1) : 0;
+    // ... and its staging role: node (jz, jr) = bits of the lane, field qa + 4 j of round j
+    const int st_jr = lane & 3, st_jz = (lane >> 2) & 3;
+    const cplx *st_ptr[NVL];
+    int st_ofs[NVL];
+    unsigned st_neg = 0u;         // bit j: the below-axis mirror of round j's field changes sign
+#pragma unroll
+    for (int j = 0; j < NVL; j++) {
+        const int f = qa + 4 * j;
+        const bool on = f < 6 * NMT;
+        const int ff = on ? f : 0;
+        const int m_ = ff / 6, k_ = ff - 6 * m_;
+        st_ptr[j] = on ? G.g[ff] : nullptr;
+        st_ofs[j] = C::phys(4 * st_jz + st_jr, C::column(m_, k_, 0));
+        // mirror below the axis: -(-1)^m for r,t components, +(-1)^m for z
+        // (inline_functions.py:70-79, 151-158)
+        const bool neg = ((k_ % 3 == 2) ? m1pow(m_) : -m1pow(m_)) < 0.;
+        st_neg |= neg ? (1u << j) : 0u;
+    }
+    // columns no field maps to (Nm = 3: the fourth quarter; Nm = 2: half of the second tile) stay 0
+    for (int o = lane; o < 16 * RS; o += 64) panel[o] = 0.;
+
+    const long chunk0 = (xcd_block_id() * nwaves + wave) * chunks_per_wave;
+    double xn = 0., yn = 0., zn = 0.;
+    if (chunk0 * 64 + lane < n) { xn = x[chunk0 * 64 + lane]; yn = y[chunk0 * 64 + lane]; zn = z[chunk0 * 64 + lane]; }
+    for (int ch = 0; ch < chunks_per_wave; ch++) {
+        const long base = (chunk0 + ch) * 64;
+        if (base >= n) break;
+        const long i = base + lane;
+        const bool act = i < n;
+        double cs = 1., sn = 0., Sz[4] = {0., 0., 0., 0.}, Sr[4] = {0., 0., 0., 0.};
+        int kz = G_NOKEY, kr = G_NOKEY;
+        bool inside = false;
+        const double xj = xn, yj = yn;
+        double zj = zn;
+        if (PA.wzmax > PA.wzmin) {
+            const double l_box = PA.wzmax - PA.wzmin;
+            while (zj >= PA.wzmax) zj -= l_box;
+            while (zj < PA.wzmin) zj += l_box;
+        }
+        if (ch + 1 < chunks_per_wave && i + 64 < n) { xn = x[i + 64]; yn = y[i + 64]; zn = z[i + 64]; }
+        // momenta of the chunk: requested now, used by the push at the end (this kernel's
+        // occupancy is set by its LDS panels, the 8 registers are free)
+        double mom[4] = {0., 0., 0., 0.};
+        if (PA.ux && act) { mom[0] = PA.ux[i]; mom[1] = PA.uy[i]; mom[2] = PA.uz[i]; mom[3] = PA.ig[i]; }
+        double rj = 0., r_cell = 0., z_cell = 0.;
         if (act) {
-            const double ex = cs * F[0] - sn * F[1], ey = sn * F[0] + cs * F[1], ez = F[2];
-            const double bx = cs * F[3] - sn * F[4], by = sn * F[3] + cs * F[4], bz = F[5];
-            if (Ex) { Ex[i] = ex; Ey[i] = ey; Ez[i] = ez; Bx[i] = bx; By[i] = by; Bz[i] = bz; }
-            if (PA.ux) {
-                // momenta are loaded here, not at the top of the chunk: 8 VGPRs less across the
-                // stencil phase; the other waves of the SIMD cover the latency (measured: -3 %)
-                double pux = PA.ux[i], puy = PA.uy[i], puz = PA.uz[i], pig = PA.ig[i];
-                vay(pux, puy, puz, pig, ex, ey, ez, bx, by, bz, PA.econst, PA.bconst);
-                PA.ux[i] = pux; PA.uy[i] = puy; PA.uz[i] = puz; PA.ig[i] = pig;
-                if (PA.chdt != 0.) {
-                    // numba_methods.py:28-30 with push_x = push_y = push_z = 1
-                    const double xp = xj + PA.chdt * pig * 1. * pux;
-                    const double yp = yj + PA.chdt * pig * 1. * puy;
-                    const double zp = zj + PA.chdt * pig * 1. * puz;
-                    PA.x[i] = xp; PA.y[i] = yp; PA.z[i] = zp;
-                    if (PA.RK.count) {
-                        // position after the coming push_x, cell as in k_cell_index / k_bin_rank
-                        const double xq = xp + PA.RK.chdt * pig * PA.RK.px * pux;
-                        const double yq = yp + PA.RK.chdt * pig * PA.RK.py * puy;
-                        const double zq = zp + PA.RK.chdt * pig * PA.RK.pz * puz;
-                        const double rq = sqrt(xq * xq + yq * yq);
-                        int ir_upper = (int)ceil(invdr * (rq - rmin) - 0.5);
-                        int iz_upper = (int)ceil(invdz * (zq - zmin) - 0.5);
-                        if (ir_upper > Nr) ir_upper = Nr;
-                        if (iz_upper < 0) iz_upper += Nz;
-                        else if (iz_upper > Nz - 1) iz_upper -= Nz;
-                        rk_c = ir_upper + iz_upper * (Nr + 1);
-                    }
+            rj = sqrt(xj * xj + yj * yj);
+            r_cell = invdr * (rj - rmin) - 0.5;
+            z_cell = invdz * (zj - zmin) - 0.5;
+            inside = rj < rmax_gather;
+            if (inside) { kr = (int)floor(r_cell) - 1; kz = (int)floor(z_cell) - 1; }
+        }
+        const int pkz = __shfl_up(kz, 1), pkr = __shfl_up(kr, 1);
+        const bool is_start = inside && (lane == 0 || kz != pkz || kr != pkr);
+        unsigned long long rem = __ballot(is_start);
+        // ---- staging of a segment: issue (node values in flight) / commit (to the LDS panel)
+        double2 vals[NVL];
+        bool st_below = false;
+        int ps = 0, pe = 0;
+        auto issue = [&]() {
+            ps = __builtin_ctzll(rem);
+            rem &= rem - 1ull;
+            pe = rem ? __builtin_ctzll(rem) : 64;
+            const int skz = __builtin_amdgcn_readlane(kz, ps), skr = __builtin_amdgcn_readlane(kr, ps);
+            int row = skz + st_jz, col = skr + st_jr;
+            if (row < 0) row += Nz; else if (row > Nz - 1) row -= Nz;
+            st_below = col < 0;
+            if (st_below) col = -col - 1; else if (col > Nr - 1) col = Nr - 1;
+            const long off = (long)row * rs + col;
+#pragma unroll
+            for (int j = 0; j < NVL; j++) {
+                vals[j] = make_double2(0., 0.);
+                if ((64 * (j + 1) <= C::NV) || st_ptr[j]) vals[j] = ldc(st_ptr[j] + off);
+            }
+        };
+        auto commit = [&]() {
+#pragma unroll
+            for (int j = 0; j < NVL; j++) {
+                if ((64 * (j + 1) <= C::NV) || st_ptr[j]) {
+                    const double sg_ = (st_below && ((st_neg >> j) & 1u)) ? -1. : 1.;
+                    panel[st_ofs[j]] = sg_ * vals[j].x;
+                    panel[st_ofs[j] ^ 4] = sg_ * vals[j].y;      // column + 4 (re -> im)
+                }
+            }
+        };
+        const bool any = rem != 0ull;
+        if (any) issue();            // the first segment's L2 round trip overlaps the rest of phase 1
+        if (act) {
+            if (rj != 0.) { const double invr = 1. / rj; cs = xj * invr; sn = yj * invr; }
+            if (inside) {
+                // threading_methods.py:312-321
+                double l = r_cell - kr;
+                double a = l - 2., b = l - 1., cc = 2. - l, d = 1. - l;
+                Sr[0] = -1. / 6. * (a * (a * a));
+                Sr[1] = 1. / 6. * (3. * (b * (b * b)) - 6. * (b * b) + 4.);
+                Sr[2] = 1. / 6. * (3. * (cc * (cc * cc)) - 6. * (cc * cc) + 4.);
+                Sr[3] = -1. / 6. * (d * (d * d));
+                l = z_cell - kz;
+                a = l - 2.; b = l - 1.; cc = 2. - l; d = 1. - l;
+                Sz[0] = -1. / 6. * (a * (a * a));
+                Sz[1] = 1. / 6. * (3. * (b * (b * b)) - 6. * (b * b) + 4.);
+                Sz[2] = 1. / 6. * (3. * (cc * (cc * cc)) - 6. * (cc * cc) + 4.);
+                Sz[3] = -1. / 6. * (d * (d * d));
+            }
+        }
+        // per-particle rows: weights (0 for a particle that gathers nothing) and exptheta_m =
+        // (cos - i sin)^m of modes 1 .. (recurrence of k_gather)
+#pragma unroll
+        for (int j = 0; j < 4; j++) { Wp[j * WPAD + lane] = Sz[j]; Wp[(4 + j) * WPAD + lane] = Sr[j]; }
+        {
+            double er = cs, ei = -sn;
+#pragma unroll
+            for (int m = 1; m < NMT; m++) {
+                Wp[(8 + 2 * (m - 1)) * WPAD + lane] = er;
+                Wp[(9 + 2 * (m - 1)) * WPAD + lane] = ei;
+                const double nr_ = er * cs - ei * (-sn);
+                const double ni_ = er * (-sn) + ei * cs;
+                er = nr_; ei = ni_;
+            }
+        }
+        double F[6] = {0., 0., 0., 0., 0., 0.};
+        double4_t acc[NT];
+        int gcur = -1;
+        // finished group: mode factor x exptheta, sum over the quarters, keep the own particle
+        auto fold = [&](int g) {
+            const int p = 16 * g + qj;
+            double er = 1., ei = 0.;
+            if (q_m > 0) { er = Wp[(8 + 2 * (q_m - 1)) * WPAD + p]; ei = Wp[(9 + 2 * (q_m - 1)) * WPAD + p]; }
+            const double factor = (q_m == 0) ? 1. : 2.;
+            double Fq[FPL];
+#pragma unroll
+            for (int kk = 0; kk < FPL; kk++) {
+                const double fr = acc[kk >> 1][2 * (kk & 1)], fi = acc[kk >> 1][2 * (kk & 1) + 1];
+                double v = factor * (fr * er - fi * ei);
+                if constexpr (C::QM == 1) v = sum_xor32(sum_xor16(v));
+                else v = sum_xor32(v);                // the other mode of the same E / B block
+                Fq[kk] = v;
+            }
+            if constexpr (C::QM == 1) {
+                if (qa == g) {
+#pragma unroll
+                    for (int k = 0; k < 6; k++) F[k] = Fq[k];
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 3; kk++) {
+                    const double other = other_xor16(Fq[kk]);       // the other block (E <-> B)
+                    if (qa == g) { F[kk] = q_h ? other : Fq[kk]; F[3 + kk] = q_h ? Fq[kk] : other; }
+                }
+            }
+        };
+        bool more = any;
+        while (more) {
+            const int cps = ps, cpe = pe;
+            commit();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // the next segment's node values travel while this one is multiplied
+            more = rem != 0ull;
+            if (more) issue();
+            for (int g = cps >> 4; g <= (cpe - 1) >> 4; g++) {
+                if (g != gcur) {
+                    if (gcur >= 0) fold(gcur);
+#pragma unroll
+                    for (int t = 0; t < NT; t++) acc[t] = (double4_t){0., 0., 0., 0.};
+                    gcur = g;
+                }
+                // B operand: lane l -> W[node 4 jz + (l >> 4)][particle 16 g + (l & 15)], zero
+                // outside the segment
+                const int p = 16 * g + qj;
+                const bool in = p >= cps && p < cpe;
+                const double srv = in ? Wp[(4 + qa) * WPAD + p] : 0.;
+#pragma unroll
+                for (int jz = 0; jz < 4; jz++) {
+                    const double b = Wp[jz * WPAD + p] * srv;
+                    // A operand fragment: lane l -> G[node 4 jz + (l >> 4)][16 t + (l & 15)]; read
+                    // per group instead of held across the segment: 18 registers less, which is
+                    // what lets the next segment's loads be in flight (the LDS pipe is idle)
+                    double ag[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; t++) ag[t] = panel[C::phys(4 * jz + qa, 16 * t + qj)];
+#pragma unroll
+                    for (int t = 0; t < NT; t++)
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ag[t], b, acc[t], 0, 0, 0);
                 }
             }
         }
-        if (PA.RK.count) {
-            // one atomic per run of equal destination cells (wave-uniform branch)
-            const int prev = __shfl_up(rk_c, 1);
-            const bool rk_start = act && (lane == 0 || rk_c != prev);
-            const unsigned long long rstarts = __ballot(rk_start);
-            const int nact = __popcll(__ballot(act));
-            const unsigned long long below = rstarts & ((2ull << lane) - 1ull);
-            const int rk_run0 = 63 - __builtin_clzll(below | 1ull);
-            int rk_base = 0;
-            if (rk_start) {
-                const unsigned long long rest = (lane + 1 < 64) ? (rstarts >> (lane + 1)) : 0ull;
-                const int len = rest ? (__builtin_ctzll(rest) + 1) : (nact - lane);
-                rk_base = atomicAdd(PA.RK.count + rk_c, len);
-            }
-            rk_base = __shfl(rk_base, rk_run0);
-            if (act) {
-                PA.RK.cell[i] = rk_c;
-                PA.RK.rank[i] = rk_base + (lane - rk_run0);
-            }
-        }
+        if (gcur >= 0) fold(gcur);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        gather_finish(act, i, lane, xj, yj, zj, cs, sn, F, Ex, Ey, Ez, Bx, By, Bz, PA,
+                      invdz, zmin, Nz, invdr, rmin, Nr, mom);
     }
 }
 
@@ -518,6 +839,30 @@ extern "C" int fb_shift_periodic(long n, double *z, double zmin, double zmax, vo
     FB_CHECK_LAUNCH("fb_shift_periodic");
 }
 
+template <int NMT>
+static int launch_gather_cubic_mx(long n, const double *x, const double *y, const double *z,
+        double rmax_gather, double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
+        const GatherGrids &G, long row_stride, double *Ex, double *Ey, double *Ez, double *Bx,
+        double *By, double *Bz, const PushArgs &PA, hipStream_t s, const char *where)
+{
+    using C = GMX<NMT>;
+    // waves per workgroup so that as many waves as possible share the 160 KB of a CU
+    const size_t wave_bytes = (size_t)C::WAVE_DOUBLES * 8;
+    int nwaves = 4;
+    if ((160 * 1024 / (wave_bytes * 3)) * 3 > (160 * 1024 / (wave_bytes * 4)) * 4) nwaves = 3;
+    const long nchunks = (n + 63) / 64;
+    const long target_waves = 256L * 64;
+    int cpw = (int)((nchunks + target_waves - 1) / target_waves);
+    if (cpw < 1) cpw = 1;
+    if (cpw > 64) cpw = 64;
+    const long total_waves = (nchunks + cpw - 1) / cpw;
+    dim3 grid((unsigned)xcd_grid((total_waves + nwaves - 1) / nwaves)), block(64 * nwaves);
+    hipLaunchKernelGGL((k_gather_cubic_mx<NMT>), grid, block, wave_bytes * nwaves, s, n, x, y, z,
+                       rmax_gather, invdz, zmin, Nz, invdr, rmin, Nr, G, row_stride, Ex, Ey, Ez,
+                       Bx, By, Bz, cpw, PA);
+    return check(hipGetLastError(), where);
+}
+
 static int launch_gather(int shape, int Nm, long n, const double *x, const double *y,
         const double *z, double rmax_gather, double invdz, double zmin, int Nz, double invdr,
         double rmin, int Nr, const void *const *grids, long row_stride,
@@ -533,6 +878,12 @@ static int launch_gather(int shape, int Nm, long n, const double *x, const doubl
     GatherGrids G;
     for (int i = 0; i < 6 * Nm; i++) G.g[i] = (const cplx *)grids[i];
     for (int i = 6 * Nm; i < 6 * FB_MAX_MODES; i++) G.g[i] = nullptr;
+    if (shape == FB_SHAPE_CUBIC && Nm >= 2 && Nm <= 4 && !getenv("FBPIC_AMD_GATHER_VALU")) {
+#define FB_MX(NMT) launch_gather_cubic_mx<NMT>(n, x, y, z, rmax_gather, invdz, zmin, Nz, invdr, rmin, Nr, G, \
+                                               row_stride, Ex, Ey, Ez, Bx, By, Bz, PA, s, where)
+        return Nm == 2 ? FB_MX(2) : (Nm == 3 ? FB_MX(3) : FB_MX(4));
+#undef FB_MX
+    }
     const int S = (shape == FB_SHAPE_LINEAR) ? 2 : 4;
     const size_t panel_bytes = (size_t)(2 * S * S * 6 * Nm + 2) * 8;
     // segments staged per round: up to 8, within ~16 KiB of LDS per wave
