@@ -93,7 +93,10 @@ __device__ __forceinline__ void fold_node(int &iz, int &ir, int Nz, int Nr)
     if (ir < 0) ir = -ir - 1; else if (ir > Nr - 1) ir = Nr - 1;
 }
 
-constexpr int DEP_PAD = 65;          // panel row stride in doubles (64 particles + 1)
+// panel row stride in doubles: 64 particles + 1 (linear: a group of 16 consecutive particles per
+// read); cubic: + 4, so that the 4 x 4 (row, particle) addresses of a column-block read fall on
+// 16 different bank pairs
+constexpr int dep_pad(int S) { return S == 4 ? 68 : 65; }
 constexpr int DEP_NOKEY = -0x40000000;
 
 // Phase 2 is a small matrix product per cell: out[node][amplitude] = sum over the particles
@@ -129,7 +132,8 @@ struct DepLayout {
     // J, linear, Nm = 2: 17 rows x 65 doubles = 8.8 KB per wave -> 4 workgroups of 4 waves per
     // CU instead of 3 with the padded 20 rows; rho: 11 rows -> 6 instead of 4.
     static constexpr int NA = R1 + RH;
-    static constexpr int WAVE_DOUBLES = (NW + NA) * DEP_PAD + 1;
+    static constexpr int PAD = dep_pad(S);
+    static constexpr int WAVE_DOUBLES = (NW + NA) * PAD + 1;
     static constexpr size_t wave_bytes() { return (size_t)WAVE_DOUBLES * 8; }
     // panel row of amplitude (component k, launch-local mode mm, re/im)
     __host__ __device__ static constexpr int row(int k, int mm, int ri)
@@ -183,22 +187,44 @@ struct DepEngine {
     using L = DepLayout<SHAPE, NCOMP, NM, Z0>;
     static constexpr int S = L::S, H = ShapeTraits<SHAPE>::H;
     static constexpr int NPT = L::NPT, RG = L::RG, NW = L::NW, NT = L::NT, T1 = L::T1;
+    static constexpr int DEP_PAD = L::PAD;
     static constexpr bool NEED_W0 = Z0, NEED_WH = (!Z0) || (NM > 1);
     // Accumulator tile u = rg * NT + t holds, in lane l, node rg*4 + kl x amplitude row 4t + jl
     // of block bl.  At a flush the 4 blocks are added (row rotations) and the lanes of block b
     // write tile 4 q + b in round q: one atomic instruction per 4 tiles.
     static constexpr int NTILE = RG * NT, NQ = (NTILE + 3) / 4;
+    // Cubic shape, CB ("column blocks"): the 4 blocks of the MFMA are the 4 node rows (jz) of the
+    // cell instead of 4 groups of particles - block b multiplies W[nodes (b, jr = 0..3)][4
+    // particles] by the amplitudes of the same 4 particles (B operand replicated over the
+    // blocks: a broadcast LDS read).  One instruction covers 4 particles x 16 nodes x 4
+    // amplitudes, the same 256 MACs, but every lane then holds ONE finished sum per column tile
+    // (node (bl, kl), amplitude jl): a quarter of the accumulator registers (J, Nm = 4: 12
+    // instead of 48) and no cross-block reduction at a flush, which was ~40 % of the kernel's VALU
+    // instructions (24 tiles x (4 DPP moves + 2 adds + 2 selects) per run; SQ counters, 2048 x 512
+    // x 64 ppc: 1187 VALU + 120 MFMA instructions per 64 particles, fp64 MFMA and VALU do not
+    // overlap on gfx950, tools/overlap_probe.hip).
+    static constexpr int STRAY_MAX = 4;          // longest run handled out of band (see reduce)
+#ifdef FB_NO_STRAYS
+    static constexpr bool STRAYS = false;
+#else
+    // cubic shape only: a flush of the linear shape is one atomic instruction, and the second
+    // product / flush path costs the fused linear pass more than the strays do (205 -> 216 us)
+    static constexpr bool STRAYS = (S == 4);
+#endif
+    static constexpr bool CB = (S == 4);
+    static constexpr int NF = CB ? NT : NQ;      // values a lane flushes per run
+    static constexpr int NAR = CB ? 1 : RG;
 
     double *Wl, *Al;
     int lane, jl, bl, kl, poff;    // poff: particle (within a group of 16) fed by this lane
-    double *f_ptr[NQ];             // grid base of this lane's amplitude (re or im part)
-    double *f_ptrz[NQ];            // ... advanced to the lane's node row: f_ptr + 2 * f_jz * rs
-    double f_sgn[NQ];
-    int f_jz[NQ], f_jr[NQ];
-    bool f_ok[NQ];
+    double *f_ptr[NF];             // grid base of this lane's amplitude (re or im part)
+    double *f_ptrz[NF];            // ... advanced to the lane's node row: f_ptr + 2 * f_jz * rs
+    double f_sgn[NF];
+    int f_jz[NF], f_jr[NF];
+    bool f_ok[NF];
     long rs, cs, cs2;              // row / column stride in elements, column stride in doubles
     int Nz, Nr, m0;
-    double acc[RG][NT];
+    double acc[NAR][NT];
     int aoff[NT];                  // LDS offset of the amplitude row this lane feeds to tile t
     int cur_z, cur_r, cur_nb;
     unsigned int my_flushes;       // wave-uniform: runs of equal cells seen by this wave
@@ -220,8 +246,9 @@ struct DepEngine {
         poff = 4 * bl + kl;
         rs = rs_; cs = G.cs; cs2 = 2 * G.cs; Nz = Nz_; Nr = Nr_; m0 = m0_;
 #pragma unroll
-        for (int qq = 0; qq < NQ; qq++) {
-            const int u = 4 * qq + bl;
+        for (int qq = 0; qq < NF; qq++) {
+            // CB: value qq of this lane = tile qq of its node (bl, kl); else tile 4 qq + bl
+            const int u = CB ? bl * NT + qq : 4 * qq + bl;
             const int rg = u / NT, t = u % NT;
             int k, mm, ri;
             bool ok = u < NTILE;
@@ -251,7 +278,7 @@ struct DepEngine {
 #pragma unroll
         for (int t = 0; t < NT; t++) aoff[t] = L::tile_row(t, jl) * DEP_PAD;
 #pragma unroll
-        for (int rg = 0; rg < RG; rg++)
+        for (int rg = 0; rg < NAR; rg++)
 #pragma unroll
             for (int t = 0; t < NT; t++) acc[rg][t] = 0.;
         cur_z = DEP_NOKEY; cur_r = DEP_NOKEY; cur_nb = 0;
@@ -259,29 +286,34 @@ struct DepEngine {
         off = 0;
     }
 
-    // flush the finished cell; keep_upper: only its lowest node column (the others carry on)
-    __device__ __forceinline__ void flush(bool keep_upper)
+    // flush the sums A of cell (cz, cr); keep_upper: only its lowest node column (the others
+    // carry on); off_: rotation of the radial columns (see `off`)
+    __device__ __forceinline__ void flush_acc(const double (&A)[NAR][NT], int cz, int cr, int cnb,
+                                              int off_, bool keep_upper)
     {
-        if (cur_z == DEP_NOKEY) return;
         my_flushes++;
-        const bool interior = cur_z >= 0 && cur_z + S <= Nz && cur_r >= 0 && cur_r + S <= Nr;
+        const bool interior = cz >= 0 && cz + S <= Nz && cr >= 0 && cr + S <= Nr;
         // offset of the cell's lowest node in doubles: wave-uniform, scalar arithmetic
-        const long cell_base2 = 2 * ((long)cur_z * rs + (long)cur_r * cs);
+        const long cell_base2 = 2 * ((long)cz * rs + (long)cr * cs);
 #pragma unroll
-        for (int qq = 0; qq < NQ; qq++) {
-            // add the 4 blocks of each tile, then keep the tile this lane writes in this round
+        for (int qq = 0; qq < NF; qq++) {
             double v = 0.;
+            if constexpr (CB) {
+                v = A[0][qq];          // already the sum over the particles of the run
+            } else {
+                // add the 4 blocks of each tile, then keep the tile this lane writes in this round
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const int u = 4 * qq + b;
-                if (u < NTILE) {
-                    double a = acc[u / NT][u % NT];
-                    a += row_ror<4>(a);
-                    a += row_ror<8>(a);
-                    v = (bl == b) ? a : v;
+                for (int b = 0; b < 4; b++) {
+                    const int u = 4 * qq + b;
+                    if (u < NTILE) {
+                        double a = A[u / NT][u % NT];
+                        a += row_ror<4>(a);
+                        a += row_ror<8>(a);
+                        v = (bl == b) ? a : v;
+                    }
                 }
             }
-            const int jr = (f_jr[qq] - off) & (S - 1);
+            const int jr = (f_jr[qq] - off_) & (S - 1);
             if (!f_ok[qq] || v == 0. || (keep_upper && jr != 0)) continue;
             if (interior) {
                 // all S x S nodes inside the grid (wave-uniform test): no guard folding, no
@@ -290,10 +322,75 @@ struct DepEngine {
                 if constexpr (S > 2) joff += (jr & 2) ? 2 * cs2 : 0;
                 atomicAdd(f_ptrz[qq] + cell_base2 + joff, v);
             } else {
-                int gz = cur_z + f_jz[qq], gr = cur_r + jr;
+                int gz = cz + f_jz[qq], gr = cr + jr;
                 fold_node(gz, gr, Nz, Nr);
-                if (jr < cur_nb) v *= f_sgn[qq];            // node below the axis: signed fold
+                if (jr < cnb) v *= f_sgn[qq];               // node below the axis: signed fold
                 atomicAdd(f_ptr[qq] + 2 * ((long)gz * rs + (long)gr * cs), v);
+            }
+        }
+    }
+    // flush the current cell
+    __device__ __forceinline__ void flush(bool keep_upper)
+    {
+        if (cur_z == DEP_NOKEY) return;
+        flush_acc(acc, cur_z, cur_r, cur_nb, off, keep_upper);
+    }
+
+    // A += W . amplitudes over the staged particles [p, e) (one run); off_ as in flush_acc
+    __device__ __forceinline__ void product(double (&A)[NAR][NT], int p, int e, int off_)
+    {
+        // node fed by this lane in row group rg: rg*4 + (its logical column).  Linear shape:
+        // jl = jz*2 + jr and only the jr bit rotates; cubic: jz = rg, jr = (jl - off) mod 4
+        const int wrow = (S == 2) ? (jl ^ off_) : ((jl - off_) & 3);
+        const int jr_row = (S == 2) ? (wrow & 1) : wrow;
+        if constexpr (CB) {
+            // steps of 4 particles; lane (bl, jl, kl): A = W[node (bl, jr_row)][particle 4 st + kl],
+            // B = amplitude row of (tile, jl) of the same particle
+            const int s1 = (e - 1) >> 2;
+            for (int st = p >> 2; st <= s1; st++) {
+                const int pi = 4 * st + kl;
+                const bool in = (pi >= p) && (pi < e);
+                const double sz = Wl[bl * DEP_PAD + pi];
+                double w0 = 0., wh = 0.;
+                if constexpr (NEED_W0) { const double v = Wl[(S + jr_row) * DEP_PAD + pi]; w0 = in ? sz * v : 0.; }
+                if constexpr (NEED_WH) { const double v = Wl[(2 * S + jr_row) * DEP_PAD + pi]; wh = in ? sz * v : 0.; }
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    const double av = Al[aoff[t] + pi];
+                    double wv;
+                    if constexpr (!NEED_WH) wv = w0;
+                    else if constexpr (!NEED_W0) wv = wh;
+                    else wv = (t < T1) ? w0 : wh;
+                    A[0][t] = __builtin_amdgcn_mfma_f64_4x4x4f64(wv, av, A[0][t], 0, 0, 0);
+                }
+            }
+        } else {
+            const int g1 = (e - 1) >> 4;
+            for (int g = p >> 4; g <= g1; g++) {
+                const int pi = 16 * g + poff;
+                const bool in = (pi >= p) && (pi < e);
+                double w0[RG], wh[RG];
+                double sr0 = 0., srh = 0.;
+                if constexpr (NEED_W0) { const double v = Wl[(S + jr_row) * DEP_PAD + pi]; sr0 = in ? v : 0.; }
+                if constexpr (NEED_WH) { const double v = Wl[(2 * S + jr_row) * DEP_PAD + pi]; srh = in ? v : 0.; }
+#pragma unroll
+                for (int rg = 0; rg < RG; rg++) {
+                    const double sz = Wl[((S == 2) ? (wrow >> 1) : rg) * DEP_PAD + pi];
+                    if constexpr (NEED_W0) w0[rg] = sz * sr0;
+                    if constexpr (NEED_WH) wh[rg] = sz * srh;
+                }
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    const double av = Al[aoff[t] + pi];
+#pragma unroll
+                    for (int rg = 0; rg < RG; rg++) {
+                        double wv;
+                        if constexpr (!NEED_WH) wv = w0[rg];
+                        else if constexpr (!NEED_W0) wv = wh[rg];
+                        else wv = (t < T1) ? w0[rg] : wh[rg];
+                        A[rg][t] = __builtin_amdgcn_mfma_f64_4x4x4f64(wv, av, A[rg][t], 0, 0, 0);
+                    }
+                }
             }
         }
     }
@@ -387,64 +484,55 @@ struct DepEngine {
         const unsigned long long starts = __ballot(is_start && lane < cnt);
         int p = 0;
         while (p < cnt) {
+            const unsigned long long rest = (p + 1 < 64) ? (starts >> (p + 1)) : 0ull;
+            int e = rest ? p + 1 + __builtin_ctzll(rest) : cnt;
+            if (e > cnt) e = cnt;
             if ((starts >> p) & 1ull) {
                 const int nz_ = __builtin_amdgcn_readlane(my_kz, p);
                 const int nr_ = __builtin_amdgcn_readlane(my_kr, p);
-                if (nz_ == cur_z && nr_ == cur_r + 1) {
+                if (nz_ == cur_z && nr_ == cur_r) {
+                    // the current cell again (after a stray, below): carry on
+                } else if (nz_ == cur_z && nr_ == cur_r + 1) {
                     flush(true);                     // column cur_r is complete
                     // the other columns carry on, one position lower in the new cell
                     const bool carry = (((kl & (S - 1)) - off) & (S - 1)) != 0;
 #pragma unroll
-                    for (int rg = 0; rg < RG; rg++)
+                    for (int rg = 0; rg < NAR; rg++)
 #pragma unroll
                         for (int t = 0; t < NT; t++) acc[rg][t] = carry ? acc[rg][t] : 0.;
                     off = (off + 1) & (S - 1);
+                    cur_r = nr_;
+                    cur_nb = __builtin_amdgcn_readlane(my_nb, p);
+                } else if (STRAYS && cur_z != DEP_NOKEY && e - p <= STRAY_MAX && e < cnt) {
+                    // A stray: a few particles that sit among those of the current cell but
+                    // deposit into another one (the stream is sorted by the cell of a position
+                    // half a step or a step away; ~1-2 % of a thermal plasma's particles).
+                    // Ending the current cell's run for them would flush it twice and lose its
+                    // sliding columns: their sums go out directly instead, the current cell's
+                    // accumulation continues.  (2048 x 512 x 64 ppc cubic Nm = 4, once the lattice
+                    // has thermalised: J deposition 7.7 ms per step with every stray ending the run.)
+                    double tmp[NAR][NT];
+#pragma unroll
+                    for (int rg = 0; rg < NAR; rg++)
+#pragma unroll
+                        for (int t = 0; t < NT; t++) tmp[rg][t] = 0.;
+                    product(tmp, p, e, 0);
+                    flush_acc(tmp, nz_, nr_, __builtin_amdgcn_readlane(my_nb, p), 0, false);
+                    p = e;
+                    continue;
                 } else {
                     flush(false);
 #pragma unroll
-                    for (int rg = 0; rg < RG; rg++)
+                    for (int rg = 0; rg < NAR; rg++)
 #pragma unroll
                         for (int t = 0; t < NT; t++) acc[rg][t] = 0.;
                     off = 0;
-                }
-                cur_z = nz_;
-                cur_r = nr_;
-                cur_nb = __builtin_amdgcn_readlane(my_nb, p);
-            }
-            const unsigned long long rest = (p + 1 < 64) ? (starts >> (p + 1)) : 0ull;
-            int e = rest ? p + 1 + __builtin_ctzll(rest) : cnt;
-            if (e > cnt) e = cnt;
-            const int g1 = (e - 1) >> 4;
-            // node fed by this lane in row group rg: rg*4 + (its logical column).  Linear shape:
-            // jl = jz*2 + jr and only the jr bit rotates; cubic: jz = rg, jr = (jl - off) mod 4
-            const int wrow = (S == 2) ? (jl ^ off) : ((jl - off) & 3);
-            const int jr_row = (S == 2) ? (wrow & 1) : wrow;
-            for (int g = p >> 4; g <= g1; g++) {
-                const int pi = 16 * g + poff;
-                const bool in = (pi >= p) && (pi < e);
-                double w0[RG], wh[RG];
-                double sr0 = 0., srh = 0.;
-                if constexpr (NEED_W0) { const double v = Wl[(S + jr_row) * DEP_PAD + pi]; sr0 = in ? v : 0.; }
-                if constexpr (NEED_WH) { const double v = Wl[(2 * S + jr_row) * DEP_PAD + pi]; srh = in ? v : 0.; }
-#pragma unroll
-                for (int rg = 0; rg < RG; rg++) {
-                    const double sz = Wl[((S == 2) ? (wrow >> 1) : rg) * DEP_PAD + pi];
-                    if constexpr (NEED_W0) w0[rg] = sz * sr0;
-                    if constexpr (NEED_WH) wh[rg] = sz * srh;
-                }
-#pragma unroll
-                for (int t = 0; t < NT; t++) {
-                    const double av = Al[aoff[t] + pi];
-#pragma unroll
-                    for (int rg = 0; rg < RG; rg++) {
-                        double wv;
-                        if constexpr (!NEED_WH) wv = w0[rg];
-                        else if constexpr (!NEED_W0) wv = wh[rg];
-                        else wv = (t < T1) ? w0[rg] : wh[rg];
-                        acc[rg][t] = __builtin_amdgcn_mfma_f64_4x4x4f64(wv, av, acc[rg][t], 0, 0, 0);
-                    }
+                    cur_z = nz_;
+                    cur_r = nr_;
+                    cur_nb = __builtin_amdgcn_readlane(my_nb, p);
                 }
             }
+            product(acc, p, e, off);
             p = e;
         }
     }
@@ -680,6 +768,24 @@ __global__ __launch_bounds__(256) void k_perm_deposit_J_rho(long n, double q, do
     er.flush(false);
 }
 
+// Waves per workgroup: the panel of a workgroup stays <= 64 KiB, and among 4, 3, 2, 1 waves the
+// choice is the one that lets most waves share the 160 KB of a CU (cubic J, Nm = 4: 17.5 KB per
+// wave -> 3 workgroups of 3 waves rather than 4 of 2)
+static int dep_waves_per_workgroup(size_t wave_bytes)
+{
+#ifdef FB_OLD_NW
+    { int nw = 4; while (nw > 1 && wave_bytes * nw > 64 * 1024) nw >>= 1; return nw; }
+#endif
+    int best = 1;
+    size_t best_waves = 0;
+    for (int nw = 4; nw >= 1; nw--) {
+        if (wave_bytes * nw > 64 * 1024 && nw > 1) continue;
+        const size_t per_cu = (160 * 1024) / (wave_bytes * nw) * nw;
+        if (per_cu > best_waves) { best_waves = per_cu; best = nw; }
+    }
+    return best;
+}
+
 template <int SHAPE, int NCOMP, int NM, bool Z0, bool RANK, bool PERM = false>
 static int launch_z(long n, const double *x, const double *y, const double *z, const double *w,
         double q, const double *ux, const double *uy, const double *uz, const double *ig,
@@ -693,8 +799,7 @@ static int launch_z(long n, const double *x, const double *y, const double *z, c
     if (PMp) PM = *PMp;
     // waves per workgroup: keep the LDS panel <= 64 KiB (1, 2 or 4 waves per workgroup and 32 /
     // 64 / 128 waves per CU in flight measured: 4 and 64 as good as any)
-    int nwaves = 4;
-    while (nwaves > 1 && L::wave_bytes() * nwaves > 64 * 1024) nwaves >>= 1;
+    const int nwaves = dep_waves_per_workgroup(L::wave_bytes());
     const long nchunks = (n + 63) / 64;
     // ~8 waves per SIMD-quad in flight over 256 CUs, each walking consecutive chunks so
     // that a cell straddling two chunks is not flushed twice
@@ -905,8 +1010,7 @@ static int launch_perm_J_rho(long n, double q, double c, const DepGeom &gJ, cons
     using ER = DepEngine<SHAPE, 1, NM, true>;
     const size_t wave_bytes = 8 * (size_t)(EJ::L::WAVE_DOUBLES > ER::L::WAVE_DOUBLES ? EJ::L::WAVE_DOUBLES
                                                                                       : ER::L::WAVE_DOUBLES);
-    int nwaves = 4;
-    while (nwaves > 1 && wave_bytes * nwaves > 64 * 1024) nwaves >>= 1;
+    const int nwaves = dep_waves_per_workgroup(wave_bytes);
     const long nchunks = (n + 63) / 64;
     const long target_waves = 256L * 64;
     int cpw = (int)((nchunks + target_waves - 1) / target_waves);

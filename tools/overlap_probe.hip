@@ -12,8 +12,23 @@ __global__ __launch_bounds__(512) void k(int mode, int iters, double *out)
     const int wave = threadIdx.x >> 6;
     const bool do_mfma = mode == 0 || (mode == 2 && wave < 4) || (mode == 3 && wave < 4);
     const bool do_fma = mode == 1 || (mode == 2 && wave >= 4) || (mode == 4 && wave >= 4);
+    const bool do_int = (mode == 5 || mode == 6) && wave >= 4;
+    const bool do_mfma2 = mode == 5 && wave < 4;
     double a = threadIdx.x * 1e-3, b = 1.0000001;
-    if (do_mfma) {
+    if (do_int) {
+        // 64 integer / fp32 VALU instructions per iteration (4 cycles each)
+        unsigned y0 = threadIdx.x, y1 = y0 + 1, y2 = y0 + 2, y3 = y0 + 3;
+        float f0 = a, f1 = a + 1, f2 = a + 2, f3 = a + 3;
+        for (int i = 0; i < iters; i++) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                y0 = y0 * 3u + 7u; y1 = (y1 ^ y0) + 5u; y2 = y2 * 5u + y1; y3 = (y3 + y2) ^ 9u;
+                f0 = __builtin_fmaf(f0, 1.0001f, 0.5f); f1 = __builtin_fmaf(f1, 1.0001f, f0); f2 = __builtin_fmaf(f2, 0.999f, f1); f3 = __builtin_fmaf(f3, 0.999f, f2);
+            }
+        }
+        out[blockIdx.x * 512 + threadIdx.x] = y0 + y1 + y2 + y3 + f0 + f1 + f2 + f3;
+    }
+    if (do_mfma || do_mfma2) {
         double4_t c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
         for (int i = 0; i < iters; i++) {
             c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
@@ -47,9 +62,9 @@ int main()
     const int iters = 4096;
     // 256 CUs x 2 workgroups of 4 waves = 2 waves per SIMD
     // one workgroup of 8 waves per CU: waves w and w + 4 share SIMD w
-    const char *names[5] = {"8 waves MFMA", "8 waves FMA", "waves 0-3 MFMA + 4-7 FMA", "waves 0-3 MFMA, 4-7 idle", "waves 0-3 idle, 4-7 FMA"};
+    const char *names[7] = {"8 waves MFMA", "8 waves FMA", "waves 0-3 MFMA + 4-7 FMA", "waves 0-3 MFMA, 4-7 idle", "waves 0-3 idle, 4-7 FMA", "waves 0-3 MFMA + 4-7 int/fp32 VALU", "waves 0-3 idle, 4-7 int/fp32 VALU"};
     for (int wg = 1; wg <= 1; wg++)
-        for (int mode = 0; mode < 5; mode++) {
+        for (int mode = 0; mode < 7; mode++) {
             hipLaunchKernelGGL(k, dim3(256 * wg), dim3(512), 0, 0, mode, iters, out);
             hipDeviceSynchronize();
             hipEventRecord(e0);
