@@ -14,6 +14,9 @@ from .. import _capi
 from .injection import generate_evenly_spaced, ContinuousInjector
 
 _SHAPE = {'linear': 1, 'cubic': 3}
+# the cubic J deposition rides along in the fused pass too since its engine holds a quarter of the
+# accumulators (2048 x 512 x 64 ppc: Nm = 4 15.4 -> 14.8 ms per step, Nm = 2 9.5 -> 8.8)
+_FUSE_J_CUBIC = os.environ.get('FBPIC_AMD_FUSE_J_CUBIC', '1') == '1'
 _STATE = ('x', 'y', 'z', 'ux', 'uy', 'uz', 'w', 'inv_gamma')
 _FIELDS = ('Ex', 'Ey', 'Ez', 'Bx', 'By', 'Bz')
 
@@ -542,11 +545,9 @@ class Particles(object):
         self._need_gpu()
         if fieldtype == 'J':
             defer, self.defer_J_deposit = self.defer_J_deposit, False
-            # (linear shape only: with the cubic shape the two depositions together need 176-264
-            # VGPRs - one or two waves per SIMD - and the fused pass is no faster than two)
             if (defer and self.fuse_sort_deposit_rho and self.use_bin_sort and self.Ntot > 0
                     and len(fld.interp) <= 4 and self._pending_push is None
-                    and self.particle_shape == 'linear'):
+                    and (self.particle_shape == 'linear' or _FUSE_J_CUBIC)):
                 self._pending_J = (fld, records)          # rides along in the rho deposition
                 self.push_after_deposit_J = None
                 return
