@@ -185,6 +185,8 @@ typedef ZCfg<4096, 1, 256, 16, 16, 16, 1, 1> ZC4096;
 // 9 x 2^k (a power-of-two slab plus 2 x 64 guard cells, e.g. 1024 + 128): 4608 points per
 // 192-lane workgroup (24 per lane), radix 6, 6 then 8 / 4: four passes (measured against the
 // 128-lane radix 9, 4, 4, 4, 2 plan with 36 points per lane and five passes)
+// head of the lengths 192 x R (fb_fft_generic: 4416 = 192 x 23), 16 columns per workgroup
+typedef ZCfg<192, 16, 128, 6, 8, 4, 1, 1> ZC192;
 typedef ZCfg<576, 8, 192, 6, 6, 4, 4, 1> ZC576;
 typedef ZCfg<1152, 4, 192, 6, 6, 8, 4, 1> ZC1152;
 typedef ZCfg<2304, 2, 192, 6, 6, 8, 8, 1> ZC2304;
@@ -267,10 +269,14 @@ __device__ __forceinline__ void zf_pass(cx *lds, const cx *__restrict__ tw,
     }
 }
 
-template <class Z, bool FWD>
+// SUB: the launch transforms `nsub` interleaved sub-sequences of every column - the head of a
+// longer transform of length nsub * N (fb_fft_generic): sub-sequence b reads rows b + nsub * u
+// (in_stride = nsub x the row stride, + b * sub_in) and writes rows b * N + k (+ b * sub_out).
+// The virtual column index runs over (b, column).
+template <class Z, bool FWD, bool SUB = false>
 __global__ __launch_bounds__(Z::NTHR) void k_zfft(long ncols, const cx *in, long in_stride,
         cx *out, long out_stride, const cx *__restrict__ tw, double scale, int ntiles, int pm_Nr,
-        int aos_Nr, int aos_rec, int aos_clear)
+        int aos_Nr, int aos_rec, int aos_clear, long sub_in = 0, long sub_out = 0, int nsub = 1)
 {
     constexpr int C = Z::C;
     extern __shared__ double2 zf_lds[];
@@ -289,11 +295,18 @@ __global__ __launch_bounds__(Z::NTHR) void k_zfft(long ncols, const cx *in, long
         const int nfld = (int)(ncols / aos_Nr);
         col = (long)(tile % nfld) * aos_Nr + (long)(tile / nfld) * C + c;
     }
-    const bool col_ok = col < ncols;
+    long col_sub_in = 0, col_sub_out = 0;
+    bool col_ok = col < ncols;
+    if constexpr (SUB) {
+        col_ok = col < ncols * nsub;
+        const long b = col / ncols;
+        col -= b * ncols;
+        col_sub_in = b * sub_in; col_sub_out = b * sub_out;
+    }
     // aos_Nr > 0: the input is node-major, in[iz * in_stride + ir * aos_rec + field] (the
     // deposition's record-per-node target); column (field, ir) of the transform gathers it
-    const cx *gin = aos_Nr > 0 ? in + (col % aos_Nr) * aos_rec + (col / aos_Nr) : in + col;
-    cx *gout = out + col;
+    const cx *gin = aos_Nr > 0 ? in + (col % aos_Nr) * aos_rec + (col / aos_Nr) : in + col + col_sub_in;
+    cx *gout = out + col + col_sub_out;
     // pm_Nr > 0: the columns are groups of (p, m, z) fields of pm_Nr columns each
     int pm = 0;
     const cx *gin2 = nullptr;
@@ -365,6 +378,37 @@ static int zfft_launch(long ncols, const cx *in, long is, cx *out, long os, int 
         hipLaunchKernelGGL((k_zfft<Z, false>), dim3(nblocks), dim3(Z::NTHR), lds_bytes, s, ncols, in,
                            is, out, os, tw, 1.0 / (double)N, ntiles, pm_Nr, aos_Nr, aos_rec, aos_clear);
     return check(hipGetLastError(), "fb_zfft");
+}
+
+// head of fb_fft_generic for Nz = 192 x nsub: all the 192-point sub-transforms in one launch
+static int zfft_head192(int nsub, long ncols, const cx *in, long is, cx *out, long os, bool fwd,
+                        hipStream_t s)
+{
+    using Z = ZC192;
+    const cx *tw = nullptr;
+    int r = get_twiddles(Z::N, &tw);
+    if (r) return r;
+    const size_t lds_bytes = (size_t)Z::LDS_CX * sizeof(cx);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_zfft<Z, true, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)k_zfft<Z, false, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return check(e, "fb_fft_generic(attr)");
+        attr_set = true;
+    }
+    const long vcols = ncols * nsub;
+    const int ntiles = (int)((vcols + Z::C - 1) / Z::C);
+    const int nblocks = (ntiles + 7) & ~7;
+    if (fwd)
+        hipLaunchKernelGGL((k_zfft<Z, true, true>), dim3(nblocks), dim3(Z::NTHR), lds_bytes, s, ncols, in,
+                           (long)nsub * is, out, os, tw, 1.0, ntiles, 0, 0, 0, 0, is, (long)Z::N * os, nsub);
+    else
+        hipLaunchKernelGGL((k_zfft<Z, false, true>), dim3(nblocks), dim3(Z::NTHR), lds_bytes, s, ncols, in,
+                           (long)nsub * is, out, os, tw, 1.0, ntiles, 0, 0, 0, 0, is, (long)Z::N * os, nsub);
+    return check(hipGetLastError(), "fb_fft_generic(head)");
 }
 
 // Direct DFT of odd prime length R = 2 h + 1 with the conjugate symmetry of the roots folded
@@ -555,6 +599,27 @@ extern "C" int fb_fft_generic(int Nz, long ncols, const void *in, long in_stride
     if (r) return r;
     hipStream_t s = (hipStream_t)stream;
     const bool fwd = direction < 0;
+    // Nz = 192 x R with a single-pass R (4416 = 192 x 23, the 4096-cell laser-wakefield window):
+    // the passes of the 192-point factor run in ONE launch through LDS (k_zfft on the
+    // interleaved sub-sequences, 256-B row pieces) and only the radix-R pass sweeps the slab
+    // again: two sweeps instead of three (24, 8, 23).
+    if (Nz % 192 == 0 && Nz > 192) {
+        const int R = Nz / 192;
+        int rr[40];
+        if (factorize(R, rr) == 1) {
+            r = zfft_head192(R, ncols, (const cx *)in, in_stride, (cx *)scratch, scratch_stride, fwd, s);
+            if (r) return r;
+            const dim3 g2((unsigned)((ncols + 255) / 256), (unsigned)(192 < 1024 ? 192 : 1024));
+            const double scale = fwd ? 1.0 : 1.0 / (double)Nz;
+#define FB_PASS(RR) case RR: pass_launch<RR>(fwd, g2, s, Nz, 192, ncols, (const cx *)scratch, scratch_stride, (cx *)out, out_stride, tw, scale); break
+            switch (R) {
+            FB_PASS(2); FB_PASS(3); FB_PASS(4); FB_PASS(5); FB_PASS(7); FB_PASS(8); FB_PASS(9); FB_PASS(11);
+            FB_PASS(13); FB_PASS(17); FB_PASS(19); FB_PASS(23); FB_PASS(24); FB_PASS(29); FB_PASS(31);
+            }
+#undef FB_PASS
+            return check(hipGetLastError(), "fb_fft_generic");
+        }
+    }
     const dim3 grid((unsigned)((ncols + 255) / 256), (unsigned)(Nz / radix[np - 1] < 1024 ? Nz / radix[np - 1] : 1024));
     // buffers alternate so that the last pass lands in `out`; pass 0 must not write what it
     // reads: in place with an odd number of passes starts with a copy to the scratch slab

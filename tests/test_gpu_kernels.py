@@ -318,7 +318,7 @@ def test_spectral_kernels(hip, oracle):
 
 
 # ------------------------------------------------------------------ FFT / Hankel
-@pytest.mark.parametrize('Nz', [6, 48, 60, 62, 690, 2400, 4416, 1024])
+@pytest.mark.parametrize('Nz', [6, 48, 60, 62, 690, 2400, 4416, 1024, 384, 960, 2112, 4608])
 def test_fft_generic_any_length(hip, Nz):
     """fb_fft_generic (pass-per-launch fallback for the lengths rocFFT refuses) against numpy:
     out of place and in place, odd and even pass counts, radices 2..31."""
