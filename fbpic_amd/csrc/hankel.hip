@@ -300,8 +300,9 @@ static int launch(int njobs, const void *const *in, long irs, void *const *out, 
             Sc.fz[j] = (v && dual) ? (const double *)out2[j0 + j] : ((v && fz) ? fz[j0 + j] : nullptr);
             Sc.fr[j] = (v && fr) ? fr[j0 + j] : nullptr;
         }
-        // wave tile: 16 x 128 columns when that still gives every CU a workgroup, else 16 x 64
-        // (twice the workgroups); the dual (two accumulator sets) variant always uses 16 x 64
+        // the dual (two accumulator sets) variant always uses the 32 x 64 workgroup: at 4416 x 256
+        // the 64 x 128 one spills (128 VGPRs at 16 waves: 0.33 -> 0.79 ms) and a 32 x 128 one
+        // with 8 waves is no faster (0.35 ms)
         int r;
         // Tile choice (measured, see the comment on top of k_hankel): 64 x 128 with 16 waves when
         // that still gives every CU two workgroups' worth of tiles (2048 x 512, 4096 x 256: the
