@@ -76,6 +76,8 @@ _SIGNATURES = {
     'fb_zfft_from_records': (I, [I, I, I, P, L, I, P, L, P]),
     'fb_zfft_from_records_consume': (I, [I, I, I, P, L, I, P, L, P]),
     'fb_fft_generic_supported': (I, [I]),
+    'fb_fft_generic_from_records_supported': (I, [I]),
+    'fb_fft_generic_from_records_consume': (I, [I, I, I, P, L, I, P, L, P, L, P]),
     'fb_fft_generic': (I, [I, L, P, L, P, L, P, L, I, P]),
     'fb_hankel': (I, [I, _PP, L, _PP, L, _PP, D, I, I, P]),
     'fb_hankel_scaled': (I, [I, _PP, L, _PP, L, _PP, _PP, _PP, _PP, D, I, I, P]),
@@ -191,7 +193,7 @@ class _TimedLib(object):
         f = getattr(self._real, name)
         if not name.startswith('fb_') or name in ('fb_last_error', 'fb_abi_version',
                                                   'fb_sort_workspace_bytes', 'fb_bin_sort_workspace_bytes', 'fb_fft_plan_create',
-                                                  'fb_fft_plan_destroy', 'fb_sync', 'fb_set_device', 'fb_comm_unique_id', 'fb_comm_init', 'fb_comm_destroy', 'fb_zfft_supported', 'fb_fft_generic_supported'):
+                                                  'fb_fft_plan_destroy', 'fb_sync', 'fb_set_device', 'fb_comm_unique_id', 'fb_comm_init', 'fb_comm_destroy', 'fb_zfft_supported', 'fb_fft_generic_supported', 'fb_fft_generic_from_records_supported'):
             return f
         t = torch()
         recs = self._records.setdefault(name, [])

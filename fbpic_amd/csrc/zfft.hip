@@ -290,7 +290,7 @@ __global__ __launch_bounds__(Z::NTHR) void k_zfft(long ncols, const cx *in, long
     if (tile >= ntiles) return;
     const int c = threadIdx.x % C, jj0 = threadIdx.x / C;
     long col = (long)tile * C + c;
-    if (aos_Nr > 0 && aos_Nr % C == 0) {
+    if (!SUB && aos_Nr > 0 && aos_Nr % C == 0) {
         // records input: order the tiles node-block major, field minor, so that the tiles that
         // read the same record lines (one 16-B field each) are neighbours on one XCD and the
         // line comes from HBM once, not once per field and XCD
@@ -301,13 +301,22 @@ __global__ __launch_bounds__(Z::NTHR) void k_zfft(long ncols, const cx *in, long
     bool col_ok = col < ncols;
     if constexpr (SUB) {
         col_ok = col < ncols * nsub;
-        const long b = col / ncols;
+        long b = col / ncols;
         col -= b * ncols;
+        if (aos_Nr > 0 && aos_Nr % C == 0) {
+            // records input: (sub-sequence, node block) major, field minor - the tiles that read
+            // the same 128-B records (one 16-B field each) are neighbours on one XCD
+            const int nfld = (int)(ncols / aos_Nr), nblk = aos_Nr / C;
+            const int q = tile / nfld;
+            b = q / nblk;
+            col = (long)(tile % nfld) * aos_Nr + (long)(q % nblk) * C + c;
+            col_ok = b < nsub;
+        }
         col_sub_in = b * sub_in; col_sub_out = b * sub_out;
     }
     // aos_Nr > 0: the input is node-major, in[iz * in_stride + ir * aos_rec + field] (the
     // deposition's record-per-node target); column (field, ir) of the transform gathers it
-    const cx *gin = aos_Nr > 0 ? in + (col % aos_Nr) * aos_rec + (col / aos_Nr) : in + col + col_sub_in;
+    const cx *gin = (aos_Nr > 0 ? in + (col % aos_Nr) * aos_rec + (col / aos_Nr) : in + col) + col_sub_in;
     cx *gout = out + col + col_sub_out;
     // pm_Nr > 0: the columns are groups of (p, m, z) fields of pm_Nr columns each
     int pm = 0;
@@ -384,7 +393,7 @@ static int zfft_launch(long ncols, const cx *in, long is, cx *out, long os, int 
 
 // head of fb_fft_generic for Nz = 192 x nsub: all the 192-point sub-transforms in one launch
 static int zfft_head192(int nsub, long ncols, const cx *in, long is, cx *out, long os, bool fwd,
-                        hipStream_t s)
+                        hipStream_t s, int aos_Nr = 0, int aos_rec = 0, int aos_clear = 0)
 {
     using Z = ZC192;
     const cx *tw = nullptr;
@@ -406,7 +415,8 @@ static int zfft_head192(int nsub, long ncols, const cx *in, long is, cx *out, lo
     const int nblocks = (ntiles + 7) & ~7;
     if (fwd)
         hipLaunchKernelGGL((k_zfft<Z, true, true>), dim3(nblocks), dim3(Z::NTHR), lds_bytes, s, ncols, in,
-                           (long)nsub * is, out, os, tw, 1.0, ntiles, 0, 0, 0, 0, is, (long)Z::N * os, nsub);
+                           (long)nsub * is, out, os, tw, 1.0, ntiles, 0, aos_Nr, aos_rec, aos_clear, is,
+                           (long)Z::N * os, nsub);
     else
         hipLaunchKernelGGL((k_zfft<Z, false, true>), dim3(nblocks), dim3(Z::NTHR), lds_bytes, s, ncols, in,
                            (long)nsub * is, out, os, tw, 1.0, ntiles, 0, 0, 0, 0, is, (long)Z::N * os, nsub);
@@ -577,6 +587,36 @@ static int factorize(int N, int *radix)
     return n == 1 ? np : 0;
 }
 
+// Nz = 192 x R with a single-pass R (4416 = 192 x 23, the 4096-cell laser-wakefield window):
+// the passes of the 192-point factor run in ONE launch through LDS (k_zfft on the interleaved
+// sub-sequences, 256-B row pieces) and only the radix-R pass sweeps the slab again: two sweeps
+// instead of three (24, 8, 23).  The head can gather its input from the deposition's records
+// (and clear them), like the single-launch LDS transform.
+static bool fft_two_sweep_supported(int Nz)
+{
+    if (Nz % 192 != 0 || Nz <= 192) return false;
+    int rr[40];
+    return factorize(Nz / 192, rr) == 1;
+}
+
+static int fft_two_sweep(int Nz, long ncols, const cx *in, long in_stride, cx *out, long out_stride,
+                         cx *scratch, long scratch_stride, bool fwd, const cx *tw, hipStream_t s,
+                         int aos_Nr, int aos_rec, int aos_clear)
+{
+    const int R = Nz / 192;
+    int r = zfft_head192(R, ncols, in, in_stride, scratch, scratch_stride, fwd, s, aos_Nr, aos_rec, aos_clear);
+    if (r) return r;
+    const dim3 g2((unsigned)((ncols + 255) / 256), 192u);
+    const double scale = fwd ? 1.0 : 1.0 / (double)Nz;
+#define FB_PASS(RR) case RR: pass_launch<RR>(fwd, g2, s, Nz, 192, ncols, scratch, scratch_stride, out, out_stride, tw, scale); break
+    switch (R) {
+    FB_PASS(2); FB_PASS(3); FB_PASS(4); FB_PASS(5); FB_PASS(7); FB_PASS(8); FB_PASS(9); FB_PASS(11);
+    FB_PASS(13); FB_PASS(17); FB_PASS(19); FB_PASS(23); FB_PASS(24); FB_PASS(29); FB_PASS(31);
+    }
+#undef FB_PASS
+    return check(hipGetLastError(), "fb_fft_generic");
+}
+
 }  // namespace fb
 
 using namespace fb;
@@ -605,23 +645,9 @@ extern "C" int fb_fft_generic(int Nz, long ncols, const void *in, long in_stride
     // the passes of the 192-point factor run in ONE launch through LDS (k_zfft on the
     // interleaved sub-sequences, 256-B row pieces) and only the radix-R pass sweeps the slab
     // again: two sweeps instead of three (24, 8, 23).
-    if (Nz % 192 == 0 && Nz > 192) {
-        const int R = Nz / 192;
-        int rr[40];
-        if (factorize(R, rr) == 1) {
-            r = zfft_head192(R, ncols, (const cx *)in, in_stride, (cx *)scratch, scratch_stride, fwd, s);
-            if (r) return r;
-            const dim3 g2((unsigned)((ncols + 255) / 256), (unsigned)(192 < 1024 ? 192 : 1024));
-            const double scale = fwd ? 1.0 : 1.0 / (double)Nz;
-#define FB_PASS(RR) case RR: pass_launch<RR>(fwd, g2, s, Nz, 192, ncols, (const cx *)scratch, scratch_stride, (cx *)out, out_stride, tw, scale); break
-            switch (R) {
-            FB_PASS(2); FB_PASS(3); FB_PASS(4); FB_PASS(5); FB_PASS(7); FB_PASS(8); FB_PASS(9); FB_PASS(11);
-            FB_PASS(13); FB_PASS(17); FB_PASS(19); FB_PASS(23); FB_PASS(24); FB_PASS(29); FB_PASS(31);
-            }
-#undef FB_PASS
-            return check(hipGetLastError(), "fb_fft_generic");
-        }
-    }
+    if (fft_two_sweep_supported(Nz))
+        return fft_two_sweep(Nz, ncols, (const cx *)in, in_stride, (cx *)out, out_stride, (cx *)scratch,
+                             scratch_stride, fwd, tw, s, 0, 0, 0);
     const dim3 grid((unsigned)((ncols + 255) / 256), (unsigned)(Nz / radix[np - 1] < 1024 ? Nz / radix[np - 1] : 1024));
     // buffers alternate so that the last pass lands in `out`; pass 0 must not write what it
     // reads: in place with an odd number of passes starts with a copy to the scratch slab
@@ -652,6 +678,23 @@ extern "C" int fb_fft_generic(int Nz, long ncols, const void *in, long in_stride
     return check(hipGetLastError(), "fb_fft_generic");
 }
 
+
+extern "C" int fb_fft_generic_from_records_supported(int Nz) { return fft_two_sweep_supported(Nz) ? 1 : 0; }
+
+extern "C" int fb_fft_generic_from_records_consume(int Nz, int nfields, int Nr, void *in, long in_stride,
+                                                   int record, void *out, long out_stride, void *scratch,
+                                                   long scratch_stride, void *stream)
+{
+    const char *who = "fb_fft_generic_from_records_consume";
+    if (!fft_two_sweep_supported(Nz)) { set_error(who, "Nz must be 192 x R with a single-pass R"); return -1; }
+    if (nfields != record || Nr <= 0) { set_error(who, "the whole record must be transformed (nfields == record)"); return -1; }
+    if (!scratch || scratch == in || scratch == out || in == out) { set_error(who, "in, out and scratch must be distinct"); return -1; }
+    const cx *tw = nullptr;
+    int r = get_twiddles(Nz, &tw);
+    if (r) return r;
+    return fft_two_sweep(Nz, (long)nfields * Nr, (const cx *)in, in_stride, (cx *)out, out_stride,
+                         (cx *)scratch, scratch_stride, true, tw, (hipStream_t)stream, Nr, record, 1);
+}
 
 extern "C" int fb_zfft_supported(int Nz)
 {

@@ -311,6 +311,16 @@ class Fields(object):
                 Nz, nf, Nr, S.data_ptr(), S.stride(0), S.shape[2], self.d_scratch[:, 0, :].data_ptr(),
                 self.d_scratch.stride(0), st), 'fb_zfft_from_records_consume')
             self._records_clean = True
+        elif from_records and lib.fb_fft_generic_from_records_supported(Nz):
+            # lengths of the two-sweep generic FFT (4416 = 192 x 23): its head gathers the records
+            from .spectral_transform.fourier import generic_scratch
+            S = self.source_records()
+            scr2 = generic_scratch(Nz, nf * Nr, S.device)
+            _capi.check(lib.fb_fft_generic_from_records_consume(
+                Nz, nf, Nr, S.data_ptr(), S.stride(0), S.shape[2], self.d_scratch[:, 0, :].data_ptr(),
+                self.d_scratch.stride(0), scr2.data_ptr(), scr2.stride(0), st),
+                'fb_fft_generic_from_records_consume')
+            self._records_clean = True
         else:
             if from_records:
                 self.unpack_source_records()

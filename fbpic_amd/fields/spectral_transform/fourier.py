@@ -24,6 +24,15 @@ def get_plan(Nz, ncols, in_stride, out_stride, inplace=False):
     return _PLANS[key]
 
 
+def generic_scratch(Nz, ncols, device):
+    """Scratch slab of the pass-per-launch FFT (one per length and column count)."""
+    t = _capi.torch()
+    key = ('G', Nz, ncols, str(device))
+    if key not in _PLANS:
+        _PLANS[key] = t.empty((Nz, ncols + 8), dtype=t.complex128, device=device)
+    return _PLANS[key]
+
+
 def _generic_exec(src, dst, direction, Nz, ncols):
     """Fallback for lengths rocFFT refuses (e.g. 4416 = 2^6 * 3 * 23): the library's own
     pass-per-launch FFT, ping-pong with a scratch slab; lengths with a prime factor > 31
@@ -32,10 +41,7 @@ def _generic_exec(src, dst, direction, Nz, ncols):
     if not _capi.lib().fb_fft_generic_supported(Nz):
         _bluestein_exec(src, dst, direction, Nz, ncols)
         return
-    key = ('G', Nz, ncols)
-    if key not in _PLANS:
-        _PLANS[key] = t.empty((Nz, ncols + 8), dtype=t.complex128, device=src.device)
-    scratch = _PLANS[key]
+    scratch = generic_scratch(Nz, ncols, src.device)
     rc = _capi.lib().fb_fft_generic(Nz, ncols, src.data_ptr(), src.stride(0), dst.data_ptr(),
                                     dst.stride(0), scratch.data_ptr(), scratch.stride(0),
                                     direction, _capi.stream())

@@ -452,6 +452,16 @@ int fb_zfft_from_records(int Nz, int nfields, int Nr, const void *in, long in_st
 int fb_zfft_from_records_consume(int Nz, int nfields, int Nr, void *in, long in_stride, int record,
                                  void *out, long out_stride, void *stream);
 
+/* The same for the lengths the single-launch LDS transform does not hold but fb_fft_generic
+ * takes in two sweeps (Nz = 192 x R with a single-pass R, e.g. 4416 = 192 x 23: the local
+ * grid of the 4096-cell laser-wakefield window): the head of the transform gathers the records
+ * and zeroes them.  `scratch`: a slab of Nz rows x >= nfields*Nr columns distinct from in / out.
+ * fb_fft_generic_from_records_supported(Nz) tells whether a length takes this path. */
+int fb_fft_generic_from_records_supported(int Nz);
+int fb_fft_generic_from_records_consume(int Nz, int nfields, int Nr, void *in, long in_stride,
+                                        int record, void *out, long out_stride, void *scratch,
+                                        long scratch_stride, void *stream);
+
 /* Self-contained fallback for every other length whose prime factors are <= 31 (rocFFT of
  * ROCm 7.2 refuses some, e.g. Nz = 4416): one Stockham pass per launch through global
  * memory, ping-pong between `out` and a caller-provided scratch slab of the same shape

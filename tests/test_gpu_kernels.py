@@ -518,6 +518,28 @@ def test_zfft_from_records(hip):
     assert np.all(host(out[:, nf, :]) == 0)
 
 
+@pytest.mark.parametrize('Nz', [4416, 960])
+def test_fft_generic_from_records_consume(hip, Nz):
+    """fb_fft_generic_from_records_consume (two-sweep lengths 192 x R): forward transform of the
+    whole record array == numpy, and the records are zero afterwards."""
+    rng = np.random.default_rng(12)
+    Nr, rec = 24, 8
+    t = hip.torch()
+    assert hip.lib().fb_fft_generic_from_records_supported(Nz)
+    assert not hip.lib().fb_fft_generic_from_records_supported(1024)
+    a = rng.normal(size=(Nz, Nr, rec)) + 1j * rng.normal(size=(Nz, Nr, rec))
+    S = dev(hip, a)
+    out = t.zeros((Nz, rec + 1, Nr), dtype=t.complex128, device='cuda')
+    scr = t.zeros((Nz, rec * Nr + 8), dtype=t.complex128, device='cuda')
+    hip.check(hip.lib().fb_fft_generic_from_records_consume(
+        Nz, rec, Nr, S.data_ptr(), Nr * rec, rec, out[:, 0, :].data_ptr(), (rec + 1) * Nr,
+        scr.data_ptr(), rec * Nr + 8, hip.stream()), 'generic records')
+    ref = np.fft.fft(np.transpose(a, (0, 2, 1)), axis=0)
+    assert rel_err(host(out[:, :rec, :]), ref) < TOL
+    assert np.all(host(out[:, rec, :]) == 0)
+    assert np.all(host(S) == 0)
+
+
 def test_psatd_step_fused_equals_separate(hip, oracle):
     """fb_psatd_step_standard == correct_currents -> push_eb -> push_rho (oracle, per mode)."""
     g = golden('spectral')
