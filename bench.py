@@ -128,6 +128,7 @@ def bench_c3(args, torch, world, rank):
     out = {
         'metric': 'particle-updates/sec', 'value': npart * args.steps / dt_wall,
         'unit': 'particle-updates/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': warm,
+        'warmup_requested': args.warmup,
         'ms_per_step': 1e3 * dt_wall / args.steps, 'higher_is_better': True, 'scaling': args.scaling,
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': 'C3 laser-wakefield 4096x256 Nm=2 16 ppc linear shape, open z (n_guard 64, '
@@ -257,8 +258,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # decomposed run: the warm-up also covers the first particle hand-over between the ranks
+    # (every `exchange_period` steps; its first execution pays one-time start-up costs, ~3 ms)
+    warm = args.warmup if world == 1 else max(args.warmup, sim.comm.exchange_period + 2)
     with GpuMemoryManager(sim):
-        sim.step(args.warmup)
+        sim.step(warm)
         barrier()
         t0 = time.perf_counter()
         sim.step(args.steps)
@@ -279,7 +283,7 @@ def main():
     value = n_total * args.steps / dt_wall
     out = {
         'metric': 'particle-updates/sec', 'value': value, 'unit': 'particle-updates/s',
-        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'n_gpus': world, 'steps': args.steps, 'warmup': warm, 'warmup_requested': args.warmup,
         'ms_per_step': 1e3 * dt_wall / args.steps, 'higher_is_better': True,
         'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'ns_per_particle_step': 1e9 * dt_wall / (args.steps * n_total) * world,

@@ -27,14 +27,17 @@ def _prime_device_ops(t, dev):
     if dev in _PRIMED or dev.type != 'cuda':
         return
     _PRIMED.add(dev)
-    n = 48
+    # sizes chosen so that the operations take the same code paths as a real hand-over (e.g.
+    # index_select switches kernels above 16 indices: rehearsed with 2-7 indices only, the first
+    # real hand-over still spent 9 ms loading the large-index variant)
+    n = 4096
     arrs = [t.arange(n, dtype=t.float64, device=dev) + i for i in range(2)]
     ps = t.arange(n, dtype=t.int32, device=dev)
-    offs = t.stack([ps[i] for i in (2, 5, 40, 44)]).tolist()
+    offs = t.stack([ps[i] for i in (40, 100, n - 120, n - 30)]).tolist()
     z = arrs[0]
     idx_l = t.cat((t.arange(0, offs[0], device=dev),
-                   offs[0] + t.nonzero(z[offs[0]:offs[1]] < 4.).reshape(-1)))
-    idx_r = t.cat((offs[2] + t.nonzero(z[offs[2]:offs[3]] > 41.).reshape(-1),
+                   offs[0] + t.nonzero(z[offs[0]:offs[1]] < 70.).reshape(-1)))
+    idx_r = t.cat((offs[2] + t.nonzero(z[offs[2]:offs[3]] > n - 80.).reshape(-1),
                    t.arange(offs[3], n, device=dev)))
     send = t.stack([a.index_select(0, idx_l) for a in arrs]).contiguous()
     cnt = t.tensor([send.shape[1]], dtype=t.int64, device=dev)
@@ -43,7 +46,7 @@ def _prime_device_ops(t, dev):
     recv = t.empty((2, int(got.item())), dtype=t.float64, device=dev)
     recv.copy_(send)
     recv[1] += 1.
-    out, n_new = _compact_and_append(t, arrs, n, idx_l, idx_r, recv, recv[:, :2].contiguous())
+    out, n_new = _compact_and_append(t, arrs, n, idx_l, idx_r, recv, recv[:, :40].contiguous())
     f = _resized(t, out[0], 0, n_new)
     f.zero_()
     _resized(t, out[1], n_new, 4 * n)
@@ -141,6 +144,14 @@ def _compact_and_append(t, arrs, n, idx_l, idx_r, recv_l, recv_r):
 def exchange_particles_between_ranks(comm, species, fld, time):
     t = _capi.torch()
     _prime_device_ops(t, species.z.device)
+    if species.z.is_cuda and not getattr(species, '_handover_pool_primed', False):
+        # message-sized blocks for the caching allocator (send / receive payloads and index
+        # tensors of a hand-over): requested from the driver now, not by the first real hand-over
+        species._handover_pool_primed = True
+        m = max(species.Ntot // 24, 4096)
+        blocks = [t.empty((len(_STATE), m), dtype=t.float64, device=species.z.device) for _ in range(4)]
+        blocks += [t.empty(2 * m, dtype=t.int64, device=species.z.device) for _ in range(4)]
+        del blocks
     g0 = fld.interp[0]
     ng = comm.n_guard
     zbox_min = g0.zmin + ng * g0.dz

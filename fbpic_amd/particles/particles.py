@@ -167,8 +167,22 @@ class Particles(object):
     def send_particles_to_gpu(self):
         if self.data_is_on_gpu:
             return
+        # every particle array gets the head-room of the helper buffers (~6 %): the first
+        # hand-over that makes a rank's particle number grow then re-uses the storage instead of
+        # re-allocating 14 arrays in the middle of a run (particle_buffer_handling._resized)
+        t = _capi.torch()
+        dev = _capi.require_device()
+        n = self.Ntot
+        cap = n + n // 16 + 1024
         for k in _STATE + _FIELDS:
-            setattr(self, k, _capi.to_device(getattr(self, k), dtype=np.float64))
+            a = getattr(self, k)
+            if isinstance(a, t.Tensor):
+                setattr(self, k, _capi.to_device(a, dtype=np.float64))
+                continue
+            host = np.ascontiguousarray(a, dtype=np.float64)
+            d = t.empty(cap, dtype=t.float64, device=dev)[:n]
+            d.copy_(t.from_numpy(host))
+            setattr(self, k, d)
         if self.cell_idx is None or self.cell_idx.shape[0] != self.Ntot:
             self._alloc_device_helpers()
         self.sorted = False
