@@ -153,8 +153,10 @@ template <int N>
 __device__ __forceinline__ double row_ror(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x120 + N, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x120 + N, 0xf, 0xf, false);
+    // (mov_dpp, not update_dpp(0, ..): a row rotation writes every lane, and the "old" operand of
+    // update_dpp cost a v_mov_b32 0 per half - 4 of the 8 instructions of a block sum)
+    lo = __builtin_amdgcn_mov_dpp(lo, 0x120 + N, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_mov_dpp(hi, 0x120 + N, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 
