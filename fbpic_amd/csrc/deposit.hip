@@ -770,23 +770,7 @@ __global__ __launch_bounds__(256) void k_perm_deposit_J_rho(long n, double q, do
     er.flush(false);
 }
 
-// Waves per workgroup: the panel of a workgroup stays <= 64 KiB, and among 4, 3, 2, 1 waves the
-// choice is the one that lets most waves share the 160 KB of a CU (cubic J, Nm = 4: 17.5 KB per
-// wave -> 3 workgroups of 3 waves rather than 4 of 2)
-static int dep_waves_per_workgroup(size_t wave_bytes)
-{
-#ifdef FB_OLD_NW
-    { int nw = 4; while (nw > 1 && wave_bytes * nw > 64 * 1024) nw >>= 1; return nw; }
-#endif
-    int best = 1;
-    size_t best_waves = 0;
-    for (int nw = 4; nw >= 1; nw--) {
-        if (wave_bytes * nw > 64 * 1024 && nw > 1) continue;
-        const size_t per_cu = (160 * 1024) / (wave_bytes * nw) * nw;
-        if (per_cu > best_waves) { best_waves = per_cu; best = nw; }
-    }
-    return best;
-}
+static int dep_waves_per_workgroup(size_t wave_bytes) { return lds_waves_per_workgroup(wave_bytes); }
 
 template <int SHAPE, int NCOMP, int NM, bool Z0, bool RANK, bool PERM = false>
 static int launch_z(long n, const double *x, const double *y, const double *z, const double *w,

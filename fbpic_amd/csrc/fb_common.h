@@ -33,6 +33,30 @@ __device__ __forceinline__ double m1pow(int m) { return (m & 1) ? -1. : 1.; }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Waves per workgroup of the kernels whose occupancy is set by a per-wave LDS panel: among 4, 3, 2,
+// 1 waves (panel of a workgroup <= 64 KiB) the choice that lets most waves share a CU.  The LDS
+// of a workgroup is allocated in blocks (2 KiB assumed): three workgroups of 53.9 KB do NOT
+// co-reside in the 160 KB of a CU although 3 x 53.9 < 160 (measured: the fused cubic pass of
+// 2048 x 512 x 64 ppc, Nm = 4, 7.09 ms with 3-wave workgroups, 5.88 ms with four 2-wave ones).
+inline int lds_waves_per_workgroup(size_t wave_bytes, int max_waves = 4, int useful_per_cu = 16)
+{
+    // waves per CU of every choice (capped at what the registers allow anyway: 4 per SIMD for
+    // these kernels), then the LARGEST workgroup within 10 % of the best
+    size_t per_cu[5] = {0, 0, 0, 0, 0}, best_waves = 0;
+    for (int nw = max_waves; nw >= 1; nw--) {
+        const size_t wg = (wave_bytes * nw + 2047) / 2048 * 2048;
+        if (wg > 64 * 1024 && nw > 1) continue;
+        size_t w = (160 * 1024) / wg * nw;
+        if (w > (size_t)useful_per_cu) w = useful_per_cu;
+        per_cu[nw] = w;
+        if (w > best_waves) best_waves = w;
+    }
+    for (int nw = max_waves; nw >= 1; nw--)
+        if (per_cu[nw] * 10 >= best_waves * 9) return nw;
+    return 1;
+}
+
+
 // Workgroups are dealt round-robin to the 8 XCDs (workgroup b runs on XCD b % 8), each with
 // its own L2.  For kernels that walk the cell-sorted particle stream, give every XCD one
 // contiguous eighth of the stream: neighbouring cells (which share grid nodes) then meet in

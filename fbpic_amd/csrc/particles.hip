@@ -848,8 +848,7 @@ static int launch_gather_cubic_mx(long n, const double *x, const double *y, cons
     using C = GMX<NMT>;
     // waves per workgroup so that as many waves as possible share the 160 KB of a CU
     const size_t wave_bytes = (size_t)C::WAVE_DOUBLES * 8;
-    int nwaves = 4;
-    if ((160 * 1024 / (wave_bytes * 3)) * 3 > (160 * 1024 / (wave_bytes * 4)) * 4) nwaves = 3;
+    const int nwaves = lds_waves_per_workgroup(wave_bytes);
     const long nchunks = (n + 63) / 64;
     const long target_waves = 256L * 64;
     int cpw = (int)((nchunks + target_waves - 1) / target_waves);
