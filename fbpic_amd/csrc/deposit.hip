@@ -219,11 +219,11 @@ struct DepEngine {
 
     double *Wl, *Al;
     int lane, jl, bl, kl, poff;    // poff: particle (within a group of 16) fed by this lane
-    double *f_ptr[NF];             // grid base of this lane's amplitude (re or im part)
-    double *f_ptrz[NF];            // ... advanced to the lane's node row: f_ptr + 2 * f_jz * rs
-    double f_sgn[NF];
+    // grid base of this lane's amplitude (re or im part), advanced to the lane's node row
+    // (+ 2 * f_jz * rs); the sign of its below-axis mirror and its validity are bit masks
+    double *f_ptrz[NF];
+    unsigned f_neg, f_okm;
     int f_jz[NF], f_jr[NF];
-    bool f_ok[NF];
     long rs, cs, cs2;              // row / column stride in elements, column stride in doubles
     int Nz, Nr, m0;
     double acc[NAR][NT];
@@ -247,6 +247,7 @@ struct DepEngine {
         jl = lane & 3; bl = (lane >> 2) & 3; kl = lane >> 4;
         poff = 4 * bl + kl;
         rs = rs_; cs = G.cs; cs2 = 2 * G.cs; Nz = Nz_; Nr = Nr_; m0 = m0_;
+        f_neg = 0u; f_okm = 0u;
 #pragma unroll
         for (int qq = 0; qq < NF; qq++) {
             // CB: value qq of this lane = tile qq of its node (bl, kl); else tile 4 qq + bl
@@ -268,14 +269,14 @@ struct DepEngine {
             }
             if (!ok) { k = 0; mm = 0; ri = 0; }
             const int m = m0 + mm;
-            f_ok[qq] = ok;
-            f_ptr[qq] = (double *)G.g[k + NCOMP * m] + ri;
+            f_okm |= ok ? (1u << qq) : 0u;
+            double *fp = (double *)G.g[k + NCOMP * m] + ri;
             // rho, Jz: (-1)^m ; Jr, Jt: -(-1)^m (threading_methods.py:143-146, 289-302)
             const double flip = m1pow(m);
-            f_sgn[qq] = (NCOMP == 1 || k == 2) ? flip : -flip;
+            f_neg |= (((NCOMP == 1 || k == 2) ? flip : -flip) < 0.) ? (1u << qq) : 0u;
             const int pt = (rg % RG) * 4 + kl;
             f_jz[qq] = pt / S; f_jr[qq] = pt % S;
-            f_ptrz[qq] = f_ptr[qq] + 2 * ((long)f_jz[qq] * rs);
+            f_ptrz[qq] = fp + 2 * ((long)f_jz[qq] * rs);
         }
 #pragma unroll
         for (int t = 0; t < NT; t++) aoff[t] = L::tile_row(t, jl) * DEP_PAD;
@@ -316,7 +317,7 @@ struct DepEngine {
                 }
             }
             const int jr = (f_jr[qq] - off_) & (S - 1);
-            if (!f_ok[qq] || v == 0. || (keep_upper && jr != 0)) continue;
+            if (!((f_okm >> qq) & 1u) || v == 0. || (keep_upper && jr != 0)) continue;
             if (interior) {
                 // all S x S nodes inside the grid (wave-uniform test): no guard folding, no
                 // axis sign
@@ -326,8 +327,8 @@ struct DepEngine {
             } else {
                 int gz = cz + f_jz[qq], gr = cr + jr;
                 fold_node(gz, gr, Nz, Nr);
-                if (jr < cnb) v *= f_sgn[qq];               // node below the axis: signed fold
-                atomicAdd(f_ptr[qq] + 2 * ((long)gz * rs + (long)gr * cs), v);
+                if (jr < cnb && ((f_neg >> qq) & 1u)) v = -v;   // node below the axis: signed fold
+                atomicAdd(f_ptrz[qq] + 2 * ((long)(gz - f_jz[qq]) * rs + (long)gr * cs), v);
             }
         }
     }
@@ -695,22 +696,45 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
 // (deposit('rho_next'), :528).  The two depositions run one after the other on the same LDS
 // panel; the arithmetic of both overlaps the memory stalls of the permutation, and the
 // stand-alone J pass (64 B per particle read again) disappears.  Modes 0 .. NM-1 (NM <= 4).
+// Engines of the fused pass.  SPLIT (tried for the cubic shape with Nm >= 3): the J deposition as
+// two engines, modes 0-1 and modes 2.., one after the other on the same panel (the second stages
+// the geometry again, ~100 VALU instructions per 64 particles); the panel shrinks from 33 to 24
+// rows (Nm = 4), 13 KB per wave.
+template <int SHAPE, int NM> struct FusedPlan {
+    // (measured, 2048 x 512 x 64 ppc, Nm = 4: 5.70 ms unsplit, 6.78 ms split - the three workgroups
+    // of 52 KB that the smaller panel should allow do not co-reside either, and the second
+    // staging is paid in full: the split stays off)
+    static constexpr bool SPLIT = false && (SHAPE == FB_SHAPE_CUBIC && NM >= 3);
+    static constexpr int NMA = SPLIT ? 2 : NM, NMB = SPLIT ? NM - 2 : 1;
+    using EJ = DepEngine<SHAPE, 3, NMA, true>;
+    using EJ2 = DepEngine<SHAPE, 3, NMB, false>;
+    using ER = DepEngine<SHAPE, 1, NM, true>;
+    static constexpr int cmax(int a, int b) { return a > b ? a : b; }
+    static constexpr int WAVE_DOUBLES = cmax(cmax(EJ::L::WAVE_DOUBLES, ER::L::WAVE_DOUBLES),
+                                             SPLIT ? EJ2::L::WAVE_DOUBLES : 0);
+};
+
 template <int SHAPE, int NM>
-__global__ __launch_bounds__(256) void k_perm_deposit_J_rho(long n, double q, double c_light,
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(FusedPlan<SHAPE, NM>::SPLIT ? 3 : 1, 8)))
+void k_perm_deposit_J_rho(long n, double q, double c_light,
         DepGeom gJ, DepGeom gR, DepGrids GJ, long rsJ, DepGrids GR, long rsR,
         const double *__restrict__ beta0, const double *__restrict__ betah,
         int chunks_per_wave, PermArgs PM)
 {
-    using EJ = DepEngine<SHAPE, 3, NM, true>;
-    using ER = DepEngine<SHAPE, 1, NM, true>;
-    constexpr int WAVE_DOUBLES = EJ::L::WAVE_DOUBLES > ER::L::WAVE_DOUBLES ? EJ::L::WAVE_DOUBLES
-                                                                           : ER::L::WAVE_DOUBLES;
+    using P = FusedPlan<SHAPE, NM>;
+    using EJ = typename P::EJ;
+    using EJ2 = typename P::EJ2;
+    using ER = typename P::ER;
+    constexpr int WAVE_DOUBLES = P::WAVE_DOUBLES;
     extern __shared__ double lds[];
     const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     EJ ej;
+    EJ2 ej2;
     ER er;
     ej.init(lds + (size_t)wave * WAVE_DOUBLES, lane, GJ, rsJ, 0, gJ.Nz, gJ.Nr);
+    if constexpr (P::SPLIT) ej2.init(lds + (size_t)wave * WAVE_DOUBLES, lane, GJ, rsJ, P::NMA, gJ.Nz, gJ.Nr);
     er.init(lds + (size_t)wave * WAVE_DOUBLES, lane, GR, rsR, 0, gR.Nz, gR.Nr);
 
     const long chunk0 = (xcd_block_id() * nwaves + wave) * chunks_per_wave;
@@ -747,6 +771,13 @@ __global__ __launch_bounds__(256) void k_perm_deposit_J_rho(long n, double q, do
         wave_lds_release();
         ej.reduce(cnt, kz, kr, nb);
         wave_lds_acquire();
+        if constexpr (P::SPLIT) {
+            ej2.stage(act, pc[0], pc[1], pc[2], wj, pc[3], pc[4], pc[5], pc[7], c_light, gJ, beta0, betah,
+                      kz, kr, nb);
+            wave_lds_release();
+            ej2.reduce(cnt, kz, kr, nb);
+            wave_lds_acquire();
+        }
         // ---- pending push_x (expression of k_push_x), attributes written at the sorted slot
         double xj = pc[0], yj = pc[1], zj = pc[2];
         if (act) {
@@ -767,6 +798,7 @@ __global__ __launch_bounds__(256) void k_perm_deposit_J_rho(long n, double q, do
         wave_lds_acquire();
     }
     ej.flush(false);
+    if constexpr (P::SPLIT) ej2.flush(false);
     er.flush(false);
 }
 
@@ -992,10 +1024,7 @@ static int launch_perm_J_rho(long n, double q, double c, const DepGeom &gJ, cons
                              const DepGrids &GJ, long rsJ, const DepGrids &GR, long rsR,
                              const double *b0, const double *bh, const PermArgs &PM, hipStream_t s)
 {
-    using EJ = DepEngine<SHAPE, 3, NM, true>;
-    using ER = DepEngine<SHAPE, 1, NM, true>;
-    const size_t wave_bytes = 8 * (size_t)(EJ::L::WAVE_DOUBLES > ER::L::WAVE_DOUBLES ? EJ::L::WAVE_DOUBLES
-                                                                                      : ER::L::WAVE_DOUBLES);
+    const size_t wave_bytes = 8 * (size_t)FusedPlan<SHAPE, NM>::WAVE_DOUBLES;
     const int nwaves = dep_waves_per_workgroup(wave_bytes);
     const long nchunks = (n + 63) / 64;
     const long target_waves = 256L * 64;

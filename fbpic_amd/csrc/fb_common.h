@@ -35,9 +35,10 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Waves per workgroup of the kernels whose occupancy is set by a per-wave LDS panel: among 4, 3, 2,
 // 1 waves (panel of a workgroup <= 64 KiB) the choice that lets most waves share a CU.  The LDS
-// of a workgroup is allocated in blocks (2 KiB assumed): three workgroups of 53.9 KB do NOT
-// co-reside in the 160 KB of a CU although 3 x 53.9 < 160 (measured: the fused cubic pass of
-// 2048 x 512 x 64 ppc, Nm = 4, 7.09 ms with 3-wave workgroups, 5.88 ms with four 2-wave ones).
+// of a workgroup is allocated in blocks of 2 KiB (tools/lds_probe.hip: 3 x 53 248 B and 4 x 40 960 B
+// co-reside on a CU, 3 x 53 880 B do not): three workgroups of 53.9 KB do NOT share the 160 KB of a
+// CU although 3 x 53.9 < 160 (the fused cubic pass of 2048 x 512 x 64 ppc, Nm = 4: 7.09 ms with
+// 3-wave workgroups, 5.7-5.9 ms with four 2-wave ones).
 inline int lds_waves_per_workgroup(size_t wave_bytes, int max_waves = 4, int useful_per_cu = 16)
 {
     // waves per CU of every choice (capped at what the registers allow anyway: 4 per SIMD for
