@@ -696,45 +696,34 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
 // (deposit('rho_next'), :528).  The two depositions run one after the other on the same LDS
 // panel; the arithmetic of both overlaps the memory stalls of the permutation, and the
 // stand-alone J pass (64 B per particle read again) disappears.  Modes 0 .. NM-1 (NM <= 4).
-// Engines of the fused pass.  SPLIT (tried for the cubic shape with Nm >= 3): the J deposition as
-// two engines, modes 0-1 and modes 2.., one after the other on the same panel (the second stages
-// the geometry again, ~100 VALU instructions per 64 particles); the panel shrinks from 33 to 24
-// rows (Nm = 4), 13 KB per wave.
+// Engines of the fused pass: J (3 components) and rho on the same per-wave panel.
+// (Tried for the cubic shape with Nm >= 3: J as two engines, modes 0-1 and modes 2.., the panel
+// shrinking from 33 to 24 rows = 13 KB per wave so that twelve instead of eight waves share a CU.
+// The second engine stages the geometry again and the kernel needs 168 VGPRs with spills:
+// 2048 x 512 x 64 ppc, Nm = 4: 5.70 ms unsplit, 6.78 ms split.)
 template <int SHAPE, int NM> struct FusedPlan {
-    // (measured, 2048 x 512 x 64 ppc, Nm = 4: 5.70 ms unsplit, 6.78 ms split - the three workgroups
-    // of 52 KB that the smaller panel should allow do not co-reside either, and the second
-    // staging is paid in full: the split stays off)
-    static constexpr bool SPLIT = false && (SHAPE == FB_SHAPE_CUBIC && NM >= 3);
-    static constexpr int NMA = SPLIT ? 2 : NM, NMB = SPLIT ? NM - 2 : 1;
-    using EJ = DepEngine<SHAPE, 3, NMA, true>;
-    using EJ2 = DepEngine<SHAPE, 3, NMB, false>;
+    using EJ = DepEngine<SHAPE, 3, NM, true>;
     using ER = DepEngine<SHAPE, 1, NM, true>;
-    static constexpr int cmax(int a, int b) { return a > b ? a : b; }
-    static constexpr int WAVE_DOUBLES = cmax(cmax(EJ::L::WAVE_DOUBLES, ER::L::WAVE_DOUBLES),
-                                             SPLIT ? EJ2::L::WAVE_DOUBLES : 0);
+    static constexpr int WAVE_DOUBLES = EJ::L::WAVE_DOUBLES > ER::L::WAVE_DOUBLES ? EJ::L::WAVE_DOUBLES
+                                                                                   : ER::L::WAVE_DOUBLES;
 };
 
 template <int SHAPE, int NM>
-__global__ __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu(FusedPlan<SHAPE, NM>::SPLIT ? 3 : 1, 8)))
-void k_perm_deposit_J_rho(long n, double q, double c_light,
+__global__ __launch_bounds__(256) void k_perm_deposit_J_rho(long n, double q, double c_light,
         DepGeom gJ, DepGeom gR, DepGrids GJ, long rsJ, DepGrids GR, long rsR,
         const double *__restrict__ beta0, const double *__restrict__ betah,
         int chunks_per_wave, PermArgs PM)
 {
     using P = FusedPlan<SHAPE, NM>;
     using EJ = typename P::EJ;
-    using EJ2 = typename P::EJ2;
     using ER = typename P::ER;
     constexpr int WAVE_DOUBLES = P::WAVE_DOUBLES;
     extern __shared__ double lds[];
     const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     EJ ej;
-    EJ2 ej2;
     ER er;
     ej.init(lds + (size_t)wave * WAVE_DOUBLES, lane, GJ, rsJ, 0, gJ.Nz, gJ.Nr);
-    if constexpr (P::SPLIT) ej2.init(lds + (size_t)wave * WAVE_DOUBLES, lane, GJ, rsJ, P::NMA, gJ.Nz, gJ.Nr);
     er.init(lds + (size_t)wave * WAVE_DOUBLES, lane, GR, rsR, 0, gR.Nz, gR.Nr);
 
     const long chunk0 = (xcd_block_id() * nwaves + wave) * chunks_per_wave;
@@ -771,13 +760,6 @@ void k_perm_deposit_J_rho(long n, double q, double c_light,
         wave_lds_release();
         ej.reduce(cnt, kz, kr, nb);
         wave_lds_acquire();
-        if constexpr (P::SPLIT) {
-            ej2.stage(act, pc[0], pc[1], pc[2], wj, pc[3], pc[4], pc[5], pc[7], c_light, gJ, beta0, betah,
-                      kz, kr, nb);
-            wave_lds_release();
-            ej2.reduce(cnt, kz, kr, nb);
-            wave_lds_acquire();
-        }
         // ---- pending push_x (expression of k_push_x), attributes written at the sorted slot
         double xj = pc[0], yj = pc[1], zj = pc[2];
         if (act) {
@@ -798,7 +780,6 @@ void k_perm_deposit_J_rho(long n, double q, double c_light,
         wave_lds_acquire();
     }
     ej.flush(false);
-    if constexpr (P::SPLIT) ej2.flush(false);
     er.flush(false);
 }
 
