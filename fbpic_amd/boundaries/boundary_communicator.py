@@ -366,8 +366,10 @@ class BoundaryCommunicator(object):
         t = _capi.torch()
         if self.transport == 'rccl' and all(x is None or x.is_cuda for x in
                                             (send_left, send_right, recv_left, recv_right)):
-            self._exchange_rccl(send_left, send_right, recv_left, recv_right)
-            return
+            self._rccl_communicator()          # first call: creation + handshake (may fall back)
+            if self.transport == 'rccl':
+                self._exchange_rccl(send_left, send_right, recv_left, recv_right)
+                return
         # RCCL moves device buffers directly over xGMI.  Under the gloo backend (CPU tests,
         # or several ranks sharing one GPU) device tensors are staged through the host.
         stage = (dist.get_backend() == 'gloo')
@@ -420,10 +422,48 @@ class BoundaryCommunicator(object):
             box = [bytes(buf.raw)]
             dist.broadcast_object_list(box, src=0)
             comm = ctypes.c_void_p()
-            _capi.check(lib.fb_comm_init(ctypes.c_char_p(box[0]), self.rank, self.size,
-                                         ctypes.byref(comm)), 'fb_comm_init')
-            self._rccl_comm = comm
+            rc = lib.fb_comm_init(ctypes.c_char_p(box[0]), self.rank, self.size, ctypes.byref(comm))
+            self._rccl_comm = comm if rc == 0 else False
+            self._rccl_handshake(init_error=(None if rc == 0 else
+                                             lib.fb_last_error().decode(errors='replace')))
         return self._rccl_comm
+
+    def _rccl_handshake(self, init_error=None):
+        """One message per neighbour carrying (sender rank, side), checked on arrival: a routing
+        mistake of the in-library transport (left / right swapped, same-peer order on a 2-rank
+        ring) is caught at start-up instead of corrupting guard cells.  On a mismatch the
+        exchange falls back to torch.distributed point-to-point (also RCCL) with a warning."""
+        t = _capi.torch()
+        dev = _capi.require_device()
+
+        def msg(side):
+            return t.tensor([float(self.rank), float(side)], dtype=t.float64, device=dev)
+        has_l, has_r = self.left_proc is not None, self.right_proc is not None
+        send_l, send_r = (msg(0) if has_l else None), (msg(1) if has_r else None)
+        recv_l = t.full((2,), -1., dtype=t.float64, device=dev) if has_l else None
+        recv_r = t.full((2,), -1., dtype=t.float64, device=dev) if has_r else None
+        # every rank must have a communicator before anyone posts a message
+        inits = [None] * self.size
+        _dist().all_gather_object(inits, init_error is None)
+        ok = all(inits)
+        try:
+            if ok:
+                self._exchange_rccl(send_l, send_r, recv_l, recv_r)
+            if has_l:
+                ok = ok and recv_l.tolist() == [float(self.left_proc), 1.]
+            if has_r:
+                ok = ok and recv_r.tolist() == [float(self.right_proc), 0.]
+        except _capi.BackendError:
+            ok = False
+        flags = [None] * self.size
+        _dist().all_gather_object(flags, bool(ok))
+        if not all(flags):
+            if self.rank == 0 or init_error:
+                print('fbpic_amd: the in-library RCCL exchange failed its start-up handshake on '
+                      'rank(s) %s%s; using torch.distributed point-to-point instead'
+                      % ([i for i, f in enumerate(flags) if not f],
+                         ' (%s)' % init_error if init_error else ''))
+            self.transport = 'torch'
 
     def _exchange_rccl(self, send_left, send_right, recv_left, recv_right):
         def pb(x):
