@@ -152,11 +152,32 @@ constexpr int G_NOKEY = -0x40000000;
 // Tail of a gather chunk, shared by the gather kernels: (r,t) -> (x,y) rotation of the gathered
 // fields, optional store, Vay push_p with the fields still in registers, push_x, and the cell /
 // rank of the position after the NEXT push_x (see PushArgs).
+// The rank of a particle = the value returned by the per-run atomic on its destination cell.  The
+// round trip of that atomic is not waited for at the end of the chunk: the (cell, rank) pair is
+// written at the start of the NEXT chunk, when the value has long arrived.
+struct RankPending {
+    long i;          // particle index of this lane in the chunk the ranks belong to (-1: none)
+    int cell, base, run0;
+};
+
+__device__ __forceinline__ void rank_commit(RankPending &pd, int lane, const PushArgs &PA)
+{
+    if (!PA.RK.count) return;
+    const int b = __shfl(pd.base, pd.run0);
+    if (pd.i >= 0) {
+        PA.RK.cell[pd.i] = pd.cell;
+        PA.RK.rank[pd.i] = b + (lane - pd.run0);
+    }
+    pd.i = -1;
+}
+
+template <bool DEFER>
 __device__ __forceinline__ void gather_finish(bool act, long i, int lane, double xj, double yj,
         double zj, double cs, double sn, const double *F,
         double *__restrict__ Ex, double *__restrict__ Ey, double *__restrict__ Ez,
         double *__restrict__ Bx, double *__restrict__ By, double *__restrict__ Bz,
         const PushArgs &PA, double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
+        RankPending &pd,
         const double *pre = nullptr)     // ux, uy, uz, inv_gamma already in registers
 {
     int rk_c = -1;
@@ -208,10 +229,15 @@ __device__ __forceinline__ void gather_finish(bool act, long i, int lane, double
             const int len = rest ? (__builtin_ctzll(rest) + 1) : (nact - lane);
             rk_base = atomicAdd(PA.RK.count + rk_c, len);
         }
-        rk_base = __shfl(rk_base, rk_run0);
-        if (act) {
-            PA.RK.cell[i] = rk_c;
-            PA.RK.rank[i] = rk_base + (lane - rk_run0);
+        if constexpr (DEFER) {
+            pd.i = act ? i : -1;
+            pd.cell = rk_c; pd.base = rk_base; pd.run0 = rk_run0;
+        } else {
+            rk_base = __shfl(rk_base, rk_run0);
+            if (act) {
+                PA.RK.cell[i] = rk_c;
+                PA.RK.rank[i] = rk_base + (lane - rk_run0);
+            }
         }
     }
 }
@@ -277,6 +303,7 @@ __global__ __launch_bounds__(256) void k_gather(int Nm_arg, long n,
     // work on chunk ch starts, so their HBM latency hides behind staging + stencil math
     double xn = 0., yn = 0., zn = 0.;
     if (chunk0 * 64 + lane < n) { xn = x[chunk0 * 64 + lane]; yn = y[chunk0 * 64 + lane]; zn = z[chunk0 * 64 + lane]; }
+    RankPending pend = {-1, 0, 0, 0};
     for (int ch = 0; ch < chunks_per_wave; ch++) {
         const long base = (chunk0 + ch) * 64;
         if (base >= n) break;
@@ -293,6 +320,7 @@ __global__ __launch_bounds__(256) void k_gather(int Nm_arg, long n,
             while (zj < PA.wzmin) zj += l_box;
         }
         if (ch + 1 < chunks_per_wave && i + 64 < n) { xn = x[i + 64]; yn = y[i + 64]; zn = z[i + 64]; }
+        rank_commit(pend, lane, PA);            // ranks of the previous chunk
         double rj = 0.;
         if (act) {
             rj = sqrt(xj * xj + yj * yj);
@@ -475,9 +503,10 @@ __global__ __launch_bounds__(256) void k_gather(int Nm_arg, long n,
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
-        gather_finish(act, i, lane, xj, yj, zj, cs, sn, F, Ex, Ey, Ez, Bx, By, Bz, PA,
-                      invdz, zmin, Nz, invdr, rmin, Nr);
+        gather_finish<true>(act, i, lane, xj, yj, zj, cs, sn, F, Ex, Ey, Ez, Bx, By, Bz, PA,
+                            invdz, zmin, Nz, invdr, rmin, Nr, pend);
     }
+    rank_commit(pend, lane, PA);
 }
 
 // ------------------------------------------------------------------ cubic gather on the matrix cores
@@ -610,6 +639,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     const long chunk0 = (xcd_block_id() * nwaves + wave) * chunks_per_wave;
     double xn = 0., yn = 0., zn = 0.;
     if (chunk0 * 64 + lane < n) { xn = x[chunk0 * 64 + lane]; yn = y[chunk0 * 64 + lane]; zn = z[chunk0 * 64 + lane]; }
+    RankPending pend = {-1, 0, 0, 0};
     for (int ch = 0; ch < chunks_per_wave; ch++) {
         const long base = (chunk0 + ch) * 64;
         if (base >= n) break;
@@ -778,8 +808,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         if (gcur >= 0) fold(gcur);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        gather_finish(act, i, lane, xj, yj, zj, cs, sn, F, Ex, Ey, Ez, Bx, By, Bz, PA,
-                      invdz, zmin, Nz, invdr, rmin, Nr, mom);
+        // (ranks not deferred to the next chunk as in k_gather: at 168 VGPRs the four registers of
+        // the pending ranks spill - 5.2 -> 5.6 ms)
+        gather_finish<false>(act, i, lane, xj, yj, zj, cs, sn, F, Ex, Ey, Ez, Bx, By, Bz, PA,
+                             invdz, zmin, Nz, invdr, rmin, Nr, pend, mom);
     }
 }
 
