@@ -86,7 +86,8 @@ int fb_shift_periodic(long n, double *z, double zmin, double zmax, void *stream)
 /* particles/particles.py:703-800 -> gather_field_gpu_{linear,cubic}[_one_mode]
  * (gathering/cuda_methods.py:26,209; cuda_methods_one_mode.py:22,46,216).
  * One launch for any Nm.  grids (HOST array of 6*Nm device pointers): for mode m,
- * grids[6m..6m+5] = Er, Et, Ez, Br, Bt, Bz. */
+ * grids[6m..6m+5] = Er, Et, Ez, Br, Bt, Bz.  (Cubic shape, Nm = 2..4: the stencil sums run as
+ * fp64 MFMA products per group of 16 particles; same results to ~2e-16 of max|F|.) */
 int fb_gather(int shape, int Nm, long n,
               const double *x, const double *y, const double *z, double rmax_gather,
               double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
@@ -465,7 +466,8 @@ int fb_fft_generic_from_records_consume(int Nz, int nfields, int Nr, void *in, l
 /* Self-contained fallback for every other length whose prime factors are <= 31 (rocFFT of
  * ROCm 7.2 refuses some, e.g. Nz = 4416): one Stockham pass per launch through global
  * memory, ping-pong between `out` and a caller-provided scratch slab of the same shape
- * (scratch_stride in complex elements); in == out allowed. */
+ * (scratch_stride in complex elements); in == out allowed.  Lengths 192 x R with a single-pass
+ * R (4416 = 192 x 23) take two sweeps: the 192-point factor in one LDS launch, then radix R. */
 int fb_fft_generic_supported(int Nz);
 int fb_fft_generic(int Nz, long ncols, const void *in, long in_stride, void *out,
                    long out_stride, void *scratch, long scratch_stride, int direction,
