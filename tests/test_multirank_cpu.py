@@ -215,3 +215,40 @@ def test_decomposition_arithmetic_single_process():
     d = comm.generate_damp_array(63, 64, 31)
     assert d.shape == (158,) and np.all(d[:94] == 0.) and np.all(d[126:] == 1.)
     assert np.all(np.diff(d[94:126]) > 0)
+
+
+def test_rccl_handshake_logic(monkeypatch):
+    """Start-up handshake of the in-library transport (boundary_communicator._rccl_handshake),
+    with the exchange replaced by a stand-in peer: correct routing keeps the transport, a peer
+    that swaps its sides or a rank without communicator makes every rank fall back."""
+    from fbpic_amd import _capi
+    from fbpic_amd.boundaries import boundary_communicator as bc
+
+    class FakeDist:
+        def __init__(self, others_ok=True):
+            self.others_ok = others_ok
+
+        def all_gather_object(self, out, obj):
+            out[:] = [obj] + [self.others_ok] * (len(out) - 1)
+
+    class Comm:            # the attributes the handshake reads
+        rank, size, left_proc, right_proc = 1, 4, 0, 2
+        transport = 'rccl'
+        _rccl_handshake = bc.BoundaryCommunicator._rccl_handshake
+
+    monkeypatch.setattr(_capi, 'require_device', lambda: torch.device('cpu'))
+
+    def peer(swap):
+        def exchange(self, send_l, send_r, recv_l, recv_r):
+            # the left neighbour's send-to-right arrives from the left, and vice versa
+            recv_l.copy_(torch.tensor([float(self.left_proc), 0. if swap else 1.], dtype=torch.float64))
+            recv_r.copy_(torch.tensor([float(self.right_proc), 1. if swap else 0.], dtype=torch.float64))
+        return exchange
+
+    for swap, others_ok, init_error, expect in ((False, True, None, 'rccl'), (True, True, None, 'torch'),
+                                                (False, False, None, 'torch'), (False, True, 'no librccl', 'torch')):
+        comm = Comm()
+        comm._exchange_rccl = peer(swap).__get__(comm)
+        monkeypatch.setattr(bc, '_dist', lambda ok=others_ok: FakeDist(ok))
+        comm._rccl_handshake(init_error=init_error)
+        assert comm.transport == expect, (swap, others_ok, init_error)
