@@ -47,6 +47,9 @@ _SIGNATURES = {
     'fb_push_x_sort_deposit_J_rho': (I, [L, I, P, P, P, P, P, P, P, D, D, D, D, D, D, D, I, D, D, I, I, _PP,
                                          _PP, P, P, P, P, Z, I, I, I, D, D, _PP, L, L, _PP, L, L, P, P, P]),
     'fb_permute': (I, [L, P, I, _PP, _PP, P]),
+    'fb_handover_pack': (I, [L, P, I, _PP, P, L, P]),
+    'fb_handover_move': (I, [L, P, P, I, _PP, P]),
+    'fb_handover_append': (I, [L, L, I, _PP, P, L, P]),
     'fb_deposit_rho': (I, [I, I, L, P, P, P, P, D, D, D, I, D, D, I, _PP, L, L, P, P, P, P, P]),
     'fb_deposit_J': (I, [I, I, L, P, P, P, P, D, P, P, P, P, D, D, D, I, D, D, I, _PP, L, L,
                          P, P, P, P, P]),

@@ -128,6 +128,18 @@ def _compact_and_append(t, arrs, n, idx_l, idx_r, recv_l, recv_r):
         tail_free[leave[in_tail] - m] = False
         src = m + t.nonzero(tail_free).reshape(-1)       # survivors sitting in the tail
         dst = leave[~in_tail]                             # holes in the head
+    if dev.type == 'cuda':
+        lib, st = _capi.lib(), _capi.stream()
+        if src is not None and src.numel():
+            _capi.check(lib.fb_handover_move(src.numel(), _capi.ptr(src), _capi.ptr(dst), len(arrs),
+                                             _capi.ptr_array(arrs), st), 'fb_handover_move')
+        out = [_resized(t, a, m, n_new) for a in arrs]
+        for buf, first in ((recv_l, m), (recv_r, m + n_rl)):
+            if buf.shape[1]:
+                assert buf.stride(1) == 1
+                _capi.check(lib.fb_handover_append(buf.shape[1], first, len(out), _capi.ptr_array(out),
+                                                   _capi.ptr(buf), buf.stride(0), st), 'fb_handover_append')
+        return out, n_new
     out = []
     for i, a in enumerate(arrs):
         if src is not None and src.numel():
@@ -164,6 +176,13 @@ def exchange_particles_between_ranks(comm, species, fld, time):
     def pack(idx, proc):
         if proc is None or idx.numel() == 0:
             return t.empty((len(_STATE), 0), dtype=t.float64, device=dev)
+        if dev.type == 'cuda':
+            # every attribute in one launch (the library's hand-over kernels)
+            buf = t.empty((len(_STATE), idx.numel()), dtype=t.float64, device=dev)
+            _capi.check(_capi.lib().fb_handover_pack(idx.numel(), _capi.ptr(idx), len(arrs),
+                                                     _capi.ptr_array(arrs), _capi.ptr(buf),
+                                                     buf.stride(0), _capi.stream()), 'fb_handover_pack')
+            return buf
         return t.stack([a.index_select(0, idx) for a in arrs]).contiguous()
     send_l = pack(idx_l, comm.left_proc)
     send_r = pack(idx_r, comm.right_proc)

@@ -64,6 +64,41 @@ __global__ __launch_bounds__(256) void k_permute(long n, const int *__restrict__
     }
 }
 
+
+// ---- particle hand-over between z-slabs (boundaries/particle_buffer_handling.py) --------
+// The three data movements of a hand-over, every attribute in one launch each:
+//   pack   : buf[k][i] = arr[k][idx[i]]                    (the particles that leave)
+//   move   : arr[k][dst[i]] = arr[k][src[i]]               (holes filled from the tail)
+//   append : arr[k][m + i] = buf[k][i]                     (the arrivals)
+// idx / src / dst are int64 (what the selection produces); src and dst are disjoint sets.
+__global__ __launch_bounds__(256) void k_handover_pack(long n, const long *__restrict__ idx, int nattr,
+                                                       CPtrs16 arr, double *__restrict__ buf, long stride)
+{
+    const long step = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+        const long j = idx[i];
+        for (int k = 0; k < nattr; k++) buf[k * stride + i] = arr.p[k][j];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_handover_move(long n, const long *__restrict__ src,
+                                                       const long *__restrict__ dst, int nattr, Ptrs16 arr)
+{
+    const long step = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+        const long a = src[i], b = dst[i];
+        for (int k = 0; k < nattr; k++) arr.p[k][b] = arr.p[k][a];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_handover_append(long n, long m, int nattr, Ptrs16 arr,
+                                                         const double *__restrict__ buf, long stride)
+{
+    const long step = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step)
+        for (int k = 0; k < nattr; k++) arr.p[k][m + i] = buf[k * stride + i];
+}
+
 // ---- counting sort by cell (fast path of Particles.sort_particles) -----------------
 // The radix sort above is general; the PIC cycle re-sorts an ALMOST sorted stream every
 // step, for which a counting sort needs one pass less over the keys and no permutation
@@ -274,6 +309,42 @@ extern "C" int fb_permute(long n, const int *sorted_idx, int nattr, const double
     hipLaunchKernelGGL(k_permute, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, n,
                        sorted_idx, nattr, a, b);
     FB_CHECK_LAUNCH("fb_permute");
+}
+
+extern "C" int fb_handover_pack(long n, const long *idx, int nattr, const double *const *arrays,
+                                double *buf, long buf_row_stride, void *stream)
+{
+    if (n <= 0 || nattr <= 0) return 0;
+    if (nattr > 16) { set_error("fb_handover_pack", "nattr > 16"); return -1; }
+    CPtrs16 a;
+    for (int k = 0; k < 16; k++) a.p[k] = k < nattr ? arrays[k] : nullptr;
+    hipLaunchKernelGGL(k_handover_pack, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, n, idx,
+                       nattr, a, buf, buf_row_stride);
+    FB_CHECK_LAUNCH("fb_handover_pack");
+}
+
+extern "C" int fb_handover_move(long n, const long *src_idx, const long *dst_idx, int nattr,
+                                double *const *arrays, void *stream)
+{
+    if (n <= 0 || nattr <= 0) return 0;
+    if (nattr > 16) { set_error("fb_handover_move", "nattr > 16"); return -1; }
+    Ptrs16 a;
+    for (int k = 0; k < 16; k++) a.p[k] = k < nattr ? arrays[k] : nullptr;
+    hipLaunchKernelGGL(k_handover_move, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, n,
+                       src_idx, dst_idx, nattr, a);
+    FB_CHECK_LAUNCH("fb_handover_move");
+}
+
+extern "C" int fb_handover_append(long n, long first, int nattr, double *const *arrays,
+                                  const double *buf, long buf_row_stride, void *stream)
+{
+    if (n <= 0 || nattr <= 0) return 0;
+    if (nattr > 16) { set_error("fb_handover_append", "nattr > 16"); return -1; }
+    Ptrs16 a;
+    for (int k = 0; k < 16; k++) a.p[k] = k < nattr ? arrays[k] : nullptr;
+    hipLaunchKernelGGL(k_handover_append, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, n,
+                       first, nattr, a, buf, buf_row_stride);
+    FB_CHECK_LAUNCH("fb_handover_append");
 }
 
 extern "C" size_t fb_bin_sort_workspace_bytes(long n, int ncell)

@@ -192,6 +192,23 @@ int fb_push_x_bin_sort_particles(long n, int ncell, const double *x, const doubl
 int fb_permute(long n, const int *sorted_idx, int nattr,
                const double *const *src, double *const *dst, void *stream);
 
+/* ---- particle hand-over between the z-slabs -------------------------------------------- */
+/* boundaries/particle_buffer_handling.py:17-172 (remove_outside_particles: the send buffers) and
+ * :289-417 (add_buffers_to_particles), as three data movements with every attribute in one
+ * launch each; indices are int64 device arrays, `arrays` a HOST array of nattr device pointers,
+ * `buf` a device buffer of nattr rows of buf_row_stride doubles (the message layout of the
+ * reference: one row per attribute).
+ *   fb_handover_pack   : buf[k][i] = arrays[k][idx[i]], i < n      (the particles that leave)
+ *   fb_handover_move   : arrays[k][dst_idx[i]] = arrays[k][src_idx[i]]  (src, dst disjoint: the
+ *                        holes left in the head are filled with survivors of the tail)
+ *   fb_handover_append : arrays[k][first + i] = buf[k][i], i < n   (the arrivals) */
+int fb_handover_pack(long n, const long *idx, int nattr, const double *const *arrays,
+                     double *buf, long buf_row_stride, void *stream);
+int fb_handover_move(long n, const long *src_idx, const long *dst_idx, int nattr,
+                     double *const *arrays, void *stream);
+int fb_handover_append(long n, long first, int nattr, double *const *arrays,
+                       const double *buf, long buf_row_stride, void *stream);
+
 /* ---- deposition ---------------------------------------------------------------- */
 /* particles/particles.py:893-936 -> deposit_rho_gpu_{linear,cubic}[_one_mode]
  * (deposition/cuda_methods.py:27,465; cuda_methods_one_mode.py).  Particles should be

@@ -1154,6 +1154,43 @@ def test_exchange_rccl_loopback(hip):
     hip.check(lib.fb_comm_destroy(comm), 'fb_comm_destroy')
 
 
+def test_handover_pack_move_append(hip):
+    """fb_handover_pack / _move / _append (the data movements of the particle hand-over, every
+    attribute in one launch) against NumPy indexing."""
+    rng = np.random.default_rng(21)
+    t = hip.torch()
+    n, nattr = 5000, 8
+    a = rng.normal(size=(nattr, n))
+    arrs = [dev(hip, np.concatenate([a[k], np.zeros(300)])) for k in range(nattr)]   # head-room
+    idx = np.sort(rng.choice(n, 400, replace=False)).astype(np.int64)
+    didx = dev(hip, idx)
+    buf = t.zeros((nattr, 450), dtype=t.float64, device='cuda')
+    hip.check(hip.lib().fb_handover_pack(idx.size, hip.ptr(didx), nattr, hip.ptr_array(arrs),
+                                         hip.ptr(buf), buf.stride(0), hip.stream()), 'pack')
+    assert np.array_equal(host(buf[:, :400]), a[:, idx]) and np.all(host(buf[:, 400:]) == 0)
+    # holes among the first m slots are filled with the survivors of the tail
+    m = n - idx.size
+    tail_free = np.ones(n - m, bool)
+    tail_free[idx[idx >= m] - m] = False
+    src = (m + np.nonzero(tail_free)[0]).astype(np.int64)
+    dst = idx[idx < m]
+    assert src.size == dst.size
+    dsrc, ddst = dev(hip, src), dev(hip, dst)          # (kept alive: the launch is asynchronous)
+    hip.check(hip.lib().fb_handover_move(src.size, hip.ptr(dsrc), hip.ptr(ddst), nattr,
+                                         hip.ptr_array(arrs), hip.stream()), 'move')
+    expect = a.copy()
+    expect[:, dst] = a[:, src]
+    got = np.array([host(x)[:n] for x in arrs])
+    assert np.array_equal(got[:, :m], expect[:, :m])
+    assert sorted(got[0, :m].tolist()) == sorted(np.delete(a[0], idx).tolist())     # exactly the stayers
+    arrivals = rng.normal(size=(nattr, 123))
+    darr = dev(hip, arrivals)
+    hip.check(hip.lib().fb_handover_append(123, m, nattr, hip.ptr_array(arrs), hip.ptr(darr),
+                                           123, hip.stream()), 'append')
+    got = np.array([host(x) for x in arrs])
+    assert np.array_equal(got[:, m:m + 123], arrivals) and np.array_equal(got[:, :m], expect[:, :m])
+
+
 def test_guard_buffers_and_damping(hip):
     """fb_guard_buffers (pack / replace / add of the guard rows of a field group, both z ends
     in one launch; boundaries/cuda_methods.py:12-484) and fb_damp_rows (:486-640) against
