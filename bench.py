@@ -147,7 +147,8 @@ def bench_c3(args, torch, world, rank):
 
 _TWO_PASS = ('two-pass MI355X sequence: gather+push_p+push_x(+rank for the sort) one pass, '
              'J deposit+push_x+sort+rho deposit one pass; sanctioned skips inside the timed region: rho_prev '
-             're-deposit after the first step of a call, ')
+             're-deposit after the first step of a call, the diagnostics-only J deposit at the first step of '
+             'a call (no diagnostic is registered), ')
 SEQUENCE_NOTE = {
     False: _TWO_PASS + 'identity iFFT/FFT of E,B on the single periodic domain, gathered E,B '
                        'stored on the last step only',

@@ -132,6 +132,7 @@ class Simulation(object):
         # deposit('J') + push_x(dt/2) + re-sort + deposit('rho_next') as ONE pass over the
         # particles (fb_push_x_sort_deposit_J_rho) when nothing sits between them in step()
         self.fuse_J_into_rho = os.environ.get('FBPIC_AMD_FUSE_J', '1') != '0'
+        self.skip_unobserved_first_J = True
         self._defer_J_ok = False
 
     # -------------------------------------------------------------------- PIC cycle
@@ -182,7 +183,11 @@ class Simulation(object):
                         self.comm.exchange_particles(species, fld, self.time)
                 if need_rho_prev:
                     self.deposit('rho_prev', exchange=(use_true_rho is True))
-            if i_step == 0:
+            if i_step == 0 and (diag_due or self.reference_sequence or not self.skip_unobserved_first_J):
+                # "For the field diagnostics of the first step: deposit J" (reference main.py:
+                # 448-451; not the corrected current).  Nothing else reads it - the J of this step
+                # is erased and deposited again below - so it is only launched when a diagnostic
+                # is due at this iteration (or the reference launch sequence is asked for).
                 self.deposit('J', exchange=True)
             for species in ptcl:
                 species.keep_fields_sorted = True
