@@ -31,16 +31,17 @@ _GPU_SELECTED = False
 def select_gpu_for_this_rank():
     """One rank per GPU (the reference's mpi_select_gpus, fbpic/utils/cuda.py:60-99, called when
     main.py is imported): bind this process to GPU LOCAL_RANK % device_count unless the script
-    already chose a device (a HIP context exists on a device other than 0, or
-    torch.cuda.set_device was called before).  Under the `nccl` (= RCCL) backend two ranks of
-    one host on the same GPU cannot exchange: that is reported here instead of as an RCCL
-    hang.  (gloo - the CPU tests, several ranks sharing the single GPU of a test box - is
-    exempt.)"""
+    already chose a device - i.e. a HIP context exists (torch.cuda.set_device / any device
+    allocation happened before the Simulation was built; set_device(0) counts) - or
+    FBPIC_AMD_NO_GPU_BINDING=1 is set.  Under the `nccl` (= RCCL) backend two ranks of one host
+    on the same GPU cannot exchange: that is reported here instead of as an RCCL hang; the
+    (host, gpu) pairs travel over the rendezvous store (TCP, host side), not over RCCL, which
+    could itself hang in exactly that situation.  (gloo - the CPU tests, several ranks sharing
+    the single GPU of a test box - is exempt.)"""
     global _GPU_SELECTED
     if _GPU_SELECTED:
         return
     _GPU_SELECTED = True
-    import os
     import socket
     t = _capi.torch()
     dist = _dist()
@@ -48,21 +49,38 @@ def select_gpu_for_this_rank():
         return
     ndev = t.cuda.device_count()
     local_rank = os.environ.get('LOCAL_RANK')
-    chosen = t.cuda.current_device() if t.cuda.is_initialized() else None
-    if local_rank is not None and ndev > 1 and chosen in (None, 0):
-        # nothing chose a device yet (or only the default context exists): one GPU per rank
+    opt_out = os.environ.get('FBPIC_AMD_NO_GPU_BINDING', '0') == '1'
+    if local_rank is not None and ndev > 1 and not t.cuda.is_initialized() and not opt_out:
         t.cuda.set_device(int(local_rank) % ndev)
     dev = t.cuda.current_device()
     _capi.check(_capi.lib().fb_set_device(dev), 'fb_set_device')
     if dist.get_backend() == 'nccl':
         mine = (socket.gethostname(), dev)
-        everyone = [None] * dist.get_world_size()
-        dist.all_gather_object(everyone, mine)
+        everyone = _host_side_all_gather(dist, mine)
         if len(set(everyone)) != len(everyone):
             raise _capi.BackendError(
                 'Two ranks are bound to the same GPU %s (all ranks: %s).  Launch one process per '
                 'GPU (torchrun sets LOCAL_RANK) or call torch.cuda.set_device before building the '
                 'Simulation.' % (mine, everyone))
+
+
+def _host_side_all_gather(dist, obj):
+    """all_gather of a small picklable object through the process group's key-value store (the
+    TCP rendezvous): no device communicator is involved.  Falls back to all_gather_object when
+    the group exposes no store (fake groups of the profiling tools)."""
+    import pickle
+    store = None
+    try:
+        store = dist.distributed_c10d._get_default_store()
+    except Exception:
+        store = None
+    if store is None:
+        out = [None] * dist.get_world_size()
+        dist.all_gather_object(out, obj)
+        return out
+    rank, size = dist.get_rank(), dist.get_world_size()
+    store.set('fbpic_amd/gpu_of_rank/%d' % rank, pickle.dumps(obj))
+    return [pickle.loads(store.get('fbpic_amd/gpu_of_rank/%d' % r)) for r in range(size)]
 
 
 class BoundaryCommunicator(object):
@@ -424,9 +442,22 @@ class BoundaryCommunicator(object):
             comm = ctypes.c_void_p()
             rc = lib.fb_comm_init(ctypes.c_char_p(box[0]), self.rank, self.size, ctypes.byref(comm))
             self._rccl_comm = comm if rc == 0 else False
+            if rc == 0:
+                import atexit
+                atexit.register(self.close)
             self._rccl_handshake(init_error=(None if rc == 0 else
                                              lib.fb_last_error().decode(errors='replace')))
         return self._rccl_comm
+
+    def close(self):
+        """Release the library's RCCL communicator (fb_comm_destroy); also runs at interpreter
+        exit.  Safe to call more than once."""
+        comm, self._rccl_comm = self._rccl_comm, None
+        if comm:
+            try:
+                _capi.lib().fb_comm_destroy(comm)
+            except Exception:
+                pass
 
     def _rccl_handshake(self, init_error=None):
         """One message per neighbour carrying (sender rank, side), checked on arrival: a routing

@@ -80,6 +80,38 @@ class Fields(object):
         self.d_spect = None
         self.d_scratch = None
         self.d_src_rec = None
+        self._epoch = 0                  # bumped by every host -> device copy of the grids
+        self._deferred_sources = None    # see defer_sources
+
+    # ---------------------------------------------------------------- deferred J / rho
+    def defer_sources(self, bring_back):
+        """Simulation.step ends with J and rho_prev going from spectral space to the
+        interpolation grid (main.py:572-586): two inverse transforms per call that only matter
+        if something reads interp[m].Jr / Jt / Jz / rho afterwards.  Instead of running them,
+        remember `bring_back` (the callable that does) and take the four attributes off the
+        grids: the first read of one of them (InterpolationGrid.__getattr__), a copy of the
+        grids to the host, or a direct erase / deposit runs it.  The next step() call drops it
+        (the arrays would have been overwritten by then anyway)."""
+        self._deferred_sources = bring_back
+        for g in self.interp:
+            for name in ('Jr', 'Jt', 'Jz', 'rho'):
+                g.__dict__.pop(name, None)
+
+    def _restore_source_views(self):
+        for m in range(self.Nm):
+            for name in ('Jr', 'Jt', 'Jz', 'rho'):
+                setattr(self.interp[m], name, self.d_interp[:, self.interp_index(name, m), :])
+
+    def drop_deferred_sources(self):
+        if self._deferred_sources is not None:
+            self._deferred_sources = None
+            self._restore_source_views()
+
+    def materialize_sources(self):
+        bring_back, self._deferred_sources = self._deferred_sources, None
+        if bring_back is not None:
+            self._restore_source_views()
+            bring_back()
 
     # ---------------------------------------------------------------- slab indexing
     def interp_index(self, name, m):
@@ -120,6 +152,8 @@ class Fields(object):
             self._build_job_tables()
         self.d_interp.copy_(t.from_numpy(hi))
         self.d_spect.copy_(t.from_numpy(hs))
+        self._epoch += 1
+        self._deferred_sources = None
         for m in range(Nm):
             for name in INTERP_FIELDS:
                 setattr(self.interp[m], name, self.d_interp[:, self.interp_index(name, m), :])
@@ -144,6 +178,7 @@ class Fields(object):
         """Copy all grid data back to host NumPy arrays (C-contiguous, like `.get()`)."""
         if not self.data_is_on_gpu:
             return
+        self.materialize_sources()
         hi = self.d_interp.cpu().numpy()
         hs = self.d_spect.cpu().numpy()
         for m in range(self.Nm):
@@ -469,6 +504,8 @@ class Fields(object):
         self._need_gpu()
         if fieldtype not in ('E', 'B', 'J', 'rho', 'J+rho'):
             raise ValueError('Invalid string for fieldtype: %s' % fieldtype)
+        if fieldtype not in ('E', 'B'):
+            self.materialize_sources()       # a direct deposit outside step(): keep the other group
         if fieldtype == 'J+rho':      # adjacent in the slab: both source groups in one launch
             fi, nf = 6 * self.Nm, 4 * self.Nm
         else:

@@ -58,6 +58,16 @@ class InterpolationGrid(object):
         self.d_ruyten_linear_coef = None
         self.d_ruyten_cubic_coef = None
 
+    def __getattr__(self, name):
+        # only reached when the normal lookup fails: Jr / Jt / Jz / rho while Fields.defer_sources
+        # holds them back (they are computed from the spectral fields on first use)
+        if name in ('Jr', 'Jt', 'Jz', 'rho'):
+            owner = self.__dict__.get('_owner')
+            if owner is not None and owner._deferred_sources is not None:
+                owner.materialize_sources()
+                return self.__dict__[name]
+        raise AttributeError(name)
+
     @property
     def z(self):
         return self.zmin + (0.5 + np.arange(self.Nz)) * self.dz

@@ -134,6 +134,15 @@ class Simulation(object):
         self.fuse_J_into_rho = os.environ.get('FBPIC_AMD_FUSE_J', '1') != '0'
         self.skip_unobserved_first_J = True
         self._defer_J_ok = False
+        # State carried from one step() call to the next while everything stays on the GPU and
+        # nobody touched the particle / field tensors in between (torch version counters, see
+        # _carry_signature): the first iteration of the next call then runs like an interior
+        # one - no re-transform of E, B, no particle exchange / rho_prev re-deposit "because
+        # the user may have changed the particles" (reference main.py:435-449), and J / rho
+        # come back to the interpolation grid only if something reads them (Fields.defer_sources).
+        # `for _ in range(n): sim.step(1)` then costs what sim.step(n) costs.
+        self.carry_state_between_calls = os.environ.get('FBPIC_AMD_CARRY', '1') != '0'
+        self._carry = None
 
     # -------------------------------------------------------------------- PIC cycle
     def step(self, N=1, correct_currents=True, correct_divE=False, use_true_rho=False,
@@ -153,26 +162,63 @@ class Simulation(object):
         was_on_gpu = fld.data_is_on_gpu and all(s.data_is_on_gpu for s in ptcl)
         send_data_to_gpu(self)
         self._in_step = True
+        carried = (was_on_gpu and self._carry is not None and N > 0
+                   and self._carry == self._carry_signature())
+        self._carry = None
+        self._last_call_carried = carried
         try:
-            self._step_loop(N, correct_currents, use_true_rho, move_positions, move_momenta)
+            self._step_loop(N, correct_currents, use_true_rho, move_positions, move_momenta,
+                            carried=carried)
         finally:
             self._in_step = False
         if not was_on_gpu:
             receive_data_from_gpu(self)
+        elif self.carry_state_between_calls and N > 0:
+            self._carry = self._carry_signature()
 
-    def _step_loop(self, N, correct_currents, use_true_rho, move_positions, move_momenta):
+    def _carry_signature(self):
+        """What must be unchanged for the device state left by one step() call to be the state
+        the next call starts from: the tensors themselves (address + torch version counter: any
+        in-place modification through the public attributes bumps it; this package's kernels
+        write through raw pointers and do not), the host <-> device epochs, the particle
+        numbers, the grid position.  Only for z-periodic runs without external hooks: an open
+        boundary is damped again at the start of every call in the reference (main.py:403-411),
+        which this keeps."""
+        fld, comm = self.fld, self.comm
+        if not self.carry_state_between_calls or comm.nz_damp != 0 or comm.moving_win is not None \
+                or self.use_galilean or self.external_fields or self.mirrors or self.laser_antennas \
+                or self.reference_sequence or fld.current_correction == 'cross-deposition':
+            return None
+        if not (fld.data_is_on_gpu and all(s.data_is_on_gpu for s in self.ptcl)):
+            return None
+        sig = [self.iteration, fld._epoch, fld.d_interp.data_ptr(), fld.d_interp._version,
+               fld.d_spect.data_ptr(), fld.d_spect._version, fld.interp[0].zmin,
+               comm._zmin_global_domain, len(self.ptcl)]
+        for sp in self.ptcl:
+            sig.append((id(sp), sp.Ntot, sp._epoch, sp._pending_push, sp._pending_J is None))
+            for k in ('x', 'y', 'z', 'ux', 'uy', 'uz', 'w', 'inv_gamma'):
+                a = getattr(sp, k)
+                sig.append((a.data_ptr(), a._version))
+        return tuple(sig)
+
+    def _step_loop(self, N, correct_currents, use_true_rho, move_positions, move_momenta,
+                   carried=False):
         ptcl, fld, dt = self.ptcl, self.fld, self.dt
-        # E and B go to spectral space once; afterwards only spectral -> interp
-        self.comm.exchange_fields(fld.interp, 'EB', 'replace')
-        self.comm.damp_EB_open_boundary(fld.interp)
-        fld.interp2spect('EB')
+        # J / rho of the previous call that nobody read are not brought back any more
+        fld.drop_deferred_sources()
+        if not carried:
+            # E and B go to spectral space once; afterwards only spectral -> interp
+            self.comm.exchange_fields(fld.interp, 'EB', 'replace')
+            self.comm.damp_EB_open_boundary(fld.interp)
+            fld.interp2spect('EB')
         for i_step in range(N):
+            first = (i_step == 0 and not carried)    # "the user may have changed the particles"
             diag_due = any(getattr(d, 'due', lambda it: True)(self.iteration) for d in self.diags)
             fused = (self.fuse_gather_push and move_momenta and move_positions
                      and not self.external_fields and not diag_due)
             wrap_z = None
-            if self.iteration % self.comm.exchange_period == 0 or i_step == 0:
-                need_rho_prev = (i_step == 0 or self.comm.n_guard != 0
+            if self.iteration % self.comm.exchange_period == 0 or first:
+                need_rho_prev = (first or self.comm.n_guard != 0
                                  or self.redeposit_rho_prev_every_step or use_true_rho)
                 if fused and not need_rho_prev and self.comm.n_guard == 0:
                     # single periodic domain: the wrap of z into the box rides along in the
@@ -183,7 +229,7 @@ class Simulation(object):
                         self.comm.exchange_particles(species, fld, self.time)
                 if need_rho_prev:
                     self.deposit('rho_prev', exchange=(use_true_rho is True))
-            if i_step == 0 and (diag_due or self.reference_sequence or not self.skip_unobserved_first_J):
+            if first and (diag_due or self.reference_sequence or not self.skip_unobserved_first_J):
                 # "For the field diagnostics of the first step: deposit J" (reference main.py:
                 # 448-451; not the corrected current).  Nothing else reads it - the J of this step
                 # is erased and deposited again below - so it is only launched when a diagnostic
@@ -297,6 +343,17 @@ class Simulation(object):
             self.iteration += 1
             for checkpoint in self.checkpoints:
                 checkpoint.write(self.iteration)
+        if self.carry_state_between_calls and self.comm.size == 1 and not self.reference_sequence:
+            # J and rho go back to the interpolation grid when something reads them there
+            # (interp[m].Jr ..., receive_fields_from_gpu, a direct deposit), not at every call
+            fld.defer_sources(self._sources_to_interp)
+        else:
+            self._sources_to_interp()
+
+    def _sources_to_interp(self):
+        """Tail of step (main.py:572-586): J and rho_prev from spectral space to the
+        interpolation grid, guard cells added if that has not happened."""
+        fld = self.fld
         fld.spect2interp('J')
         if (not fld.exchanged_source['J']) and (self.comm.size > 1):
             self.comm.exchange_fields(fld.interp, 'J', 'add')

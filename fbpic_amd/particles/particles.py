@@ -116,6 +116,7 @@ class Particles(object):
         self._sort_ws = None
         self._counts_clean = False
         self._cell_size = None
+        self._epoch = 0               # bumped by every host -> device copy of the arrays
 
     # ---------------------------------------------------------------- host <-> device
     def _alloc_device_helpers(self):
@@ -189,6 +190,7 @@ class Particles(object):
         self._moved_since_sort = np.inf
         self._pending_push = None
         self._prerank = None
+        self._epoch += 1
         self.data_is_on_gpu = True
 
     def receive_particles_from_gpu(self):
@@ -444,18 +446,21 @@ class Particles(object):
         names = list(_STATE) + (list(_FIELDS) if self.keep_fields_sorted else [])
         src = [getattr(self, k) for k in names]
         dst = self._alt[:len(names)]
+        pj = self._pending_J
+        if pj is not None and (pj[0] is not fld or pj[1] != records):
+            # different target: J on its own, then as usual.  That deposit may re-sort the
+            # particles (new order, workspace overwritten): it goes BEFORE the ranks of the
+            # pending push are looked at, and flush_pending_J / sort_particles drop them
+            self.flush_pending_J()
+            pj = None
+        self._pending_J = None
         pend, self._pending_push = self._pending_push, None
-        preranked = int(self._prerank == pend)
+        preranked = int(pend is not None and self._prerank == pend)
         self._prerank = None
         suffix = 'linear' if self.particle_shape == 'linear' else 'cubic'
         ruy0 = getattr(grid[0], 'd_ruyten_%s_coef' % suffix)
         ruyh = getattr(grid[1 if Nm > 1 else 0], 'd_ruyten_%s_coef' % suffix)
         views = fld.record_views('rho') if records else [grid[m].rho for m in range(Nm)]
-        pj = self._pending_J
-        if pj is not None and (pj[0] is not fld or pj[1] != records):
-            self.flush_pending_J()              # different target: J on its own, then as usual
-            pj = None
-        self._pending_J = None
         if pj is not None:
             if records:
                 jviews = fld.record_views('J')
