@@ -41,7 +41,9 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (datasheet)
 
-# algorithmic work per launch: name -> (bound, function(args) -> bytes|flops)
+# ALGORITHMIC work per launch, strictly as SURVEY.md 8d counts it: the union rule (8 B x distinct
+# per-particle arrays read + distinct arrays written by the operations the kernel fuses).
+# name -> (bound, function(args) -> bytes|flops)
 WORK = {
     'fb_push_x': ('hbm', lambda a: 80.0 * a[0]),
     'fb_push_p': ('hbm', lambda a: 112.0 * a[0]),
@@ -49,26 +51,20 @@ WORK = {
     # fused gather+push_p+push_x: 56 B read + 56 B written (+ 48 B when E,B are stored for an
     # observer: last iteration of a step() call), union rule of SURVEY.md 8d
     'fb_gather_push': ('hbm', lambda a: (160.0 if a[19] is not None else 112.0) * a[2]),
-    # ... + cell and rank of the next sort written (8 B): 120 B, the first pass of the two-pass
-    # step of SURVEY.md 8d
-    'fb_gather_push_rank_next': ('hbm', lambda a: (168.0 if a[19] is not None else 120.0) * a[2]),
+    # the first pass of the two-pass step: the same 112 B (the 8 B of cell + rank it also writes
+    # are sort bytes: OVERHEAD below)
+    'fb_gather_push_rank_next': ('hbm', lambda a: (160.0 if a[19] is not None else 112.0) * a[2]),
     'fb_deposit_rho': ('hbm', lambda a: 32.0 * a[2]),
     'fb_deposit_J': ('hbm', lambda a: 64.0 * a[2]),
-    # J deposition + cell/rank of the pushed position for the next sort: 64 B read + 8 B written
-    'fb_deposit_J_rank_next': ('hbm', lambda a: 72.0 * a[2]),
-    # push_x folded into the counting sort (pre-ranked): 8 arrays + cell + rank read, 8 arrays +
-    # sorted cell + permutation written (sort = implementation overhead)
-    'fb_push_x_bin_sort_particles': ('hbm', lambda a: 144.0 * a[0]),
-    # destination-ordered push_x + sort + rho deposition: permutation (4 B) + 8 arrays read,
-    # 8 arrays written (union rule; building the permutation is sort overhead, as above)
-    'fb_push_x_sort_deposit_rho': ('hbm', lambda a: 132.0 * a[0]),
-    # the same pass with the J deposition riding along: same bytes (the second pass of the
-    # two-pass step: 4 B permutation + 8 arrays read, 8 arrays written)
-    'fb_push_x_sort_deposit_J_rho': ('hbm', lambda a: 132.0 * a[0]),
+    'fb_deposit_J_rank_next': ('hbm', lambda a: 64.0 * a[2]),
+    # push_x folded into the counting sort: the push_x bytes
+    'fb_push_x_bin_sort_particles': ('hbm', lambda a: 80.0 * a[0]),
+    # destination-ordered push_x + sort + rho deposition: x,y,z,ux,uy,uz,inv_gamma,w read, x,y,z
+    # written = 64 R + 24 W ("two-pass fused lower bound 120 + (64 R + 24 W)")
+    'fb_push_x_sort_deposit_rho': ('hbm', lambda a: 88.0 * a[0]),
+    # the same pass with the J deposition riding along: same distinct arrays
+    'fb_push_x_sort_deposit_J_rho': ('hbm', lambda a: 88.0 * a[0]),
     'fb_zfft': ('hbm', lambda a: 32.0 * a[0] * a[1]),
-    'fb_cell_index': ('hbm', lambda a: 32.0 * a[0]),
-    'fb_sort_by_cell': ('hbm', lambda a: 16.0 * a[0]),          # one read+write of (key, value)
-    'fb_permute': ('hbm', lambda a: (16.0 * a[2] + 4.0) * a[0]),
     'fb_shift_periodic': ('hbm', lambda a: 8.0 * a[0]),
     'fb_hankel': ('mfma', lambda a: 4.0 * a[7] * a[8] * a[8] * a[0]),
     # (p | m) formed in the operand load: same GEMM work per job
@@ -77,6 +73,23 @@ WORK = {
     # pair jobs carry two products
     'fb_hankel_pm_to_rt': ('mfma', lambda a: 4.0 * a[10] * a[11] * a[11]
                            * sum(2 if a[2][j] else 1 for j in range(a[0]))),
+}
+# Sort / permutation bytes the same launches move ("implementation overhead, not algorithmic
+# work - report separately"): reported as `overhead_bytes` per launch and in
+# `frac_incl_overhead`, never in `frac`.
+OVERHEAD = {
+    'fb_gather_push_rank_next': lambda a: 8.0 * a[2],          # cell + rank of the next sort, written
+    'fb_deposit_J_rank_next': lambda a: 8.0 * a[2],
+    # the sort pass re-writes the 5 arrays the push does not change (40 B) + reads cell and rank
+    # (8 B) + writes sorted cell and permutation (8 B) + reads w (8 B)
+    'fb_push_x_bin_sort_particles': lambda a: 64.0 * a[0],
+    # permutation index read (4 B) + ux,uy,uz,inv_gamma,w re-written at the sorted slot (40 B)
+    'fb_push_x_sort_deposit_rho': lambda a: 44.0 * a[0],
+    'fb_push_x_sort_deposit_J_rho': lambda a: 44.0 * a[0],
+    'fb_cell_index': lambda a: 32.0 * a[0],
+    'fb_sort_by_cell': lambda a: 16.0 * a[0],
+    'fb_permute': lambda a: (16.0 * a[2] + 4.0) * a[0],
+    'fb_bin_sort_particles': lambda a: 144.0 * a[0],
 }
 
 
@@ -140,7 +153,7 @@ def bench_c3(args, torch, world, rank):
     }
     if kern:
         ceil = measured_ceilings(torch)
-        out['roofline'], out['kernels'] = roofline(kern, ceil, False)
+        out['roofline'], out['kernels'] = roofline(kern, ceil, 'c3')
         out['measured_ceilings'] = ceil
     print(json.dumps(out))
 
@@ -298,7 +311,7 @@ def main():
     }
     if kern:
         ceil = measured_ceilings(torch)
-        out['roofline'], out['kernels'] = roofline(kern, ceil, config_name(args, ppc, world) == 'C2')
+        out['roofline'], out['kernels'] = roofline(kern, ceil, {'C2': True, 'C5': 'c5'}.get(config_name(args, ppc, world), False))
         out['measured_ceilings'] = ceil
     if cpu_base:
         out['cpu_baseline'] = cpu_base
@@ -343,12 +356,16 @@ def roofline(kern, ceil=None, profiled_workload=True):
         ms = [r[0] for r in recs]
         tot = sum(ms)
         ent = {'launches': len(ms), 'mean_ms': tot / max(len(ms), 1), 'total_ms': tot}
+        over = sum(OVERHEAD[name](r[1]) for r in recs) if name in OVERHEAD else 0.
         if name in WORK:
             bound, fn = WORK[name]
             work = sum(fn(r[1]) for r in recs)
             if bound == 'hbm':
                 ent.update(bound='hbm', achieved=work / (tot * 1e-3) / 1e9, unit='GB/s',
-                           peak=HBM_PEAK_GBS)
+                           peak=HBM_PEAK_GBS, algorithmic_bytes=work / len(ms))
+                if over:
+                    ent['overhead_bytes'] = over / len(ms)
+                    ent['frac_incl_overhead'] = (work + over) / (tot * 1e-3) / 1e9 / HBM_PEAK_GBS
             else:
                 ent.update(bound='mfma', achieved=work / (tot * 1e-3) / 1e12, unit='TFLOP/s',
                            peak=FP64_MFMA_PEAK_TFLOPS)
@@ -356,6 +373,9 @@ def roofline(kern, ceil=None, profiled_workload=True):
             if ceil:
                 meas = ceil['triad_GBs'] if bound == 'hbm' else ceil['dgemm_4096_TFLOPs']
                 ent['frac_of_measured'] = ent['achieved'] / meas
+        elif over:
+            # pure sort launches: no algorithmic work, only overhead bytes
+            ent.update(overhead_bytes=over / len(ms), overhead_GBs=over / (tot * 1e-3) / 1e9)
         table[name] = ent
     cand = sorted((n for n in table if 'frac' in table[n]), key=lambda n: -table[n]['total_ms'])
     dom = cand[0]
@@ -373,10 +393,20 @@ def roofline(kern, ceil=None, profiled_workload=True):
     roof = {'kernel': dom, 'bound': d['bound'], 'achieved': d['achieved'], 'peak': d['peak'],
             'unit': d['unit'], 'frac': d['frac'], 'traffic': None,
             'mean_launch_ms': d['mean_ms']}
-    if 'frac_of_measured' in d:
-        roof['frac_of_measured'] = d['frac_of_measured']
-    if profiled_workload:   # the PMC passes under profiles/ are of the default (C2) command
-        roof.update(pmc_traffic(dom))
+    for k in ('frac_of_measured', 'algorithmic_bytes', 'overhead_bytes', 'frac_incl_overhead'):
+        if k in d:
+            roof[k] = d[k]
+    if profiled_workload:   # tag of the PMC passes under profiles/ for this workload ('' = C2)
+        roof.update(pmc_traffic(dom, '' if profiled_workload is True else profiled_workload))
+    # the other particle pass of the two-pass step next to it (the target names gather/push)
+    for n in ('fb_gather_push_rank_next', 'fb_gather_push'):
+        if n in table and n != dom and 'frac' in table[n]:
+            roof['gather_push'] = {k: table[n][k] for k in
+                                   ('achieved', 'frac', 'frac_of_measured', 'algorithmic_bytes',
+                                    'overhead_bytes', 'frac_incl_overhead', 'mean_ms') if k in table[n]}
+            if profiled_workload:
+                roof['gather_push'].update(pmc_traffic(n, '' if profiled_workload is True else profiled_workload))
+            break
     # the Hankel GEMM (the MFMA-bound kernel of the path) next to it: all launches together
     hk = [table[n] for n in table if n.startswith('fb_hankel') and 'achieved' in table[n]]
     if hk:
@@ -389,7 +419,8 @@ def roofline(kern, ceil=None, profiled_workload=True):
         if ceil:
             roof['hankel']['frac_of_measured'] = roof['hankel']['achieved'] / ceil['dgemm_4096_TFLOPs']
     compact = {n: {k: (round(v, 5) if isinstance(v, float) else v) for k, v in e.items()
-                   if k in ('launches', 'mean_ms', 'achieved', 'unit', 'frac', 'frac_of_measured')}
+                   if k in ('launches', 'mean_ms', 'achieved', 'unit', 'frac', 'frac_of_measured',
+                            'frac_incl_overhead', 'overhead_GBs')}
                for n, e in table.items()}
     return roof, compact
 
@@ -397,7 +428,7 @@ def roofline(kern, ceil=None, profiled_workload=True):
 # entry point -> substrings identifying its dominant device kernel in the rocprofv3 summaries
 _KERNEL_OF = {
     'fb_gather_push': ('k_gather<',), 'fb_gather': ('k_gather<',),
-    'fb_gather_push_rank_next': ('k_gather<',),
+    'fb_gather_push_rank_next': ('k_gather',),
     'fb_push_x_sort_deposit_J_rho': ('k_perm_deposit_J_rho<',),
     'fb_deposit_J_rank_next': ('k_deposit<', ', 3, ', 'true, true>'),
     'fb_deposit_J': ('k_deposit<', ', 3, '), 'fb_deposit_rho': ('k_deposit<', ', 1, '),
@@ -407,17 +438,23 @@ _KERNEL_OF = {
 }
 
 
-def pmc_traffic(entry):
+def pmc_traffic(entry, tag=''):
     """HBM-side bytes per launch of the dominant kernel from the PMC passes committed under
     profiles/ (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate runs of this same
-    command: counters cannot be collected inside the timed run).  FETCH_SIZE is doubled as
-    MI355X_MICROARCH.md prescribes for gfx950 (calibrated here on fb_push_x: 2 x FETCH_SIZE =
-    56 B / particle exactly); both counters are in KiB."""
+    command: counters cannot be collected inside the timed run).  `tag`: '' for the default (C2)
+    command, 'c5' / 'c3' for the passes of --config C5 / C3 (profiles/rNN_vM_<tag>_pmc_*.csv).
+    FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (calibrated here on
+    fb_push_x: 2 x FETCH_SIZE = 56 B / particle exactly); both counters are in KiB."""
     import csv
     import glob
+    import re
     keys = _KERNEL_OF.get(entry)
-    fetch = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_fetch_size.csv')))
-    write = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_write_size.csv')))
+    mid = ('_%s' % tag) if tag else ''
+    pat = re.compile(r'^r\d+_v\d+%s_pmc_(fetch|write)_size\.csv$' % mid)
+    names = sorted(os.path.basename(f) for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_*_size.csv'))
+                   if pat.match(os.path.basename(f)))
+    fetch = [os.path.join(ROOT, 'profiles', f) for f in names if 'fetch' in f]
+    write = [os.path.join(ROOT, 'profiles', f) for f in names if 'write' in f]
     if not keys or not fetch or not write:
         return {}
 
