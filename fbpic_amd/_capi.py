@@ -50,6 +50,11 @@ _SIGNATURES = {
     'fb_handover_pack': (I, [L, P, I, _PP, P, L, P]),
     'fb_handover_move': (I, [L, P, P, I, _PP, P]),
     'fb_handover_append': (I, [L, L, I, _PP, P, L, P]),
+    'fb_handover_select_pack': (I, [L, P, P, L, L, L, L, D, D, I, _PP, L, L, L, P, P, P, P, P, P]),
+    'fb_handover_recv_counts': (I, [P, P, P, P]),
+    'fb_handover_workspace_bytes': (Z, [L]),
+    'fb_handover_compact': (I, [L, L, P, L, P, I, _PP, P, Z, P]),
+    'fb_handover_append_shift': (I, [L, L, I, _PP, P, L, I, D, P]),
     'fb_deposit_rho': (I, [I, I, L, P, P, P, P, D, D, D, I, D, D, I, _PP, L, L, P, P, P, P, P]),
     'fb_deposit_J': (I, [I, I, L, P, P, P, P, D, P, P, P, P, D, D, D, I, D, D, I, _PP, L, L,
                          P, P, P, P, P]),
@@ -195,7 +200,7 @@ class _TimedLib(object):
     def __getattr__(self, name):
         f = getattr(self._real, name)
         if not name.startswith('fb_') or name in ('fb_last_error', 'fb_abi_version',
-                                                  'fb_sort_workspace_bytes', 'fb_bin_sort_workspace_bytes', 'fb_fft_plan_create',
+                                                  'fb_sort_workspace_bytes', 'fb_bin_sort_workspace_bytes', 'fb_handover_workspace_bytes', 'fb_fft_plan_create',
                                                   'fb_fft_plan_destroy', 'fb_sync', 'fb_set_device', 'fb_comm_unique_id', 'fb_comm_init', 'fb_comm_destroy', 'fb_zfft_supported', 'fb_fft_generic_supported', 'fb_fft_generic_from_records_supported'):
             return f
         t = torch()

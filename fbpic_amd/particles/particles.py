@@ -117,6 +117,9 @@ class Particles(object):
         self._counts_clean = False
         self._cell_size = None
         self._epoch = 0               # bumped by every host -> device copy of the arrays
+        # `prefix_sum` is the exact inclusive per-cell count of the arrays as they are now (set by
+        # the sorts, dropped when particles are added / removed)
+        self._prefix_valid = False
 
     # ---------------------------------------------------------------- host <-> device
     def _alloc_device_helpers(self):
@@ -187,6 +190,7 @@ class Particles(object):
         if self.cell_idx is None or self.cell_idx.shape[0] != self.Ntot:
             self._alloc_device_helpers()
         self.sorted = False
+        self._prefix_valid = False
         self._moved_since_sort = np.inf
         self._pending_push = None
         self._prerank = None
@@ -215,6 +219,7 @@ class Particles(object):
     def on_particle_number_changed(self):
         """Re-size the device helpers after particles were added / removed."""
         self.sorted = False
+        self._prefix_valid = False
         self._moved_since_sort = np.inf
         self._prerank = None
         if self.data_is_on_gpu and self.x.is_cuda:
@@ -407,6 +412,7 @@ class Particles(object):
                     self._sort_ws.shape[0], st)
                 _capi.check(rc, 'fb_bin_sort_particles')
             self._counts_clean = True    # the scatter pass leaves the counters zeroed
+            self._prefix_valid = True
             for i, k in enumerate(names):
                 setattr(self, k, dst[i])
                 self._alt[i] = src[i]
@@ -432,6 +438,7 @@ class Particles(object):
             self.cell_idx, self._cell_idx_alt = self._cell_idx_alt, self.cell_idx
             self.sorted_idx, self._sorted_idx_alt = self._sorted_idx_alt, self.sorted_idx
         self.prefix_sum_shift = 0
+        self._prefix_valid = True
         self._cell_size = (g0.dz, g0.dr)
         self._moved_since_sort = 0.
         self.rearrange_particle_arrays()
@@ -491,6 +498,7 @@ class Particles(object):
                 views[0].stride(0), views[0].stride(1), p(ruy0), p(ruyh), st)
             _capi.check(rc, 'fb_push_x_sort_deposit_rho')
         self._counts_clean = True
+        self._prefix_valid = True
         for i, k in enumerate(names):
             setattr(self, k, dst[i])
             self._alt[i] = src[i]

@@ -30,6 +30,8 @@ extern "C" {
 #define FB_SHAPE_LINEAR 1
 #define FB_SHAPE_CUBIC 3
 #define FB_MAX_MODES 8
+/* doubles in front of the attribute rows of a particle hand-over message ([0] = particle count) */
+#define FB_HANDOVER_HEADER 8
 
 /* ---- runtime ---------------------------------------------------------------- */
 int fb_abi_version(void);
@@ -208,6 +210,40 @@ int fb_handover_move(long n, const long *src_idx, const long *dst_idx, int nattr
                      double *const *arrays, void *stream);
 int fb_handover_append(long n, long first, int nattr, double *const *arrays,
                        const double *buf, long buf_row_stride, void *stream);
+
+/* The same hand-over with the SELECTION in the library and every count on the device
+ * (boundaries/particle_buffer_handling.py:178-236 is the reference's GPU cut; the ownership rule
+ * here is the one of its CPU path, :58-172: left if z < zbox_min, right if z > zbox_max).
+ *
+ * fb_handover_select_pack: one launch selects the leaving particles of both sides, writes their
+ *   indices (int32, at most idx_cap per side) and packs them into the two fixed-size messages
+ *   `send_left` / `send_right` = FB_HANDOVER_HEADER doubles ([0] = number selected, which may
+ *   exceed the capacity: then only the first `cap` are packed and the caller sends the rest in a
+ *   second message) followed by nattr rows of `cap` doubles.  A NULL message = open end (the
+ *   leavers are dropped).  With `prefix_sum` (cell-sorted arrays, inclusive per-cell prefix sum)
+ *   only the particles before the offset prefix_sum[cut1] and after prefix_sum[cut2] are tested
+ *   (everything before prefix_sum[cut0] / after prefix_sum[cut3] leaves without a test; a cut
+ *   of -1 stands for offset 0); with prefix_sum = NULL every particle is tested.
+ *   counts (device, 8 longs, zeroed here): [0] n_left, [1] n_right.
+ * fb_handover_recv_counts: counts[2], counts[3] = header counts of the two received messages.
+ * fb_handover_compact: removes the listed particles from the length-n arrays in O(n_left + n_right):
+ *   the holes below n - n_left - n_right are filled with the survivors above it (any order).
+ * fb_handover_append_shift: fb_handover_append with `shift` added to attribute `shift_attr`
+ *   (the periodic wrap of z across the ends of the global box, :401-417); shift_attr < 0: none. */
+int fb_handover_select_pack(long n, const double *z, const int *prefix_sum,
+                            long cut0, long cut1, long cut2, long cut3,
+                            double zbox_min, double zbox_max, int nattr,
+                            const double *const *arrays, long cap_left, long cap_right, long idx_cap,
+                            double *send_left, double *send_right, int *idx_left, int *idx_right,
+                            long *counts, void *stream);
+int fb_handover_recv_counts(const double *recv_left, const double *recv_right, long *counts,
+                            void *stream);
+size_t fb_handover_workspace_bytes(long max_leavers);
+int fb_handover_compact(long n, long n_left, const int *idx_left, long n_right, const int *idx_right,
+                        int nattr, double *const *arrays, void *workspace, size_t workspace_bytes,
+                        void *stream);
+int fb_handover_append_shift(long n, long first, int nattr, double *const *arrays, const double *buf,
+                             long buf_row_stride, int shift_attr, double shift, void *stream);
 
 /* ---- deposition ---------------------------------------------------------------- */
 /* particles/particles.py:893-936 -> deposit_rho_gpu_{linear,cubic}[_one_mode]

@@ -17,7 +17,11 @@ def loopback(self, send_left, send_right, recv_left, recv_right, skip_empty=Fals
         if recv is None or send is None or recv.numel() == 0:
             continue
         recv.copy_(send)
-        if recv.dim() == 2 and recv.shape[0] == 8 and recv.dtype == torch.float64:
+        caps = getattr(self, '_handover_caps', None)
+        if caps is not None and recv.dim() == 1:         # fixed-size hand-over message
+            cap = (recv.numel() - 8) // 8
+            recv[8 + 2 * cap:8 + 3 * cap] += L_local
+        elif recv.dim() == 2 and recv.shape[0] == 8 and recv.dtype == torch.float64:
             recv[2] += L_local
 bc.BoundaryCommunicator.exchange_domains = loopback
 orig = pbh.exchange_particles_between_ranks

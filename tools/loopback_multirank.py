@@ -51,7 +51,11 @@ def main():
                 if recv is None or send is None or recv.numel() == 0:
                     continue
                 recv.copy_(send)
-                if recv.dim() == 2 and recv.shape[0] == 8 and recv.dtype == torch.float64:
+                caps = getattr(self, '_handover_caps', None)
+                if caps is not None and recv.dim() == 1:     # fixed-size hand-over message
+                    cap = (recv.numel() - 8) // 8
+                    recv[8 + 2 * cap:8 + 3 * cap] += L_local     # z row: re-enter on the other side
+                elif recv.dim() == 2 and recv.shape[0] == 8 and recv.dtype == torch.float64:
                     recv[2] += L_local      # particle payload: re-enter on the other side
         bc.BoundaryCommunicator.exchange_domains = loopback
     world = 1 if a.single else 2
