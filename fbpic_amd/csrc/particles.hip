@@ -139,6 +139,12 @@ struct PushArgs {
     // cell + rank of the position after the NEXT push_x, for the counting sort that follows it
     // (fb_gather_push_rank_next); RK.count == null -> off
     RankNext RK;
+    // Restriction of the pass to a contiguous range [*range_lo, *range_hi) of the (cell-sorted)
+    // particle arrays (range_mode 1) or to its complement (2); the bounds are read on the
+    // device - entries of the per-cell prefix sum - so that no offset travels to the host.
+    // A null pointer stands for 0.  range_mode 0: every particle (fb_gather_push_range).
+    const int *range_lo, *range_hi;
+    int range_mode;
 };
 
 __device__ __forceinline__ double2 ldc(const cplx *p) { return *(const double2 *)p; }
@@ -304,11 +310,28 @@ __global__ __launch_bounds__(256) void k_gather(int Nm_arg, long n,
     double xn = 0., yn = 0., zn = 0.;
     if (chunk0 * 64 + lane < n) { xn = x[chunk0 * 64 + lane]; yn = y[chunk0 * 64 + lane]; zn = z[chunk0 * 64 + lane]; }
     RankPending pend = {-1, 0, 0, 0};
+    long r_lo = 0, r_hi = n;
+    if (PA.range_mode) {
+        r_lo = PA.range_lo ? (long)*PA.range_lo : 0;
+        r_hi = PA.range_hi ? (long)*PA.range_hi : 0;
+        if (r_hi < r_lo) r_hi = r_lo;
+    }
     for (int ch = 0; ch < chunks_per_wave; ch++) {
         const long base = (chunk0 + ch) * 64;
         if (base >= n) break;
         const long i = base + lane;
-        const bool act = i < n;
+        bool act = i < n;
+        if (PA.range_mode) {
+            const bool in_range = i >= r_lo && i < r_hi;
+            act = act && (PA.range_mode == 1 ? in_range : !in_range);
+            // chunks without a particle of this pass (wave-uniform test)
+            const bool none = PA.range_mode == 1 ? (base + 64 <= r_lo || base >= r_hi)
+                                                 : (base >= r_lo && base + 64 <= r_hi);
+            if (none) {
+                if (ch + 1 < chunks_per_wave && i + 64 < n) { xn = x[i + 64]; yn = y[i + 64]; zn = z[i + 64]; }
+                continue;
+            }
+        }
         double cs = 1., sn = 0., Sz[S], Sr[S];
         int kz = G_NOKEY, kr = G_NOKEY;
         bool inside = false;
@@ -909,7 +932,7 @@ static int launch_gather(int shape, int Nm, long n, const double *x, const doubl
     GatherGrids G;
     for (int i = 0; i < 6 * Nm; i++) G.g[i] = (const cplx *)grids[i];
     for (int i = 6 * Nm; i < 6 * FB_MAX_MODES; i++) G.g[i] = nullptr;
-    if (shape == FB_SHAPE_CUBIC && Nm >= 2 && Nm <= 4 && !getenv("FBPIC_AMD_GATHER_VALU")) {
+    if (shape == FB_SHAPE_CUBIC && Nm >= 2 && Nm <= 4 && !getenv("FBPIC_AMD_GATHER_VALU") && !PA.range_mode) {
 #define FB_MX(NMT) launch_gather_cubic_mx<NMT>(n, x, y, z, rmax_gather, invdz, zmin, Nz, invdr, rmin, Nr, G, \
                                                row_stride, Ex, Ey, Ez, Bx, By, Bz, PA, s, where)
         return Nm == 2 ? FB_MX(2) : (Nm == 3 ? FB_MX(3) : FB_MX(4));
@@ -971,10 +994,13 @@ static int gather_push_impl(const char *who, int shape, int Nm, long n, double *
         const void *const *grids, long row_stride,
         double *Ex, double *Ey, double *Ez, double *Bx, double *By, double *Bz,
         double q, double m, double c, double dt, double dt_x, double wrap_zmin, double wrap_zmax,
-        const RankNext &RK, void *stream)
+        const RankNext &RK, void *stream, const int *range_lo = nullptr, const int *range_hi = nullptr,
+        int range_mode = 0)
 {
     PushArgs PA;
     PA.RK = RK;
+    PA.range_lo = range_lo; PA.range_hi = range_hi; PA.range_mode = range_mode;
+    if (range_mode < 0 || range_mode > 2) { set_error(who, "range_mode must be 0, 1 or 2"); return -1; }
     PA.x = x; PA.y = y; PA.z = z;
     PA.ux = ux; PA.uy = uy; PA.uz = uz; PA.ig = inv_gamma;
     PA.econst = q * dt / (m * c);
@@ -1004,14 +1030,15 @@ extern "C" int fb_gather_push(int shape, int Nm, long n, double *x, double *y, d
                             q, m, c, dt, dt_x, wrap_zmin, wrap_zmax, none, stream);
 }
 
-extern "C" int fb_gather_push_rank_next(int shape, int Nm, long n, double *x, double *y, double *z,
+extern "C" int fb_gather_push_rank_next_range(int shape, int Nm, long n, double *x, double *y, double *z,
         double *ux, double *uy, double *uz, double *inv_gamma,
         double rmax_gather, double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
         const void *const *grids, long row_stride,
         double *Ex, double *Ey, double *Ez, double *Bx, double *By, double *Bz,
         double q, double m, double c, double dt, double dt_x, double wrap_zmin, double wrap_zmax,
         double dt_push, double x_push, double y_push, double z_push, int ncell,
-        void *sort_workspace, size_t workspace_bytes, int counts_are_zero, void *stream)
+        void *sort_workspace, size_t workspace_bytes, int counts_are_zero,
+        const int *range_lo, const int *range_hi, int range_mode, void *stream)
 {
     const char *who = "fb_gather_push_rank_next";
     hipStream_t s = (hipStream_t)stream;
@@ -1027,5 +1054,21 @@ extern "C" int fb_gather_push_rank_next(int shape, int Nm, long n, double *x, do
     const RankNext RK = {c * dt_push, x_push, y_push, z_push, W.cell, W.rank, W.count};
     return gather_push_impl(who, shape, Nm, n, x, y, z, ux, uy, uz, inv_gamma, rmax_gather,
                             invdz, zmin, Nz, invdr, rmin, Nr, grids, row_stride, Ex, Ey, Ez, Bx, By, Bz,
-                            q, m, c, dt, dt_x, wrap_zmin, wrap_zmax, RK, stream);
+                            q, m, c, dt, dt_x, wrap_zmin, wrap_zmax, RK, stream, range_lo, range_hi,
+                            range_mode);
+}
+
+extern "C" int fb_gather_push_rank_next(int shape, int Nm, long n, double *x, double *y, double *z,
+        double *ux, double *uy, double *uz, double *inv_gamma,
+        double rmax_gather, double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
+        const void *const *grids, long row_stride,
+        double *Ex, double *Ey, double *Ez, double *Bx, double *By, double *Bz,
+        double q, double m, double c, double dt, double dt_x, double wrap_zmin, double wrap_zmax,
+        double dt_push, double x_push, double y_push, double z_push, int ncell,
+        void *sort_workspace, size_t workspace_bytes, int counts_are_zero, void *stream)
+{
+    return fb_gather_push_rank_next_range(shape, Nm, n, x, y, z, ux, uy, uz, inv_gamma, rmax_gather,
+            invdz, zmin, Nz, invdr, rmin, Nr, grids, row_stride, Ex, Ey, Ez, Bx, By, Bz, q, m, c, dt,
+            dt_x, wrap_zmin, wrap_zmax, dt_push, x_push, y_push, z_push, ncell, sort_workspace,
+            workspace_bytes, counts_are_zero, nullptr, nullptr, 0, stream);
 }

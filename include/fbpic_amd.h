@@ -132,6 +132,25 @@ int fb_gather_push_rank_next(int shape, int Nm, long n, double *x, double *y, do
                              void *sort_workspace, size_t workspace_bytes, int counts_are_zero,
                              void *stream);
 
+/* fb_gather_push_rank_next restricted to a contiguous range of the (cell-sorted) particle arrays,
+ * [*range_lo, *range_hi) (range_mode 1), or to everything outside it (range_mode 2); mode 0 = all.
+ * The bounds are DEVICE pointers (entries of the per-cell prefix sum; NULL = 0), so no offset is
+ * read back by the host.  Lets Simulation.step (main.py:469-490 after :719-769) gather + push
+ * the particles whose stencil lies in rows that the pending guard-cell exchange of E, B does not
+ * touch while that exchange is in flight on another stream, then the rest.  The two calls of a
+ * step share one sort workspace: pass counts_are_zero = 1 to the second.  (Not with the cubic
+ * matrix-core gather: returns an error.) */
+int fb_gather_push_rank_next_range(int shape, int Nm, long n, double *x, double *y, double *z,
+                             double *ux, double *uy, double *uz, double *inv_gamma,
+                             double rmax_gather, double invdz, double zmin, int Nz, double invdr,
+                             double rmin, int Nr, const void *const *grids, long row_stride,
+                             double *Ex, double *Ey, double *Ez, double *Bx, double *By, double *Bz,
+                             double q, double m, double c, double dt, double dt_x,
+                             double wrap_zmin, double wrap_zmax,
+                             double dt_push, double x_push, double y_push, double z_push, int ncell,
+                             void *sort_workspace, size_t workspace_bytes, int counts_are_zero,
+                             const int *range_lo, const int *range_hi, int range_mode, void *stream);
+
 /* ---- cell sort ---------------------------------------------------------------- */
 /* particles/particles.py:1075-1081 -> get_cell_idx_per_particle
  * (utilities/cuda_sorting.py:21-88): cell_idx = ir_upper + iz_upper*(Nr+1);

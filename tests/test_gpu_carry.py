@@ -18,7 +18,9 @@ def _state(sim):
             out['%s%d' % (k, m)] = getattr(sim.fld.interp[m], k)
     out = {k: v.detach().cpu().numpy().copy() for k, v in out.items()}
     s = sim.ptcl[0]
-    P = np.array([getattr(s, k).detach().cpu().numpy() for k in helpers.PTCL])
+    # (Ex..Bz keep the order of the gather that wrote them, not the order of the sort that
+    # followed it - in the reference's GPU path too -, so only the eight state arrays compare)
+    P = np.array([getattr(s, k).detach().cpu().numpy() for k in helpers.PTCL[:8]])
     o = np.lexsort((P[2], P[1], P[0], P[7]))
     out['ptcl'] = P[:, o]
     return out
@@ -30,7 +32,7 @@ def _compare(a, b, tag, tol):
         scale = max(np.abs(b[k]).max() for k in keys)
         if scale > 0:
             achieved('%s fields %s' % (tag, grp), max(np.abs(a[k] - b[k]).max() for k in keys) / scale, tol)
-    for j, k in enumerate(helpers.PTCL):
+    for j, k in enumerate(helpers.PTCL[:8]):
         sc = np.abs(b['ptcl'][j]).max()
         if sc > 0:
             achieved('%s particles' % tag, np.abs(a['ptcl'][j] - b['ptcl'][j]).max() / sc, tol)
