@@ -303,6 +303,15 @@ class BoundaryCommunicator(object):
                 for k in names:
                     getattr(g, k)[-nd:, :] *= self.d_right_damp[:, None]
 
+    def rows_untouched_by_EB_exchange(self, Nz):
+        """(lo, hi): the z rows [lo, hi) of a local grid that neither the 'replace' exchange of
+        the guard cells nor the open-boundary damping modifies."""
+        lo = self.n_guard if self.left_proc is not None else \
+            (self.n_guard + self.nz_damp + self.n_inject if self.nz_damp else 0)
+        hi = Nz - (self.n_guard if self.right_proc is not None else
+                   (self.n_guard + self.nz_damp + self.n_inject if self.nz_damp else 0))
+        return lo, max(hi, lo)
+
     # ---------------------------------------------------------------- field exchange
     def exchange_fields(self, interp, fldtype, method, slab=None):
         """Guard-cell exchange with the two z neighbours (boundary_communicator.py:556-671):
@@ -337,6 +346,20 @@ class BoundaryCommunicator(object):
                 base, f0 = slab, 0
             region = base[:, f0:f0 + nf, :]
             nrows, ncontig = s_l.stop - s_l.start, nf * region.shape[2]
+            if method == 'replace' and slab is not None and nf == base.shape[1] and f0 == 0 \
+                    and base.stride(1) == base.shape[2] and base.stride(2) == 1:
+                # The group is the whole slab: a block of z rows is ONE contiguous piece of memory
+                # (row stride included), so the messages are sent from and received into the
+                # rows themselves - no pack / unpack launch, no message buffers
+                rs = base.stride(0)
+
+                def rows(sl, present):
+                    if not present:
+                        return None
+                    return t.as_strided(base, ((sl.stop - sl.start) * rs,), (1,),
+                                        base.storage_offset() + sl.start * rs)
+                self.exchange_domains(rows(s_l, has_l), rows(s_r, has_r), rows(d_l, has_l), rows(d_r, has_r))
+                return
             key = (fldtype, method, nrows, ncontig)
             bufs = self._guard_bufs.get(key)
             if bufs is None:        # persistent message buffers: stable addresses for RCCL

@@ -415,17 +415,22 @@ class Fields(object):
         src = self.d_scratch[:, 0, :] if from_scratch else self.d_interp[:, fi, :]
         fft_exec(src, self.d_spect[:, fs, :], -1, ncols=nf * self.Nr)
 
-    def partial2interp(self, fieldtype):
+    def partial2interp(self, fieldtype, rows=None):
         """z-real / r-spectral (p, m, z) fields in the scratch slab -> interpolation grid:
         inverse Hankel transform with (p, m) -> (r, t) folded into the GEMM, one launch.
         Equals partial_interp2spect followed by spect2interp (the z-FFT round trip is the
-        identity, main.py:741-766) without the two FFTs."""
+        identity, main.py:741-766) without the two FFTs.  `rows` = (first, last+1): only that
+        block of z rows (the transform is local in z: the rows a pending guard-cell exchange
+        does not touch can go first, the exchanged ones when they have arrived)."""
         self._need_gpu()
         fi, _, nf, vec = self._group(fieldtype)
         assert vec and nf <= self.NFx
+        r0, r1 = (0, self.Nz) if rows is None else rows
+        if r1 <= r0:
+            return
         lib, pa, st = _capi.lib(), _capi.ptr_array, _capi.stream()
-        scr_f = self._field_views(self.d_scratch, 0, nf)
-        out = self._field_views(self.d_interp, fi, nf)
+        scr_f = [v[r0:r1] for v in self._field_views(self.d_scratch, 0, nf)]
+        out = [v[r0:r1] for v in self._field_views(self.d_interp, fi, nf)]
         mats = self._mats['vec_inv']
         if fieldtype == 'EB':
             mats = mats + mats
@@ -440,7 +445,7 @@ class Fields(object):
             m2 += [mats[g + 1], None]
         _capi.check(lib.fb_hankel_pm_to_rt(
             len(ins), pa(ins), pa(in2), self.d_scratch.stride(0), pa(o1), pa(o2),
-            self.d_interp.stride(0), pa(m1), pa(m2), 1.0, self.Nz, self.Nr, st), 'fb_hankel_pm_to_rt')
+            self.d_interp.stride(0), pa(m1), pa(m2), 1.0, r1 - r0, self.Nr, st), 'fb_hankel_pm_to_rt')
 
     # ---------------------------------------------------------------- solver steps
     def push(self, use_true_rho=False, check_exchanges=False):

@@ -143,6 +143,14 @@ class Simulation(object):
         # `for _ in range(n): sim.step(1)` then costs what sim.step(n) costs.
         self.carry_state_between_calls = os.environ.get('FBPIC_AMD_CARRY', '1') != '0'
         self._carry = None
+        # Decomposed runs: the guard-cell exchange of E, B (message, FFT of the exchanged fields,
+        # inverse Hankel transform of the guard rows) runs on a second stream while the main
+        # stream transforms the rows the exchange does not touch and gathers + pushes the
+        # particles of those rows (exchange_and_damp_EB / _wait_eb; reference schedule:
+        # main.py:719-769 then :469-490, serial)
+        self.overlap_guard_exchange = os.environ.get('FBPIC_AMD_OVERLAP', '1') != '0'
+        self._eb_pending = None
+        self._comm_stream = None
 
     # -------------------------------------------------------------------- PIC cycle
     def step(self, N=1, correct_currents=True, correct_divE=False, use_true_rho=False,
@@ -249,11 +257,29 @@ class Simulation(object):
                 cross_ = bool(correct_currents) and fld.current_correction == 'cross-deposition'
                 hint = (0.5 * dt, 1., 1., 1.) if (self.prerank_in_deposit and not self.use_galilean
                                                   and not cross_) else None
-                for species in ptcl:
-                    species.gather_push(fld.interp, self.comm, 0.5 * dt,
-                                        store_fields=(i_step == N - 1), wrap_z=wrap_z,
-                                        rank_next=hint)
+                pend = self._eb_pending
+                if pend is not None and hint is not None and wrap_z is None \
+                        and all(sp.can_split_gather(fld.Nm) for sp in ptcl):
+                    # the rows [lo, hi) of the interpolation grid are final; a particle of cell
+                    # row iz_upper reads rows iz_upper - 2 ... iz_upper + 1 at most (cubic shape)
+                    rows = (pend[1] + 2, pend[2] - 2)
+                    for species in ptcl:
+                        species.gather_push(fld.interp, self.comm, 0.5 * dt,
+                                            store_fields=(i_step == N - 1), rank_next=hint,
+                                            part='inside', rows=rows)
+                    self._wait_eb()
+                    for species in ptcl:
+                        species.gather_push(fld.interp, self.comm, 0.5 * dt,
+                                            store_fields=(i_step == N - 1), rank_next=hint,
+                                            part='outside', rows=rows)
+                else:
+                    self._wait_eb()
+                    for species in ptcl:
+                        species.gather_push(fld.interp, self.comm, 0.5 * dt,
+                                            store_fields=(i_step == N - 1), wrap_z=wrap_z,
+                                            rank_next=hint)
             else:
+                self._wait_eb()
                 for species in ptcl:
                     species.gather(fld.interp, self.comm)
                 for ext_field in self.external_fields:
@@ -341,8 +367,11 @@ class Simulation(object):
             self.exchange_and_damp_EB()
             self.time += dt
             self.iteration += 1
+            if any(ck.due(self.iteration) for ck in self.checkpoints):
+                self._wait_eb()          # the dump reads the guard rows of E, B
             for checkpoint in self.checkpoints:
                 checkpoint.write(self.iteration)
+        self._wait_eb()
         if self.carry_state_between_calls and self.comm.size == 1 and not self.reference_sequence:
             # J and rho go back to the interpolation grid when something reads them there
             # (interp[m].Jr ..., receive_fields_from_gpu, a direct deposit), not at every call
@@ -415,6 +444,7 @@ class Simulation(object):
         by deposit('rho_next')): J stays on the interpolation grid and is transformed
         together with rho_next, in one FFT and one Hankel launch."""
         fld = self.fld
+        self._wait_eb()          # the transforms below use the scratch slab of a pending exchange
         if species_list is None:
             species_list = [s for s in self.ptcl if not s.is_tracer]
         if fieldtype.startswith('rho'):
@@ -494,7 +524,29 @@ class Simulation(object):
             # the damping, the interpolation grid follows from them by the inverse Hankel
             # transform alone: one 6*Nm-field FFT launch less than via the spectral fields
             scr = fld.d_scratch
+            self._wait_eb()
             fld.spect2partial_interp('EB', to_scratch=True)
+            if self.overlap_guard_exchange and self.comm.size > 1 and scr.is_cuda:
+                t = _capi.torch()
+                if self._comm_stream is None:
+                    self._comm_stream = t.cuda.Stream()
+                    self._ev_ready, self._ev_done = t.cuda.Event(), t.cuda.Event()
+                main, side = t.cuda.current_stream(), self._comm_stream
+                lo, hi = self.comm.rows_untouched_by_EB_exchange(fld.Nz)
+                self._ev_ready.record(main)
+                with t.cuda.stream(side):
+                    side.wait_event(self._ev_ready)
+                    # exchanged / damped rows: message, then their half of the work
+                    self.comm.exchange_fields(fld.interp, 'EB', 'replace', slab=scr)
+                    self.comm.damp_EB_open_boundary(fld.interp, slab=scr)
+                    fld.partial_interp2spect('EB', from_scratch=True)
+                    fld.partial2interp('EB', rows=(0, lo))
+                    fld.partial2interp('EB', rows=(hi, fld.Nz))
+                    self._ev_done.record(side)
+                # meanwhile: the rows the exchange does not touch (the transform is local in z)
+                fld.partial2interp('EB', rows=(lo, hi))
+                self._eb_pending = (self._ev_done, lo, hi)
+                return
             self.comm.exchange_fields(fld.interp, 'EB', 'replace', slab=scr)
             self.comm.damp_EB_open_boundary(fld.interp, slab=scr)
             fld.partial_interp2spect('EB', from_scratch=True)
@@ -508,6 +560,14 @@ class Simulation(object):
                 mirror.set_fields_to_zero(fld.interp, self.comm, self.time)
             fld.partial_interp2spect('EB')
         fld.spect2interp('EB')
+
+    def _wait_eb(self):
+        """Make the main stream wait for a guard-cell exchange of E, B that is still in flight on
+        the communication stream (no-op otherwise): before anything reads the guard rows of the
+        interpolation grid, the spectral E, B, or re-uses the scratch slab."""
+        pend, self._eb_pending = self._eb_pending, None
+        if pend is not None:
+            _capi.torch().cuda.current_stream().wait_event(pend[0])
 
     def set_moving_window(self, v=c, **deprecated):
         """Attach a window moving at velocity v to the simulation (main.py:1004-1032)."""

@@ -323,15 +323,27 @@ class Particles(object):
                                    p(self.Bz), _capi.stream())
         _capi.check(rc, 'fb_gather')
 
-    def gather_push(self, grid, comm, dt_x, store_fields=True, wrap_z=None, rank_next=None):
+    def can_split_gather(self, Nm):
+        """The range-restricted gather + push (gather_push(part=...)) needs cell-sorted arrays with
+        an exact prefix sum, the ranking pass, and the lane-by-lane gather kernel."""
+        return bool(self.sorted and self._prefix_valid and self.use_bin_sort and self.Ntot > 0
+                    and self.q != 0 and not (self.particle_shape == 'cubic' and 2 <= Nm <= 4))
+
+    def gather_push(self, grid, comm, dt_x, store_fields=True, wrap_z=None, rank_next=None,
+                    part=None, rows=None):
         """gather -> push_p -> push_x(dt_x) in one pass (fb_gather_push): the fused form of
         the three consecutive calls of Simulation.step (main.py:469-490).  Results are
         identical to calling gather(), push_p(), push_x(dt_x) one after the other.
         `rank_next` = (dt, x_push, y_push, z_push) of the push_x that will follow: the pass also
-        ranks the particles for the sort after that push (fb_gather_push_rank_next)."""
+        ranks the particles for the sort after that push (fb_gather_push_rank_next).
+        `part` = 'inside' / 'outside' with `rows` = (a, b): only the particles whose (sorted) cell
+        row is / is not in [a, b) - Simulation.step runs the inside part while the guard-cell
+        exchange of E, B is in flight and the outside part after it (can_split_gather)."""
         self._need_gpu()
         self.flush_pending_push()
         if self.q == 0:
+            if part == 'inside':
+                return
             if wrap_z is not None:
                 rc = _capi.lib().fb_shift_periodic(self.Ntot, _capi.ptr(self.z), float(wrap_z[0]),
                                                    float(wrap_z[1]), _capi.stream())
@@ -349,7 +361,29 @@ class Particles(object):
         wz = (0., 0.) if wrap_z is None else (float(wrap_z[0]), float(wrap_z[1]))
         ranked = (rank_next is not None and self.use_bin_sort and self.Ntot > 0 and dt_x != 0.
                   and g0.Nz * (g0.Nr + 1) == self.prefix_sum.shape[0])
-        if ranked:
+        if part is not None:
+            assert ranked and self.can_split_gather(Nm) and part in ('inside', 'outside')
+            ncol = g0.Nr + 1
+            a = min(max(rows[0] + self.prefix_sum_shift, 0), g0.Nz)
+            b = min(max(rows[1] + self.prefix_sum_shift, a), g0.Nz)
+            ps, es = self.prefix_sum.data_ptr(), self.prefix_sum.element_size()
+            lo_ptr = None if a == 0 else ps + (a * ncol - 1) * es
+            hi_ptr = None if b == 0 else ps + (b * ncol - 1) * es
+            clean = int(self._counts_clean) if part == 'inside' else 1
+            rc = _capi.lib().fb_gather_push_rank_next_range(
+                _SHAPE[self.particle_shape], Nm, self.Ntot, p(self.x), p(self.y), p(self.z),
+                p(self.ux), p(self.uy), p(self.uz), p(self.inv_gamma),
+                comm.get_rmax(with_damp=False), g0.invdz, g0.zmin, g0.Nz, g0.invdr, g0.rmin, g0.Nr,
+                _capi.ptr_array(views), _capi.row_stride(views[0]), *eb,
+                self.q, self.m, c, self.dt, dt_x, wz[0], wz[1],
+                rank_next[0], rank_next[1], rank_next[2], rank_next[3], self.prefix_sum.shape[0],
+                p(self._sort_ws), self._sort_ws.shape[0], clean, lo_ptr, hi_ptr,
+                1 if part == 'inside' else 2, _capi.stream())
+            self._counts_clean = False
+            _capi.check(rc, 'fb_gather_push_rank_next_range')
+            if part == 'inside':
+                return                      # the book-keeping below belongs to the completed pass
+        elif ranked:
             rc = _capi.lib().fb_gather_push_rank_next(
                 _SHAPE[self.particle_shape], Nm, self.Ntot, p(self.x), p(self.y), p(self.z),
                 p(self.ux), p(self.uy), p(self.uz), p(self.inv_gamma),

@@ -32,10 +32,16 @@ def rel_err(a, b):
 _ACHIEVED = []
 
 
-def achieved(name, err, tol):
+def achieved(name, err, tol, what=''):
     """Assert err < tol and keep the achieved figure: the list is printed at the end of the run
     (pytest_terminal_summary) and written to gpurun_out/achieved_errors.json, so a bound that is
-    wider than what the kernels deliver is visible."""
+    wider than what the kernels deliver is visible.  name = None: the id of the running test
+    (+ `what`, e.g. 'fields s5')."""
+    if name is None:
+        name = os.environ.get('PYTEST_CURRENT_TEST', '?').split(' ')[0].split('::', 1)[-1]
+        name = name.replace('test_', '', 1)
+        if what:
+            name += ' ' + what
     _ACHIEVED.append((name, float(err), float(tol)))
     assert err < tol, (name, err, tol)
 
@@ -49,7 +55,7 @@ def pytest_terminal_summary(terminalreporter):
             worst[name] = (err, tol)
     terminalreporter.write_line('achieved errors (worst case per check, bound):')
     for name in sorted(worst):
-        terminalreporter.write_line('  %-44s %.2e  (< %.0e)' % (name, worst[name][0], worst[name][1]))
+        terminalreporter.write_line('  %-76s %.2e  (< %.0e)' % (name, worst[name][0], worst[name][1]))
     try:
         import json
         out = os.path.join(ROOT, 'gpurun_out')

@@ -1,0 +1,167 @@
+"""BASELINE config C4 at its own size: the laser-wakefield run of docs/source/example_input/
+lwfa_script.py on a 4096 x 256 grid (Nm = 2, 16 ppc, open z, moving window, continuous
+injection, a0 = 4 laser), n_order = 32, cut into 8 z-slabs (reference:
+tests/test_example_docs_scripts.py:40-51 runs that script on several MPI ranks).
+
+The test box has one GPU, so the 8 ranks are 8 processes sharing it (gloo transport staged
+through the host; on an 8-GPU node the same code path moves device buffers with RCCL, see
+test_decomposed_on_real_gpus).  Without current correction every operation is local within the
+stencil reach, so the decomposed run must reproduce the single-domain run (= C3 with the same
+finite-order solver) in the physical region to rounding, with exactly the same global particle
+set: 16 steps cover one particle hand-over between all neighbours, 16 moves of the window and
+one injection of new plasma on the last rank.  (With the curl-free correction the decomposed
+SCHEME differs from the single domain by construction, in the reference too; that path is
+pinned rank by rank against the reference running decomposed - tests/test_gpu_multirank_golden.py,
+`mr_lwfa_lin_2r` being this configuration in miniature.)"""
+import json
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+from scipy.constants import c
+from conftest import achieved, ROOT
+
+pytestmark = pytest.mark.gpu
+
+NZ, NR, NM = 4096, 256, 2
+ZMIN, ZMAX, RMAX = -10.e-6, 30.e-6, 20.e-6
+NSTEP = 16
+FIELDS = ['Er', 'Et', 'Ez', 'Br', 'Bt', 'Bz', 'Jr', 'Jt', 'Jz', 'rho']
+PTCL = ['x', 'y', 'z', 'ux', 'uy', 'uz', 'inv_gamma', 'w']
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build():
+    from fbpic_amd.main import Simulation
+    ramp_start, ramp_length = 5.e-6, 10.e-6
+
+    def dens_func(z, r):
+        n = np.ones_like(z)
+        n = np.where(z < ramp_start + ramp_length, (z - ramp_start) / ramp_length, n)
+        return np.where(z < ramp_start, 0., n)
+    np.random.seed(0)
+    dt = (ZMAX - ZMIN) / NZ / c
+    return Simulation(NZ, ZMAX, NR, RMAX, NM, dt, zmin=ZMIN, p_zmin=ramp_start, p_zmax=500.e-6,
+                      p_rmin=0., p_rmax=18.e-6, p_nz=2, p_nr=2, p_nt=4, n_e=4.e24,
+                      dens_func=dens_func, n_order=32, particle_shape='linear',
+                      boundaries={'z': 'open', 'r': 'reflective'})
+
+
+def _run(rank, world, port, outdir):
+    import torch.distributed as dist
+    import helpers
+    from fbpic_amd.lpa_utils.laser import add_laser_pulse, GaussianLaser
+    # the GLOBAL initial plasma (built before the ranks exist: lattice + one np.random stream)
+    glob = _build()
+    P = np.array([getattr(glob.ptcl[0], k) for k in helpers.PTCL])
+    del glob
+    if world > 1:
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank,
+                                world_size=world)
+    sim = _build()
+    assert sim.comm.n_guard == 64 and sim.comm.exchange_period == 14
+    zlo, zhi = sim.comm.get_zmin_zmax(local=True, with_damp=False, with_guard=False, rank=rank)
+    if rank == world - 1:
+        zhi = np.inf
+    sel = (P[2] >= zlo) & (P[2] < zhi)
+    helpers.set_species_state(sim.ptcl[0], P[:, sel])
+    add_laser_pulse(sim, GaussianLaser(a0=4., waist=5.e-6, tau=16.e-15, z0=15.e-6))
+    sim.set_moving_window(v=c)
+    np.random.seed(12345)              # the angles of the injected plasma: same draws in both runs
+    sim.step(NSTEP, correct_currents=False)
+    Nz_phys, iz0 = sim.comm.get_Nz_and_iz(local=True, with_damp=False, with_guard=False, rank=rank)
+    _, iz_arr = sim.comm.get_Nz_and_iz(local=True, with_damp=True, with_guard=True, rank=rank)
+    sl = slice(iz0 - iz_arr, iz0 - iz_arr + Nz_phys)
+    out = {'zmin': sim.fld.interp[0].zmin + (iz0 - iz_arr) * sim.fld.interp[0].dz, 'Nz_local': sim.fld.Nz}
+    for m in range(NM):
+        for k in FIELDS:
+            out['%s_%d' % (k, m)] = getattr(sim.fld.interp[m], k)[sl]
+    for k in PTCL:
+        out['p_' + k] = getattr(sim.ptcl[0], k)
+    np.savez(os.path.join(outdir, 'w%d_r%d.npz' % (world, rank)), **out)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _worker(rank, world, port, outdir, q):
+    try:
+        _run(rank, world, port, outdir)
+        q.put((rank, 'ok'))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+def _launch(world, outdir):
+    ctx = mp.get_context('spawn')
+    port = _free_port()
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, outdir, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=1500) for _ in range(world)]
+    for p in procs:
+        p.join(120)
+    for rank, msg in res:
+        assert msg == 'ok', 'world %d rank %d:\n%s' % (world, rank, msg)
+
+
+def test_c4_lwfa_4096x256_on_8_slabs_reproduces_the_single_domain():
+    outdir = tempfile.mkdtemp()
+    world = 8
+    _launch(1, outdir)
+    _launch(world, outdir)
+    one = np.load(os.path.join(outdir, 'w1_r0.npz'))
+    parts = [np.load(os.path.join(outdir, 'w%d_r%d.npz' % (world, r))) for r in range(world)]
+    # local grids: 512 physical cells each + 2 x 64 guard cells (+ 96 damp / inject cells at the ends)
+    assert [int(p['Nz_local']) for p in parts] == [736] + [640] * 6 + [736]
+    assert int(one['Nz_local']) == 4416
+    assert abs(float(parts[0]['zmin']) - float(one['zmin'])) < 1e-12 * (ZMAX - ZMIN)   # same window motion
+    for grp in ('E', 'B', 'J', 'r'):
+        keys = ['%s_%d' % (k, m) for k in FIELDS if k[0] == grp for m in range(NM)]
+        scale = max(np.abs(one[k]).max() for k in keys)
+        assert scale > 0
+        for k in keys:
+            got = np.concatenate([p[k] for p in parts], axis=0)
+            assert got.shape == one[k].shape == (NZ, NR)
+            achieved(None, np.abs(got - one[k]).max() / scale, 1e-9, 'fields ' + grp)
+    ref = np.array([one['p_' + k] for k in PTCL])
+    got = np.concatenate([np.array([p['p_' + k] for k in PTCL]) for p in parts], axis=1)
+    assert got.shape == ref.shape and ref.shape[1] > 9.0e6       # nobody lost, duplicated or mis-injected
+    assert np.array_equal(np.sort(got[7]), np.sort(ref[7]))
+    o1 = np.lexsort((ref[2], ref[1], ref[0], ref[7]))
+    o2 = np.lexsort((got[2], got[1], got[0], got[7]))
+    for j, k in enumerate(PTCL):
+        achieved(None, np.abs(got[j][o2] - ref[j][o1]).max() / max(np.abs(ref[j]).max(), 1e-300), 1e-9,
+                 'particles')
+
+
+def test_bench_strong_scaling_dry_run_on_8_ranks():
+    """`bench.py --gpus 8 --scaling strong` (the fixed 1024 x 128 box of BASELINE.json cut into 8
+    slabs of 128 + 2 x 64 rows) launched as the driver launches it, the 8 ranks sharing the GPU
+    over gloo: the decomposed bench path runs end to end and prints its one JSON line."""
+    env = dict(os.environ, FBPIC_AMD_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8',
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+           os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--scaling', 'strong', '--steps', '4',
+           '--warmup', '2', '--no-kernel-timing', '--no-cpu-baseline']
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert res.returncode == 0, res.stderr[-4000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 8 and out['scaling'] == 'strong' and out['steps'] == 4
+    assert out['config']['particles'] == 4194304 and out['value'] > 0
+    assert 'x8' in out['config']['parallelism']

@@ -19,6 +19,7 @@ import numpy as np
 import pytest
 from scipy.constants import c, e, m_e, epsilon_0
 import helpers
+from conftest import achieved
 from helpers import PTCL, INTERP
 
 pytestmark = pytest.mark.gpu
@@ -85,14 +86,14 @@ def test_c1_node_aligned_lattice_vs_oracle(oracle, shape):
                 continue
             err = np.abs(getattr(sim.fld.interp[m], k) - orc.interp[m][k]).max() / scale
             worst = max(worst, err)
-            assert err < 2e-11, (m, k, err)
+            achieved(None, err, 2e-11, 'fields vs oracle')
     o = orc.species[0]
     got = np.array([getattr(s, k) for k in PTCL[:8]])
     ref = np.array([o[k] for k in PTCL[:8]])
     o1 = np.lexsort((ref[2], ref[1], ref[0], ref[7]))
     o2 = np.lexsort((got[2], got[1], got[0], got[7]))
     for j, k in enumerate(PTCL[:8]):
-        assert np.abs(got[j][o2] - ref[j][o1]).max() < 1e-11 * np.abs(ref[j]).max(), k
+        achieved(None, np.abs(got[j][o2] - ref[j][o1]).max() / np.abs(ref[j]).max(), 1e-11, 'particles vs oracle')
     # (c) cell indices after the steps: identical wherever the particle is not within 1e-9 of
     #     a cell boundary (SURVEY.md 8c tie mask; momenta differ by ~1e-13 between the paths)
     gx, gy, gz = got[0][o2], got[1][o2], got[2][o2]
@@ -145,7 +146,7 @@ def test_periodic_plasma_wave_at_reference_parameters(shape):
         rho_eps0 = sp.rho_prev / epsilon_0
         rel = np.sqrt(np.sum(abs(divE - rho_eps0)**2) / np.sum(abs(rho_eps0)**2))
         print('plasma wave %s, mode %d: relative error on div E %.2e' % (shape, m, rel))
-        assert rel < 1.e-11, (m, rel)
+        achieved(None, rel, 1.e-11, 'divE - rho/eps0')
 
 
 # ------------------------------------------------------------------------------ C5
@@ -178,7 +179,7 @@ def test_hankel_gemm_large(Nz, Nr):
         got = outs[j].cpu().numpy()
         err = np.abs(got - ref).max() / np.abs(ref).max()
         print('hankel %dx%d job %d: %.2e' % (Nz, Nr, j, err))
-        assert err < 1e-13, (j, err)
+        achieved(None, err, 1e-13, 'vs np.dot')
 
 
 def test_cycle_cubic_nm4_vs_oracle(oracle):
@@ -194,14 +195,14 @@ def test_cycle_cubic_nm4_vs_oracle(oracle):
             if scale == 0:
                 continue
             err = np.abs(getattr(sim.fld.interp[m], k) - orc.interp[m][k]).max() / scale
-            assert err < 2e-11, (m, k, err)
+            achieved(None, err, 2e-11, 'fields vs oracle')
     s, o = sim.ptcl[0], orc.species[0]
     got = np.array([getattr(s, k) for k in PTCL[:8]])
     ref = np.array([o[k] for k in PTCL[:8]])
     o1 = np.lexsort((ref[2], ref[1], ref[0], ref[7]))
     o2 = np.lexsort((got[2], got[1], got[0], got[7]))
     for j, k in enumerate(PTCL[:8]):
-        assert np.abs(got[j][o2] - ref[j][o1]).max() < 1e-11 * np.abs(ref[j]).max(), k
+        achieved(None, np.abs(got[j][o2] - ref[j][o1]).max() / np.abs(ref[j]).max(), 1e-11, 'particles vs oracle')
 
 
 def test_c5_size_properties():
@@ -240,10 +241,10 @@ def test_c5_size_properties():
         umax = max(float(getattr(s, k).abs().max()) for k in ('ux', 'uy', 'uz'))
     vol = 1. / sim.fld.interp[0].invvol
     q_grid = (rho0.real * vol[None, :]).sum()
-    assert abs(q_grid - q_tot) < 1e-12 * abs(q_tot)
+    achieved(None, abs(q_grid - q_tot) / abs(q_tot), 1e-12, 'charge on the grid')
     assert np.abs(rho0.imag).max() == 0.
     assert np.isfinite(rho3).all()
-    assert err < 1e-10, err
+    achieved(None, err, 1e-10, 'transform round trip')
     assert umax < 0.1
 
 
@@ -308,3 +309,34 @@ def test_c3_lwfa_full_size():
                                              + 2 * sim.comm.exchange_period) * per_cell_z
     assert 0.01 < umax < 50.
     print('C3: %d -> %d macroparticles over %d steps' % (n0, n1, nstep))
+
+
+def test_c2_step1_loop_costs_what_stepN_costs():
+    """State carried across step() calls (fbpic_amd/main.py `_carry_signature`): at the headline
+    size `for _ in range(20): sim.step(1)` runs within 10 % of `sim.step(20)` (the reference
+    repeats the particle exchange, the rho_prev deposition and the E, B transform at the first
+    iteration of every call, main.py:403-451; here only while somebody touched the data)."""
+    import time
+    import torch
+    from fbpic_amd.main import GpuMemoryManager
+    sim = helpers.uniform_plasma_sim(1024, 128, 2, (2, 4, 4), 'linear', seed=0)
+    n = 20
+    with GpuMemoryManager(sim):
+        sim.step(5)
+        torch.cuda.synchronize()
+        one, loop = [], []
+        for rep in range(4):
+            t0 = time.perf_counter()
+            sim.step(n)
+            torch.cuda.synchronize()
+            one.append(time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            for _ in range(n):
+                sim.step(1)
+            torch.cuda.synchronize()
+            loop.append(time.perf_counter() - t0)
+            assert sim._last_call_carried
+    ratio = min(loop) / min(one)
+    print('step(%d): %.4f ms/step, %d x step(1): %.4f ms/step, ratio %.3f'
+          % (n, 1e3 * min(one) / n, n, 1e3 * min(loop) / n, ratio))
+    achieved(None, ratio, 1.10, 'time ratio')

@@ -104,7 +104,7 @@ def test_select_with_prefix_sum_equals_full_scan():
         assert np.array_equal(sl.cpu().numpy()[HEADER:].reshape(8, cap)[:, :len(exp_l)], A[:, idx[0, :len(exp_l)]])
 
 
-@pytest.mark.parametrize('frac', [0.0005, 0.02, 0.6])
+@pytest.mark.parametrize('frac', [0.0005, 0.02, 0.45])
 def test_compact_and_append(frac):
     """After compaction the first n - n_leave slots hold exactly the survivors (any order); the
     arrivals follow, with the periodic shift applied to z only."""

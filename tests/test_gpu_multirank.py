@@ -11,6 +11,7 @@ import tempfile
 import numpy as np
 import pytest
 import torch.multiprocessing as mp
+from conftest import achieved
 from scipy.constants import c
 
 pytestmark = pytest.mark.gpu
@@ -115,7 +116,7 @@ def test_two_ranks_reproduce_single_domain(shape, correct, tol, nranks):
             scale = max(np.abs(one['%s_%d' % (kk, mm)]).max() for kk in grp for mm in range(NM))
             if scale > 0:
                 err = np.abs(got - ref).max() / scale
-                assert err < tol, (key, err)
+                achieved(None, err, tol, 'fields')
     # global particle set (order differs: compare sorted by (w, x, y, z))
     ref = np.array([one['p_' + k] for k in helpers.PTCL[:8]])
     got = np.concatenate([np.array([t['p_' + k] for k in helpers.PTCL[:8]]) for t in two], axis=1)
@@ -132,4 +133,98 @@ def test_two_ranks_reproduce_single_domain(shape, correct, tol, nranks):
         d = np.abs(got[j][o2] - ref[j][o1])
         if k == 'z':
             d = np.minimum(d, L - d)
-        assert d.max() < max(tol * 1e-2, 1e-9) * max(np.abs(ref[j]).max(), 1e-300), k
+        achieved(None, d.max() / max(np.abs(ref[j]).max(), 1e-300), max(tol * 1e-2, 1e-9), 'particles')
+
+
+def _run_restart(rank, world, port, shape, outdir, correct):
+    """6 steps with a checkpoint after 3 (one file per rank), then a NEW decomposed Simulation
+    filled from that checkpoint and stepped 3 more times."""
+    import torch.distributed as dist
+    import helpers
+    from fbpic_amd.main import Simulation
+    from fbpic_amd.openpmd_diag import set_periodic_checkpoint, restart_from_checkpoint
+    P = _global_particles(shape)
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
+    zmax = NZ * DZ
+
+    def build(content):
+        sim = Simulation(NZ, zmax, NR, NR * DZ, NM, DZ / c, n_order=N_ORDER, n_guard=N_GUARD,
+                         particle_shape=shape)
+        zlo, zhi = sim.comm.get_zmin_zmax(local=True, with_damp=False, with_guard=False, rank=rank)
+        sel = (P[2] >= zlo) & (P[2] < zhi)
+        sp = sim.add_new_species(q=-1.602176634e-19, m=9.1093837139e-31)
+        Q = P[:, sel].copy()
+        if not content:                    # something else entirely: the checkpoint must replace it
+            Q = Q[:, ::2]
+            Q[3:6] *= -3.
+        helpers.set_species_state(sp, Q)
+        return sim, sp
+    ckdir = os.path.join(outdir, 'ck')
+    a, spa = build(True)
+    set_periodic_checkpoint(a, 3, checkpoint_dir=ckdir)
+    a.step(3, correct_currents=correct)
+    a.step(3, correct_currents=correct)
+    dist.barrier()
+    b, spb = build(False)
+    assert restart_from_checkpoint(b, 3, checkpoint_dir=ckdir) == 3 and b.iteration == 3
+    b.step(3, correct_currents=correct)
+    out = {}
+    for tag, sim, sp in (('a', a, spa), ('b', b, spb)):
+        for m in range(NM):
+            for k in helpers.INTERP:
+                out['%s_%s_%d' % (tag, k, m)] = getattr(sim.fld.interp[m], k)
+        for k in helpers.PTCL[:8]:
+            out['%s_p_%s' % (tag, k)] = getattr(sp, k)
+    np.savez(os.path.join(outdir, 'restart_r%d.npz' % rank), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _restart_worker(rank, world, port, shape, outdir, correct, q):
+    try:
+        _run_restart(rank, world, port, shape, outdir, correct)
+        q.put((rank, 'ok'))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+def test_two_rank_checkpoint_restart():
+    """Restart of a decomposed run (reference: tests/test_example_docs_scripts.py:40-51 with
+    test_checkpoint_dir=True on 2 MPI ranks; checkpoint_restart.py:36-37 writes / reads one file
+    per rank): run 6 == run 3 + restart on the same 2 ranks + run 3, every rank's whole local
+    grids (guard cells included) and particles, with the curl-free correction on."""
+    import helpers
+    outdir = tempfile.mkdtemp()
+    ctx = mp.get_context('spawn')
+    port = _free_port()
+    q = ctx.Queue()
+    world = 2
+    procs = [ctx.Process(target=_restart_worker, args=(r, world, port, 'linear', outdir, True, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    for rank, msg in res:
+        assert msg == 'ok', 'rank %d:\n%s' % (rank, msg)
+    assert sorted(os.listdir(os.path.join(outdir, 'ck', 'npz'))) == [
+        'checkpoint%08d_rank%d.npz' % (it, r) for it in (3, 6) for r in range(world)]
+    for r in range(world):
+        d = np.load(os.path.join(outdir, 'restart_r%d.npz' % r))
+        for m in range(NM):
+            for k in helpers.INTERP:
+                grp = [kk for kk in helpers.INTERP if kk[0] == k[0]]
+                scale = max(np.abs(d['a_%s_%d' % (kk, mm)]).max() for kk in grp for mm in range(NM))
+                if scale > 0:
+                    achieved(None, np.abs(d['b_%s_%d' % (k, m)] - d['a_%s_%d' % (k, m)]).max() / scale,
+                             1e-11, 'fields')
+        A = np.array([d['a_p_' + k] for k in helpers.PTCL[:8]])
+        B = np.array([d['b_p_' + k] for k in helpers.PTCL[:8]])
+        assert A.shape == B.shape
+        o1 = np.lexsort((A[2], A[1], A[0], A[7]))
+        o2 = np.lexsort((B[2], B[1], B[0], B[7]))
+        for j in range(8):
+            achieved(None, np.abs(B[j][o2] - A[j][o1]).max() / max(np.abs(A[j]).max(), 1e-300), 1e-11,
+                     'particles')

@@ -22,7 +22,7 @@ import numpy as np
 import pytest
 import torch.multiprocessing as mp
 from scipy.constants import c, e, m_e
-from conftest import golden
+from conftest import golden, achieved
 
 pytestmark = pytest.mark.gpu
 
@@ -153,7 +153,7 @@ def _compare(got, g, tag, rank, tol_f, tol_p, nfields=10, ptcl=True, worst=None)
             err = np.abs(got['%s_%s_%d' % (tag, k, m)] - ref[m, i]).max() / scale
             if worst is not None:
                 worst[0] = max(worst[0], err)
-            assert err < tol_f, (tag, 'rank', rank, m, k, err)
+            achieved(None, err, tol_f, 'fields ' + tag)
     assert got[tag + '_zmin'] == float(g['%s_r%d_zmin' % (tag, rank)])
     if not ptcl:
         if '%s_r%d_n0' % (tag, rank) in g.files:
@@ -170,7 +170,7 @@ def _compare(got, g, tag, rank, tol_f, tol_p, nfields=10, ptcl=True, worst=None)
             err = np.abs(gotp[j][o2] - refp[j][o1]).max() / sc
             if worst is not None:
                 worst[1] = max(worst[1], err)
-            assert err < tol_p, (tag, 'rank', rank, k, err)
+            achieved(None, err, tol_p, 'particles ' + tag)
 
 
 @pytest.mark.parametrize('name,world', [('mr_periodic_lin_2r', 2), ('mr_periodic_cub_2r', 2),
