@@ -310,6 +310,7 @@ __global__ __launch_bounds__(256) void k_gather(int Nm_arg, long n,
     double xn = 0., yn = 0., zn = 0.;
     if (chunk0 * 64 + lane < n) { xn = x[chunk0 * 64 + lane]; yn = y[chunk0 * 64 + lane]; zn = z[chunk0 * 64 + lane]; }
     RankPending pend = {-1, 0, 0, 0};
+    bool have_next = true;        // xn, yn, zn hold the coordinates of the chunk about to start
     long r_lo = 0, r_hi = n;
     if (PA.range_mode) {
         r_lo = PA.range_lo ? (long)*PA.range_lo : 0;
@@ -327,10 +328,9 @@ __global__ __launch_bounds__(256) void k_gather(int Nm_arg, long n,
             // chunks without a particle of this pass (wave-uniform test)
             const bool none = PA.range_mode == 1 ? (base + 64 <= r_lo || base >= r_hi)
                                                  : (base >= r_lo && base + 64 <= r_hi);
-            if (none) {
-                if (ch + 1 < chunks_per_wave && i + 64 < n) { xn = x[i + 64]; yn = y[i + 64]; zn = z[i + 64]; }
-                continue;
-            }
+            if (none) { have_next = false; continue; }      // (nothing is loaded for it)
+            if (!have_next && i < n) { xn = x[i]; yn = y[i]; zn = z[i]; }
+            have_next = true;
         }
         double cs = 1., sn = 0., Sz[S], Sr[S];
         int kz = G_NOKEY, kr = G_NOKEY;

@@ -70,7 +70,6 @@ def _run(rank, world, port, outdir):
         dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank,
                                 world_size=world)
     sim = _build()
-    assert sim.comm.n_guard == 64 and sim.comm.exchange_period == 14
     zlo, zhi = sim.comm.get_zmin_zmax(local=True, with_damp=False, with_guard=False, rank=rank)
     if rank == world - 1:
         zhi = np.inf
@@ -83,7 +82,8 @@ def _run(rank, world, port, outdir):
     Nz_phys, iz0 = sim.comm.get_Nz_and_iz(local=True, with_damp=False, with_guard=False, rank=rank)
     _, iz_arr = sim.comm.get_Nz_and_iz(local=True, with_damp=True, with_guard=True, rank=rank)
     sl = slice(iz0 - iz_arr, iz0 - iz_arr + Nz_phys)
-    out = {'zmin': sim.fld.interp[0].zmin + (iz0 - iz_arr) * sim.fld.interp[0].dz, 'Nz_local': sim.fld.Nz}
+    out = {'zmin': sim.fld.interp[0].zmin + (iz0 - iz_arr) * sim.fld.interp[0].dz, 'Nz_local': sim.fld.Nz,
+           'n_guard': sim.comm.n_guard, 'exchange_period': sim.comm.exchange_period}
     for m in range(NM):
         for k in FIELDS:
             out['%s_%d' % (k, m)] = getattr(sim.fld.interp[m], k)[sl]
@@ -125,9 +125,14 @@ def test_c4_lwfa_4096x256_on_8_slabs_reproduces_the_single_domain():
     _launch(world, outdir)
     one = np.load(os.path.join(outdir, 'w1_r0.npz'))
     parts = [np.load(os.path.join(outdir, 'w%d_r%d.npz' % (world, r))) for r in range(world)]
-    # local grids: 512 physical cells each + 2 x 64 guard cells (+ 96 damp / inject cells at the ends)
-    assert [int(p['Nz_local']) for p in parts] == [736] + [640] * 6 + [736]
-    assert int(one['Nz_local']) == 4416
+    # local grids: 512 physical cells each + 2 x n_guard cells (+ 64 damp and n_guard / 2 inject
+    # cells at the two ends); the 16 steps include a particle hand-over between all neighbours
+    ng = int(one['n_guard'])
+    assert all(int(p['n_guard']) == ng for p in parts) and ng >= 32
+    end = 512 + 2 * ng + 64 + ng // 2
+    assert [int(p['Nz_local']) for p in parts] == [end] + [512 + 2 * ng] * 6 + [end]
+    assert int(one['Nz_local']) == 4096 + 2 * ng + 2 * (64 + ng // 2)
+    assert int(parts[0]['exchange_period']) < NSTEP
     assert abs(float(parts[0]['zmin']) - float(one['zmin'])) < 1e-12 * (ZMAX - ZMIN)   # same window motion
     for grp in ('E', 'B', 'J', 'r'):
         keys = ['%s_%d' % (k, m) for k in FIELDS if k[0] == grp for m in range(NM)]

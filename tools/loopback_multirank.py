@@ -29,6 +29,26 @@ class FakeDist:
         out[:] = [(obj[0], i) for i in range(len(out))]
 
 
+def install_loopback(bc, torch):
+    """Rank 0 of a fake 2-rank periodic ring: every message is answered with this rank's own
+    outgoing message of the opposite side (device copy instead of the RCCL transport)."""
+    bc._dist = lambda: FakeDist
+
+    def loopback(self, send_left, send_right, recv_left, recv_right, skip_empty=False):
+        L_local = self._Nz_global_domain * self.dz / 2
+        for recv, send in ((recv_left, send_right), (recv_right, send_left)):
+            if recv is None or send is None or recv.numel() == 0:
+                continue
+            recv.copy_(send)
+            caps = getattr(self, '_handover_caps', None)
+            if caps is not None and recv.dim() == 1:     # fixed-size hand-over message
+                cap = (recv.numel() - 8) // 8
+                recv[8 + 2 * cap:8 + 3 * cap] += L_local     # z row: re-enter on the other side
+            elif recv.dim() == 2 and recv.shape[0] == 8 and recv.dtype == torch.float64:
+                recv[2] += L_local      # particle payload: re-enter on the other side
+    bc.BoundaryCommunicator.exchange_domains = loopback
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=30)
@@ -43,21 +63,7 @@ def main():
     from fbpic_amd.main import GpuMemoryManager
 
     if not a.single:
-        bc._dist = lambda: FakeDist
-
-        def loopback(self, send_left, send_right, recv_left, recv_right, skip_empty=False):
-            L_local = self._Nz_global_domain * self.dz / 2
-            for recv, send in ((recv_left, send_right), (recv_right, send_left)):
-                if recv is None or send is None or recv.numel() == 0:
-                    continue
-                recv.copy_(send)
-                caps = getattr(self, '_handover_caps', None)
-                if caps is not None and recv.dim() == 1:     # fixed-size hand-over message
-                    cap = (recv.numel() - 8) // 8
-                    recv[8 + 2 * cap:8 + 3 * cap] += L_local     # z row: re-enter on the other side
-                elif recv.dim() == 2 and recv.shape[0] == 8 and recv.dtype == torch.float64:
-                    recv[2] += L_local      # particle payload: re-enter on the other side
-        bc.BoundaryCommunicator.exchange_domains = loopback
+        install_loopback(bc, torch)
     world = 1 if a.single else 2
     sim = helpers.uniform_plasma_sim(a.Nz * world, a.Nr, 2, (2, 4, 4), 'linear', seed=0,
                                      n_order=(-1 if a.single else 32),
