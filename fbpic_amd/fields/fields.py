@@ -97,6 +97,17 @@ class Fields(object):
             for name in ('Jr', 'Jt', 'Jz', 'rho'):
                 g.__dict__.pop(name, None)
 
+    def snapshot_EB(self):
+        """Copy of E, B of all modes on the interpolation grid (the first 6 Nm fields of the
+        slab) as they are now: what a gather launched at this point reads
+        (Particles.defer_fields evaluates the particles' E, B from it later)."""
+        self._need_gpu()
+        n = 6 * self.Nm
+        if getattr(self, 'd_EB_snap', None) is None:
+            self.d_EB_snap = self._alloc_slab(n)
+        self.d_EB_snap.copy_(self.d_interp[:, :n, :])
+        return self.d_EB_snap
+
     def _restore_source_views(self):
         for m in range(self.Nm):
             for name in ('Jr', 'Jt', 'Jz', 'rho'):

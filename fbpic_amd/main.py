@@ -143,12 +143,19 @@ class Simulation(object):
         # `for _ in range(n): sim.step(1)` then costs what sim.step(n) costs.
         self.carry_state_between_calls = os.environ.get('FBPIC_AMD_CARRY', '1') != '0'
         self._carry = None
-        # Decomposed runs: the guard-cell exchange of E, B (message, FFT of the exchanged fields,
-        # inverse Hankel transform of the guard rows) runs on a second stream while the main
-        # stream transforms the rows the exchange does not touch and gathers + pushes the
-        # particles of those rows (exchange_and_damp_EB / _wait_eb; reference schedule:
-        # main.py:719-769 then :469-490, serial)
-        self.overlap_guard_exchange = os.environ.get('FBPIC_AMD_OVERLAP', '1') != '0'
+        # Decomposed / open-boundary runs, overlap of the E, B tail of a step with the particles
+        # (reference schedule: main.py:719-769 then :469-490, serial):
+        #   'fft'   (default) the forward FFT of the exchanged (z-real) E, B back to spectral
+        #           space - only the NEXT field push reads it - runs on a second stream next to
+        #           the gather + push of the next step;
+        #   'split' also the message itself and the inverse Hankel transform of the guard rows
+        #           go to the second stream, while the main stream transforms the rows the
+        #           exchange does not touch and gathers + pushes the particles of those rows
+        #           (worth it only when the message latency exceeds the cost of the two extra
+        #           launches: measured on one GPU with a device copy as transport it loses 60 us
+        #           per step, profiles/README.md);
+        #   'off'   everything on the compute stream.
+        self.overlap_guard_exchange = os.environ.get('FBPIC_AMD_OVERLAP', 'fft')
         self._eb_pending = None
         self._comm_stream = None
 
@@ -212,8 +219,11 @@ class Simulation(object):
     def _step_loop(self, N, correct_currents, use_true_rho, move_positions, move_momenta,
                    carried=False):
         ptcl, fld, dt = self.ptcl, self.fld, self.dt
-        # J / rho of the previous call that nobody read are not brought back any more
+        # J / rho (and the particles' E, B) of the previous call that nobody read are not brought
+        # back any more
         fld.drop_deferred_sources()
+        for species in ptcl:
+            species.drop_deferred_fields()
         if not carried:
             # E and B go to spectral space once; afterwards only spectral -> interp
             self.comm.exchange_fields(fld.interp, 'EB', 'replace')
@@ -245,6 +255,14 @@ class Simulation(object):
                 self.deposit('J', exchange=True)
             for species in ptcl:
                 species.keep_fields_sorted = True
+            lazy_eb = False
+            if fused and i_step == N - 1 and self._can_defer_particle_fields():
+                # Last iteration of the call: the reference leaves the gathered E, B of this step
+                # in the particle arrays (48 B per particle written for whoever reads them).
+                # Instead, keep a copy of the E, B grids the gather reads (25 MB at 1024 x 128)
+                # and evaluate species.Ex ... on first use (Particles.defer_fields).
+                fld.snapshot_EB()
+                lazy_eb = True
             if fused:
                 # nothing observes the particles between gather and the half position push:
                 # one pass instead of three (gather, push_p, push_x)
@@ -258,26 +276,26 @@ class Simulation(object):
                 hint = (0.5 * dt, 1., 1., 1.) if (self.prerank_in_deposit and not self.use_galilean
                                                   and not cross_) else None
                 pend = self._eb_pending
-                if pend is not None and hint is not None and wrap_z is None \
+                if pend is not None and pend[1] is not None and hint is not None and wrap_z is None \
                         and all(sp.can_split_gather(fld.Nm) for sp in ptcl):
                     # the rows [lo, hi) of the interpolation grid are final; a particle of cell
                     # row iz_upper reads rows iz_upper - 2 ... iz_upper + 1 at most (cubic shape)
                     rows = (pend[1] + 2, pend[2] - 2)
                     for species in ptcl:
                         species.gather_push(fld.interp, self.comm, 0.5 * dt,
-                                            store_fields=(i_step == N - 1), rank_next=hint,
-                                            part='inside', rows=rows)
+                                            store_fields=(i_step == N - 1 and not lazy_eb),
+                                            rank_next=hint, part='inside', rows=rows)
                     self._wait_eb()
                     for species in ptcl:
                         species.gather_push(fld.interp, self.comm, 0.5 * dt,
-                                            store_fields=(i_step == N - 1), rank_next=hint,
-                                            part='outside', rows=rows)
+                                            store_fields=(i_step == N - 1 and not lazy_eb),
+                                            rank_next=hint, part='outside', rows=rows)
                 else:
-                    self._wait_eb()
+                    self._wait_eb(rows_only=True)
                     for species in ptcl:
                         species.gather_push(fld.interp, self.comm, 0.5 * dt,
-                                            store_fields=(i_step == N - 1), wrap_z=wrap_z,
-                                            rank_next=hint)
+                                            store_fields=(i_step == N - 1 and not lazy_eb),
+                                            wrap_z=wrap_z, rank_next=hint)
             else:
                 self._wait_eb()
                 for species in ptcl:
@@ -367,6 +385,9 @@ class Simulation(object):
             self.exchange_and_damp_EB()
             self.time += dt
             self.iteration += 1
+            if lazy_eb:
+                for species in ptcl:
+                    species.defer_fields(fld, self.comm.get_rmax(with_damp=False), dt)
             if any(ck.due(self.iteration) for ck in self.checkpoints):
                 self._wait_eb()          # the dump reads the guard rows of E, B
             for checkpoint in self.checkpoints:
@@ -378,6 +399,16 @@ class Simulation(object):
             fld.defer_sources(self._sources_to_interp)
         else:
             self._sources_to_interp()
+
+    def _can_defer_particle_fields(self):
+        """Same conditions as the carried state: a z-periodic single domain whose grid does not
+        move, positions and momenta both advanced by the fused passes (the deferred evaluation
+        steps the positions back by one full push)."""
+        comm = self.comm
+        return bool(self.carry_state_between_calls and comm.size == 1 and comm.nz_damp == 0
+                    and comm.moving_win is None and not self.use_galilean
+                    and self.fld.current_correction != 'cross-deposition'
+                    and all(sp.use_bin_sort for sp in self.ptcl))
 
     def _sources_to_interp(self):
         """Tail of step (main.py:572-586): J and rho_prev from spectral space to the
@@ -526,12 +557,14 @@ class Simulation(object):
             scr = fld.d_scratch
             self._wait_eb()
             fld.spect2partial_interp('EB', to_scratch=True)
-            if self.overlap_guard_exchange and self.comm.size > 1 and scr.is_cuda:
+            mode = self.overlap_guard_exchange if scr.is_cuda else 'off'
+            if mode in ('fft', 'split'):
                 t = _capi.torch()
                 if self._comm_stream is None:
                     self._comm_stream = t.cuda.Stream()
                     self._ev_ready, self._ev_done = t.cuda.Event(), t.cuda.Event()
                 main, side = t.cuda.current_stream(), self._comm_stream
+            if mode == 'split' and self.comm.size > 1:
                 lo, hi = self.comm.rows_untouched_by_EB_exchange(fld.Nz)
                 self._ev_ready.record(main)
                 with t.cuda.stream(side):
@@ -549,6 +582,21 @@ class Simulation(object):
                 return
             self.comm.exchange_fields(fld.interp, 'EB', 'replace', slab=scr)
             self.comm.damp_EB_open_boundary(fld.interp, slab=scr)
+            if mode == 'fft':
+                # scratch -> spectral E, B on the side stream; the interpolation grid is complete
+                # on the main stream, so the next gather does not wait for it (lo = hi: no rows
+                # are pending); _wait_eb orders it before the next user of the spectral E, B or
+                # of the scratch slab (the deposition's transform)
+                self._ev_ready.record(main)
+                with t.cuda.stream(side):
+                    side.wait_event(self._ev_ready)
+                    fld.partial_interp2spect('EB', from_scratch=True)
+                    self._ev_done.record(side)
+                fld.partial2interp('EB')
+                self._eb_pending = (self._ev_done, None, None)
+                return
+            self.comm.exchange_fields(fld.interp, 'EB', 'replace', slab=scr)
+            self.comm.damp_EB_open_boundary(fld.interp, slab=scr)
             fld.partial_interp2spect('EB', from_scratch=True)
             fld.partial2interp('EB')
             return
@@ -561,13 +609,17 @@ class Simulation(object):
             fld.partial_interp2spect('EB')
         fld.spect2interp('EB')
 
-    def _wait_eb(self):
-        """Make the main stream wait for a guard-cell exchange of E, B that is still in flight on
-        the communication stream (no-op otherwise): before anything reads the guard rows of the
-        interpolation grid, the spectral E, B, or re-uses the scratch slab."""
-        pend, self._eb_pending = self._eb_pending, None
-        if pend is not None:
-            _capi.torch().cuda.current_stream().wait_event(pend[0])
+    def _wait_eb(self, rows_only=False):
+        """Make the main stream wait for the E, B tail of the previous step that is still in
+        flight on the second stream (no-op otherwise): before anything reads the guard rows of
+        the interpolation grid, the spectral E, B, or re-uses the scratch slab.  `rows_only`:
+        the caller only reads the interpolation grid - nothing to wait for when just the forward
+        FFT of E, B is pending."""
+        pend = self._eb_pending
+        if pend is None or (rows_only and pend[1] is None):
+            return
+        self._eb_pending = None
+        _capi.torch().cuda.current_stream().wait_event(pend[0])
 
     def set_moving_window(self, v=c, **deprecated):
         """Attach a window moving at velocity v to the simulation (main.py:1004-1032)."""

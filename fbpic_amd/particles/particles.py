@@ -117,6 +117,8 @@ class Particles(object):
         self._counts_clean = False
         self._cell_size = None
         self._epoch = 0               # bumped by every host -> device copy of the arrays
+        self._deferred_fields = None  # see defer_fields
+        self._field_store = None
         # `prefix_sum` is the exact inclusive per-cell count of the arrays as they are now (set by
         # the sorts, dropped when particles are added / removed)
         self._prefix_valid = False
@@ -200,11 +202,65 @@ class Particles(object):
     def receive_particles_from_gpu(self):
         if not self.data_is_on_gpu:
             return
+        if self.__dict__.get('_deferred_fields') is not None:
+            self._materialize_fields()
         self.flush_pending_push()
         self._prerank = None
         for k in _STATE + _FIELDS:
             setattr(self, k, _capi.to_host(getattr(self, k)))
         self.data_is_on_gpu = False
+
+    # ---------------------------------------------------------------- deferred E, B
+    def defer_fields(self, fld, rmax_gather, dt):
+        """Called by Simulation.step after the last iteration of a call whose gather did not
+        store E, B on the particles: `fld.d_EB_snap` holds the grids that gather read and the
+        positions have since been pushed twice by dt / 2.  Ex ... Bz are taken off the object and
+        evaluated by the first read (__getattr__): positions stepped back by the two half
+        pushes (same expression, opposite sign: <= 2 ulp from the positions the gather saw), then
+        the plain gather kernel on the saved grids - the values the reference leaves in these
+        arrays (particles.py:703-800), in the CURRENT order of the particles."""
+        if self.q == 0:
+            return
+        g0 = fld.interp[0]
+        self._deferred_fields = (fld.d_EB_snap, len(fld.interp), rmax_gather,
+                                 (g0.invdz, g0.zmin, g0.Nz, g0.invdr, g0.rmin, g0.Nr), dt)
+        self._field_store = [self.__dict__.pop(k) for k in _FIELDS]
+
+    def drop_deferred_fields(self):
+        if self.__dict__.get('_deferred_fields') is not None:
+            self._deferred_fields = None
+            for k, a in zip(_FIELDS, self._field_store):
+                setattr(self, k, a)
+            self._field_store = None
+
+    def _materialize_fields(self):
+        snap, Nm, rmax_gather, geom, dt = self._deferred_fields
+        self.drop_deferred_fields()
+        self.flush_pending_push()
+        lib, p, st = _capi.lib(), _capi.ptr, _capi.stream()
+        pos = [self.x.clone(), self.y.clone(), self.z.clone()]
+        for _ in range(2):
+            _capi.check(lib.fb_push_x(self.Ntot, p(pos[0]), p(pos[1]), p(pos[2]), p(self.ux), p(self.uy),
+                                      p(self.uz), p(self.inv_gamma), c, -0.5 * dt, 1., 1., 1., st),
+                        'fb_push_x')
+        views = [snap[:, f, :] for f in range(6 * Nm)]
+        invdz, zmin, Nz, invdr, rmin, Nr = geom
+        for k in _FIELDS:
+            a = getattr(self, k)
+            if a.shape[0] != self.Ntot:
+                setattr(self, k, _capi.torch().empty(self.Ntot, dtype=a.dtype, device=a.device))
+        rc = lib.fb_gather(_SHAPE[self.particle_shape], Nm, self.Ntot, p(pos[0]), p(pos[1]), p(pos[2]),
+                           rmax_gather, invdz, zmin, Nz, invdr, rmin, Nr, _capi.ptr_array(views),
+                           _capi.row_stride(views[0]), p(self.Ex), p(self.Ey), p(self.Ez), p(self.Bx),
+                           p(self.By), p(self.Bz), st)
+        _capi.check(rc, 'fb_gather')
+
+    def __getattr__(self, name):
+        # only reached when the normal lookup fails: Ex ... Bz while defer_fields holds them back
+        if name in _FIELDS and self.__dict__.get('_deferred_fields') is not None:
+            self._materialize_fields()
+            return self.__dict__[name]
+        raise AttributeError(name)
 
     def generate_continuously_injected_particles(self, time):
         """(8, N) float buffer of the plasma uncovered by the moving window since the last
@@ -307,6 +363,7 @@ class Particles(object):
         if self.q == 0:
             return
         self._need_gpu()
+        self.drop_deferred_fields()
         self.flush_pending_push()
         Nm = len(grid)
         rmax_gather = comm.get_rmax(with_damp=False)
@@ -340,6 +397,7 @@ class Particles(object):
         row is / is not in [a, b) - Simulation.step runs the inside part while the guard-cell
         exchange of E, B is in flight and the outside part after it (can_split_gather)."""
         self._need_gpu()
+        self.drop_deferred_fields()
         self.flush_pending_push()
         if self.q == 0:
             if part == 'inside':

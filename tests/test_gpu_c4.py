@@ -54,7 +54,7 @@ def _build():
     dt = (ZMAX - ZMIN) / NZ / c
     return Simulation(NZ, ZMAX, NR, RMAX, NM, dt, zmin=ZMIN, p_zmin=ramp_start, p_zmax=500.e-6,
                       p_rmin=0., p_rmax=18.e-6, p_nz=2, p_nr=2, p_nt=4, n_e=4.e24,
-                      dens_func=dens_func, n_order=32, particle_shape='linear',
+                      dens_func=dens_func, n_order=32, n_guard=64, particle_shape='linear',
                       boundaries={'z': 'open', 'r': 'reflective'})
 
 
@@ -62,10 +62,8 @@ def _run(rank, world, port, outdir):
     import torch.distributed as dist
     import helpers
     from fbpic_amd.lpa_utils.laser import add_laser_pulse, GaussianLaser
-    # the GLOBAL initial plasma (built before the ranks exist: lattice + one np.random stream)
-    glob = _build()
-    P = np.array([getattr(glob.ptcl[0], k) for k in helpers.PTCL])
-    del glob
+    # the GLOBAL initial plasma (lattice + one np.random stream), built once by the parent
+    P = np.load(os.path.join(outdir, 'global_particles.npy'), mmap_mode='r')
     if world > 1:
         dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank,
                                 world_size=world)
@@ -73,8 +71,9 @@ def _run(rank, world, port, outdir):
     zlo, zhi = sim.comm.get_zmin_zmax(local=True, with_damp=False, with_guard=False, rank=rank)
     if rank == world - 1:
         zhi = np.inf
-    sel = (P[2] >= zlo) & (P[2] < zhi)
-    helpers.set_species_state(sim.ptcl[0], P[:, sel])
+    z = np.asarray(P[2])
+    sel = (z >= zlo) & (z < zhi)
+    helpers.set_species_state(sim.ptcl[0], np.asarray(P[:, sel]))
     add_laser_pulse(sim, GaussianLaser(a0=4., waist=5.e-6, tau=16.e-15, z0=15.e-6))
     sim.set_moving_window(v=c)
     np.random.seed(12345)              # the angles of the injected plasma: same draws in both runs
@@ -119,16 +118,22 @@ def _launch(world, outdir):
 
 
 def test_c4_lwfa_4096x256_on_8_slabs_reproduces_the_single_domain():
+    import helpers
     outdir = tempfile.mkdtemp()
     world = 8
+    glob = _build()
+    np.save(os.path.join(outdir, 'global_particles.npy'),
+            np.array([getattr(glob.ptcl[0], k) for k in helpers.PTCL]))
+    del glob
     _launch(1, outdir)
     _launch(world, outdir)
     one = np.load(os.path.join(outdir, 'w1_r0.npz'))
     parts = [np.load(os.path.join(outdir, 'w%d_r%d.npz' % (world, r))) for r in range(world)]
     # local grids: 512 physical cells each + 2 x n_guard cells (+ 64 damp and n_guard / 2 inject
     # cells at the two ends); the 16 steps include a particle hand-over between all neighbours
+    # (n_guard = 64 >= stencil reach of n_order 32 + 1 = 63: FFT-friendly lengths 640 / 736 / 4416)
     ng = int(one['n_guard'])
-    assert all(int(p['n_guard']) == ng for p in parts) and ng >= 32
+    assert all(int(p['n_guard']) == ng for p in parts) and ng == 64
     end = 512 + 2 * ng + 64 + ng // 2
     assert [int(p['Nz_local']) for p in parts] == [end] + [512 + 2 * ng] * 6 + [end]
     assert int(one['Nz_local']) == 4096 + 2 * ng + 2 * (64 + ng // 2)

@@ -107,3 +107,41 @@ def test_deferred_sources_are_what_the_eager_tail_gives():
         assert isinstance(sim.fld.interp[0].Jr, np.ndarray)
     for a, b in zip(vals[True], vals[False]):
         achieved('deferred J / rho vs eager', np.abs(a - b).max() / np.abs(b).max(), 1e-13)
+
+
+@pytest.mark.parametrize('shape', ['linear', 'cubic'])
+def test_deferred_particle_fields_vs_oracle(oracle, shape):
+    """species.Ex ... Bz after a call whose last gather did not store them: evaluated on first
+    read from the saved grids and the stepped-back positions (Particles.defer_fields).  The
+    oracle keeps its particles in their initial order and stores E, B at every gather
+    (reference semantics), so all 14 arrays can be compared particle by particle."""
+    from fbpic_amd.main import GpuMemoryManager
+    sim = helpers.uniform_plasma_sim(32, 16, 2, (2, 2, 4), shape, seed=6, u_th=0.05)
+    orc = helpers.oracle_from_sim(oracle, sim)
+    with GpuMemoryManager(sim):
+        sim.step(2)
+        sim.step(1)
+        s = sim.ptcl[0]
+        assert s._deferred_fields is not None and 'Ex' not in s.__dict__
+        got = np.array([getattr(s, k).detach().cpu().numpy() for k in helpers.PTCL])
+        assert s._deferred_fields is None
+    orc.step(3)
+    o = orc.species[0]
+    ref = np.array([o[k] for k in helpers.PTCL])
+    o1 = np.lexsort((ref[2], ref[1], ref[0], ref[7]))
+    o2 = np.lexsort((got[2], got[1], got[0], got[7]))
+    for j, k in enumerate(helpers.PTCL):
+        grp = slice(8, 11) if 8 <= j < 11 else (slice(11, 14) if j >= 11 else slice(j, j + 1))
+        sc = np.abs(ref[grp]).max()
+        achieved(None, np.abs(got[j][o2] - ref[j][o1]).max() / sc, 1e-11,
+                 'state' if j < 8 else 'E, B on the particles')
+    # leaving the manager with deferred fields pending: they are evaluated for the host copy
+    sim2 = helpers.uniform_plasma_sim(32, 16, 2, (2, 2, 4), shape, seed=6, u_th=0.05)
+    with GpuMemoryManager(sim2):
+        sim2.step(3)
+    got2 = np.array([getattr(sim2.ptcl[0], k) for k in helpers.PTCL])
+    o3 = np.lexsort((got2[2], got2[1], got2[0], got2[7]))
+    for j in range(8, 14):
+        grp = slice(8, 11) if j < 11 else slice(11, 14)
+        achieved(None, np.abs(got2[j][o3] - ref[j][o1]).max() / np.abs(ref[grp]).max(), 1e-11,
+                 'E, B on the particles (host copy)')
