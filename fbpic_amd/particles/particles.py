@@ -222,7 +222,10 @@ class Particles(object):
         if self.q == 0:
             return
         g0 = fld.interp[0]
-        self._deferred_fields = (fld.d_EB_snap, len(fld.interp), rmax_gather,
+        # the saved grids in the order the gather wants them: per mode Er, Et, Ez, Br, Bt, Bz
+        views = [fld.d_EB_snap[:, fld.interp_index(name, m), :] for m in range(len(fld.interp))
+                 for name in ('Er', 'Et', 'Ez', 'Br', 'Bt', 'Bz')]
+        self._deferred_fields = (views, len(fld.interp), rmax_gather,
                                  (g0.invdz, g0.zmin, g0.Nz, g0.invdr, g0.rmin, g0.Nr), dt)
         self._field_store = [self.__dict__.pop(k) for k in _FIELDS]
 
@@ -234,7 +237,7 @@ class Particles(object):
             self._field_store = None
 
     def _materialize_fields(self):
-        snap, Nm, rmax_gather, geom, dt = self._deferred_fields
+        views, Nm, rmax_gather, geom, dt = self._deferred_fields
         self.drop_deferred_fields()
         self.flush_pending_push()
         lib, p, st = _capi.lib(), _capi.ptr, _capi.stream()
@@ -243,7 +246,6 @@ class Particles(object):
             _capi.check(lib.fb_push_x(self.Ntot, p(pos[0]), p(pos[1]), p(pos[2]), p(self.ux), p(self.uy),
                                       p(self.uz), p(self.inv_gamma), c, -0.5 * dt, 1., 1., 1., st),
                         'fb_push_x')
-        views = [snap[:, f, :] for f in range(6 * Nm)]
         invdz, zmin, Nz, invdr, rmin, Nr = geom
         for k in _FIELDS:
             a = getattr(self, k)

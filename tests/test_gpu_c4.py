@@ -59,8 +59,19 @@ def _build():
 
 
 def _run(rank, world, port, outdir):
+    import time
+    t_start = time.time()
+    tlog = os.path.join(ROOT, 'gpurun_out', 'c4_timing')
+    os.makedirs(tlog, exist_ok=True)
+
+    def mark(what):
+        with open(os.path.join(tlog, 'w%d_r%d.log' % (world, rank)), 'a') as f:
+            f.write('%8.1f s  %s\n' % (time.time() - t_start, what))
+    import torch
+    torch.set_num_threads(2)
     import torch.distributed as dist
     import helpers
+    mark('imports done')
     from fbpic_amd.lpa_utils.laser import add_laser_pulse, GaussianLaser
     # the GLOBAL initial plasma (lattice + one np.random stream), built once by the parent
     P = np.load(os.path.join(outdir, 'global_particles.npy'), mmap_mode='r')
@@ -68,6 +79,7 @@ def _run(rank, world, port, outdir):
         dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank,
                                 world_size=world)
     sim = _build()
+    mark('Simulation built (local grid %d rows)' % sim.fld.Nz)
     zlo, zhi = sim.comm.get_zmin_zmax(local=True, with_damp=False, with_guard=False, rank=rank)
     if rank == world - 1:
         zhi = np.inf
@@ -76,8 +88,10 @@ def _run(rank, world, port, outdir):
     helpers.set_species_state(sim.ptcl[0], np.asarray(P[:, sel]))
     add_laser_pulse(sim, GaussianLaser(a0=4., waist=5.e-6, tau=16.e-15, z0=15.e-6))
     sim.set_moving_window(v=c)
+    mark('particles selected, laser added')
     np.random.seed(12345)              # the angles of the injected plasma: same draws in both runs
     sim.step(NSTEP, correct_currents=False)
+    mark('%d steps done' % NSTEP)
     Nz_phys, iz0 = sim.comm.get_Nz_and_iz(local=True, with_damp=False, with_guard=False, rank=rank)
     _, iz_arr = sim.comm.get_Nz_and_iz(local=True, with_damp=True, with_guard=True, rank=rank)
     sl = slice(iz0 - iz_arr, iz0 - iz_arr + Nz_phys)
@@ -89,6 +103,7 @@ def _run(rank, world, port, outdir):
     for k in PTCL:
         out['p_' + k] = getattr(sim.ptcl[0], k)
     np.savez(os.path.join(outdir, 'w%d_r%d.npz' % (world, rank)), **out)
+    mark('results written')
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -104,6 +119,12 @@ def _worker(rank, world, port, outdir, q):
 
 
 def _launch(world, outdir):
+    # The ranks are processes of ONE host here: keep their BLAS / OpenMP pools small.  The GPU
+    # boxes show 256 logical CPUs but grant a quota of 16 cores; eight processes with one
+    # 256-thread pool each (scipy pinv of the Hankel matrices, NumPy, torch) spend their time
+    # being throttled (measured: 13 minutes for this test, against ~1 with two threads each).
+    for var in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
+        os.environ[var] = '2'
     ctx = mp.get_context('spawn')
     port = _free_port()
     q = ctx.Queue()
