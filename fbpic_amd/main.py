@@ -143,19 +143,21 @@ class Simulation(object):
         # `for _ in range(n): sim.step(1)` then costs what sim.step(n) costs.
         self.carry_state_between_calls = os.environ.get('FBPIC_AMD_CARRY', '1') != '0'
         self._carry = None
-        # Decomposed / open-boundary runs, overlap of the E, B tail of a step with the particles
-        # (reference schedule: main.py:719-769 then :469-490, serial):
-        #   'fft'   (default) the forward FFT of the exchanged (z-real) E, B back to spectral
-        #           space - only the NEXT field push reads it - runs on a second stream next to
-        #           the gather + push of the next step;
-        #   'split' also the message itself and the inverse Hankel transform of the guard rows
-        #           go to the second stream, while the main stream transforms the rows the
-        #           exchange does not touch and gathers + pushes the particles of those rows
-        #           (worth it only when the message latency exceeds the cost of the two extra
-        #           launches: measured on one GPU with a device copy as transport it loses 60 us
-        #           per step, profiles/README.md);
-        #   'off'   everything on the compute stream.
-        self.overlap_guard_exchange = os.environ.get('FBPIC_AMD_OVERLAP', 'fft')
+        # Decomposed / open-boundary runs: what runs on a second stream next to the particle
+        # work of the next step (reference schedule: main.py:719-769 then :469-490, serial).
+        #   'off'   (default) nothing - everything on the compute stream;
+        #   'fft'   the forward FFT of the exchanged (z-real) E, B back to spectral space (only
+        #           the NEXT field push reads it), next to the gather + push;
+        #   'split' also the message itself and the inverse Hankel transform of the guard rows,
+        #           while the main stream transforms the rows the exchange does not touch and
+        #           gathers + pushes the particles of those rows, then the remaining ones.
+        # Measured on one MI355X with a device copy standing in for the transport (C2 per rank,
+        # tools/loopback_multirank.py): off 0.58, fft 0.59, split 0.64 ms per step - the particle
+        # kernels already fill the GPU, a concurrent kernel only time-shares with them, and the
+        # split costs two extra launches.  'split' can only pay when a real message latency
+        # (xGMI, RCCL) exceeds ~60 us; it is kept selectable for that measurement
+        # (FBPIC_AMD_OVERLAP) and pinned by tests/test_gpu_multirank_golden.py.
+        self.overlap_guard_exchange = os.environ.get('FBPIC_AMD_OVERLAP', 'off')
         self._eb_pending = None
         self._comm_stream = None
 

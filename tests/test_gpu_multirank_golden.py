@@ -192,6 +192,26 @@ def test_decomposed_periodic_vs_reference_ranks(name, world):
     print('%s: worst field error %.2e, worst particle error %.2e' % (name, worst[0], worst[1]))
 
 
+@pytest.mark.parametrize('mode', ['fft', 'split'])
+@pytest.mark.parametrize('kind,name', [('periodic', 'mr_periodic_lin_2r'), ('lwfa', 'mr_lwfa_lin_2r')])
+def test_decomposed_with_second_stream_vs_reference_ranks(kind, name, mode):
+    """The two optional overlap schedules of the E, B tail (Simulation.overlap_guard_exchange:
+    forward FFT of the exchanged fields on a second stream / message + guard rows on a second
+    stream with the gather + push split into interior and boundary particles) against the same
+    reference trajectories as the default serial schedule."""
+    g = golden(name)
+    os.environ['FBPIC_AMD_OVERLAP'] = mode
+    try:
+        got = _launch(kind, name, 2)
+    finally:
+        del os.environ['FBPIC_AMD_OVERLAP']
+    steps = [int(v) for v in g['nsteps']]
+    for upto in steps:
+        tol = (5e-13 if upto == 1 else 2e-11) if kind == 'periodic' else 1e-9
+        for r in range(2):
+            _compare(got[r], g, 's%d' % upto, r, tol, tol, ptcl=(upto == steps[-1]))
+
+
 def test_decomposed_lwfa_vs_reference_ranks():
     """C4 in miniature: open z + damping + moving window + continuous injection + laser, 2 ranks."""
     name = 'mr_lwfa_lin_2r'
