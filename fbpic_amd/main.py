@@ -245,6 +245,7 @@ class Simulation(object):
                     # gather+push launch that comes next (nothing reads z in between)
                     wrap_z = (fld.interp[0].zmin, fld.interp[0].zmax)
                 else:
+                    self._wait_eb()      # one exchange at a time on the communicator
                     for species in ptcl:
                         self.comm.exchange_particles(species, fld, self.time)
                 if need_rho_prev:

@@ -122,7 +122,8 @@ def _launch(world, outdir):
     # The ranks are processes of ONE host here: keep their BLAS / OpenMP pools small.  The GPU
     # boxes show 256 logical CPUs but grant a quota of 16 cores; eight processes with one
     # 256-thread pool each (scipy pinv of the Hankel matrices, NumPy, torch) spend their time
-    # being throttled (measured: 13 minutes for this test, against ~1 with two threads each).
+    # being throttled (measured on the test box: 13 minutes for this test, against 28 s with two
+    # threads each).
     for var in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
         os.environ[var] = '2'
     ctx = mp.get_context('spawn')

@@ -1,17 +1,25 @@
-# usage: bash tools/profile_round.sh <tag> [bench args]
+# usage: bash tools/profile_round.sh <tag> [--traffic-only] [bench args]
 # One --kernel-trace --stats run and separate --pmc runs (FETCH_SIZE, WRITE_SIZE, MFMA counters) of
 # the same bench.py command; summaries under gpurun_out/<tag>_*.csv (copy to profiles/).
-TAG=${1:-r02}; shift
+# --traffic-only: kernel stats + FETCH_SIZE + WRITE_SIZE (the passes bench.py's roofline.traffic reads).
+TAG=${1:-r03}; shift
+PASSES="stats fetch write mfma mfmautil"
+if [ "$1" = "--traffic-only" ]; then PASSES="stats fetch write"; shift; fi
 mkdir -p gpurun_out/$TAG
 cd /tmp && export TMPDIR=/tmp
 CMD="python /root/repo/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing $@"
-rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/$TAG/stats -o r -- $CMD > /root/repo/gpurun_out/$TAG/stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d /root/repo/gpurun_out/$TAG/fetch -o r -- $CMD > /root/repo/gpurun_out/$TAG/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d /root/repo/gpurun_out/$TAG/write -o r -- $CMD > /root/repo/gpurun_out/$TAG/write.log 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAVES -d /root/repo/gpurun_out/$TAG/mfma -o r -- $CMD > /root/repo/gpurun_out/$TAG/mfma.log 2>&1
-rocprofv3 --pmc MfmaUtil -d /root/repo/gpurun_out/$TAG/mfmautil -o r -- $CMD > /root/repo/gpurun_out/$TAG/mfmautil.log 2>&1
+for d in $PASSES; do
+  case $d in
+    stats) OPT="--kernel-trace --stats";;
+    fetch) OPT="--pmc FETCH_SIZE";;
+    write) OPT="--pmc WRITE_SIZE";;
+    mfma) OPT="--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAVES";;
+    mfmautil) OPT="--pmc MfmaUtil";;
+  esac
+  rocprofv3 $OPT -d /root/repo/gpurun_out/$TAG/$d -o r -- $CMD > /root/repo/gpurun_out/$TAG/$d.log 2>&1
+done
 cd /root/repo
-for d in stats fetch write mfma mfmautil; do
+for d in $PASSES; do
   db=$(find gpurun_out/$TAG/$d -name '*.db' | head -1)
   mode=pmc; [ $d = stats ] && mode=stats
   name=$d; [ $d = stats ] && name=kernel_stats; [ $d = fetch ] && name=pmc_fetch_size; [ $d = write ] && name=pmc_write_size
@@ -19,5 +27,4 @@ for d in stats fetch write mfma mfmautil; do
   if [ -n "$db" ]; then python tools/rocpd_summary.py $mode $db gpurun_out/${TAG}_${name}.csv; fi
   rm -rf gpurun_out/$TAG/$d
 done
-head -16 gpurun_out/${TAG}_kernel_stats.csv
-grep -i hankel gpurun_out/${TAG}_pmc_mfma.csv gpurun_out/${TAG}_pmc_mfmautil.csv
+head -12 gpurun_out/${TAG}_kernel_stats.csv
