@@ -106,7 +106,7 @@ def test_deferred_sources_are_what_the_eager_tail_gives():
         # leaving the manager copies the grids to the host: NumPy arrays, as in the reference
         assert isinstance(sim.fld.interp[0].Jr, np.ndarray)
     for a, b in zip(vals[True], vals[False]):
-        achieved('deferred J / rho vs eager', np.abs(a - b).max() / np.abs(b).max(), 1e-13)
+        achieved('deferred J / rho vs eager', np.abs(a - b).max() / np.abs(b).max(), 2e-14)
 
 
 @pytest.mark.parametrize('shape', ['linear', 'cubic'])
@@ -133,8 +133,8 @@ def test_deferred_particle_fields_vs_oracle(oracle, shape):
     for j, k in enumerate(helpers.PTCL):
         grp = slice(8, 11) if 8 <= j < 11 else (slice(11, 14) if j >= 11 else slice(j, j + 1))
         sc = np.abs(ref[grp]).max()
-        achieved(None, np.abs(got[j][o2] - ref[j][o1]).max() / sc, 1e-11,
-                 'state' if j < 8 else 'E, B on the particles')
+        achieved(None, np.abs(got[j][o2] - ref[j][o1]).max() / sc, 1e-12,
+                 'state' if j < 8 else 'E, B on the particles')          # measured 9.4e-14
     # leaving the manager with deferred fields pending: they are evaluated for the host copy
     sim2 = helpers.uniform_plasma_sim(32, 16, 2, (2, 2, 4), shape, seed=6, u_th=0.05)
     with GpuMemoryManager(sim2):
@@ -143,5 +143,5 @@ def test_deferred_particle_fields_vs_oracle(oracle, shape):
     o3 = np.lexsort((got2[2], got2[1], got2[0], got2[7]))
     for j in range(8, 14):
         grp = slice(8, 11) if j < 11 else slice(11, 14)
-        achieved(None, np.abs(got2[j][o3] - ref[j][o1]).max() / np.abs(ref[grp]).max(), 1e-11,
+        achieved(None, np.abs(got2[j][o3] - ref[j][o1]).max() / np.abs(ref[grp]).max(), 1e-12,
                  'E, B on the particles (host copy)')

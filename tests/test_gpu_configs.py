@@ -93,7 +93,7 @@ def test_c1_node_aligned_lattice_vs_oracle(oracle, shape):
     o1 = np.lexsort((ref[2], ref[1], ref[0], ref[7]))
     o2 = np.lexsort((got[2], got[1], got[0], got[7]))
     for j, k in enumerate(PTCL[:8]):
-        achieved(None, np.abs(got[j][o2] - ref[j][o1]).max() / np.abs(ref[j]).max(), 1e-11, 'particles vs oracle')
+        achieved(None, np.abs(got[j][o2] - ref[j][o1]).max() / np.abs(ref[j]).max(), 1.5e-12, 'particles vs oracle')
     # (c) cell indices after the steps: identical wherever the particle is not within 1e-9 of
     #     a cell boundary (SURVEY.md 8c tie mask; momenta differ by ~1e-13 between the paths)
     gx, gy, gz = got[0][o2], got[1][o2], got[2][o2]
@@ -179,7 +179,7 @@ def test_hankel_gemm_large(Nz, Nr):
         got = outs[j].cpu().numpy()
         err = np.abs(got - ref).max() / np.abs(ref).max()
         print('hankel %dx%d job %d: %.2e' % (Nz, Nr, j, err))
-        achieved(None, err, 1e-13, 'vs np.dot')
+        achieved(None, err, 2e-14, 'vs np.dot')
 
 
 def test_cycle_cubic_nm4_vs_oracle(oracle):
@@ -195,14 +195,14 @@ def test_cycle_cubic_nm4_vs_oracle(oracle):
             if scale == 0:
                 continue
             err = np.abs(getattr(sim.fld.interp[m], k) - orc.interp[m][k]).max() / scale
-            achieved(None, err, 2e-11, 'fields vs oracle')
+            achieved(None, err, 5e-12, 'fields vs oracle')          # measured 6.8e-13
     s, o = sim.ptcl[0], orc.species[0]
     got = np.array([getattr(s, k) for k in PTCL[:8]])
     ref = np.array([o[k] for k in PTCL[:8]])
     o1 = np.lexsort((ref[2], ref[1], ref[0], ref[7]))
     o2 = np.lexsort((got[2], got[1], got[0], got[7]))
     for j, k in enumerate(PTCL[:8]):
-        achieved(None, np.abs(got[j][o2] - ref[j][o1]).max() / np.abs(ref[j]).max(), 1e-11, 'particles vs oracle')
+        achieved(None, np.abs(got[j][o2] - ref[j][o1]).max() / np.abs(ref[j]).max(), 1e-14, 'particles vs oracle')
 
 
 def test_c5_size_properties():
@@ -241,10 +241,10 @@ def test_c5_size_properties():
         umax = max(float(getattr(s, k).abs().max()) for k in ('ux', 'uy', 'uz'))
     vol = 1. / sim.fld.interp[0].invvol
     q_grid = (rho0.real * vol[None, :]).sum()
-    achieved(None, abs(q_grid - q_tot) / abs(q_tot), 1e-12, 'charge on the grid')
+    achieved(None, abs(q_grid - q_tot) / abs(q_tot), 2e-14, 'charge on the grid')
     assert np.abs(rho0.imag).max() == 0.
     assert np.isfinite(rho3).all()
-    achieved(None, err, 1e-10, 'transform round trip')
+    achieved(None, err, 1.5e-12, 'transform round trip')
     assert umax < 0.1
 
 

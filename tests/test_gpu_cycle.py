@@ -64,10 +64,12 @@ def test_cycle_vs_reference_golden(name):
     sim = build_from_golden(g, name)
     utr = bool(g['use_true_rho'])
     done = 0
-    for upto, tol in ((1, 5e-13), (2, 2e-12), (5, 2e-11)):
+    # bounds = 10 x the worst deviation measured on MI355X (profiles/r03_achieved_errors.json):
+    # fields 3.1e-13 / 1.5e-13 / 6.2e-14 after 1 / 2 / 5 steps, particles 5.7e-14
+    for upto, tol in ((1, 5e-13), (2, 1.5e-12), (5, 1e-12)):
         sim.step(upto - done, use_true_rho=utr)
         done = upto
-        compare_state(sim, g, 's%d' % upto, tol, tol)
+        compare_state(sim, g, 's%d' % upto, tol, 5e-13)
 
 
 @pytest.mark.parametrize('name', ['cycle_galilean_cub_16x8', 'cycle_comoving_lin_16x8',
@@ -79,10 +81,11 @@ def test_galilean_cycle_vs_reference_golden(name):
     g = golden(name)
     sim = build_from_golden(g, name)
     done = 0
-    for upto, tol in ((1, 5e-13), (2, 2e-12), (5, 2e-11)):
+    # (measured: <= 1.6e-15 on fields, <= 7e-16 on particles at every snapshot)
+    for upto, tol in ((1, 5e-14), (2, 5e-14), (5, 5e-14)):
         sim.step(upto - done)
         done = upto
-        compare_state(sim, g, 's%d' % upto, tol, tol)
+        compare_state(sim, g, 's%d' % upto, tol, 2e-14)
         assert abs(sim.fld.interp[0].zmin - float(g['s%d_zmin' % upto])) <= 1e-15 * float(g['zmax'])
 
 
@@ -99,10 +102,11 @@ def test_crossdeposition_cycle_vs_reference_golden(name):
     sim = build_from_golden(g, name)
     assert sim.fld.current_correction == 'cross-deposition'
     done = 0
-    for upto, tol in ((1, 1e-11), (2, 2e-11), (5, 1e-10)):
+    # (measured: spectral fields 2.1e-12 / 1.0e-12 / 4.5e-13 after 1 / 2 / 5 steps, particles 7e-16)
+    for upto, tol in ((1, 1e-11), (2, 1e-11), (5, 5e-12)):
         sim.step(upto - done)
         done = upto
-        compare_state(sim, g, 's%d' % upto, tol, tol)
+        compare_state(sim, g, 's%d' % upto, tol, 2e-14)
         assert abs(sim.fld.interp[0].zmin - float(g['s%d_zmin' % upto])) <= 1e-15 * float(g['zmax'])
 
 
@@ -120,7 +124,7 @@ def test_bunch_deposition_vs_reference_golden(shape):
                 F = getattr(sim.fld.interp[m], k)
                 grp = [0, 1, 2] if i < 3 else [3]
                 scale = np.abs(ref[:, grp]).max() + np.abs(F).max()
-                achieved(None, np.abs(F - ref[m, i]).max() / scale, 1.e-13 * (5 if it > 1 else 1), 'step %d' % it)
+                achieved(None, np.abs(F - ref[m, i]).max() / scale, 1.e-14, 'step %d' % it)      # measured 5.7e-16; the reference's own bound is 1e-13
 
 
 @pytest.mark.parametrize('shape,Nm', [('linear', 2), ('cubic', 2), ('linear', 4), ('cubic', 3)])
@@ -138,14 +142,14 @@ def test_cycle_vs_oracle_medium(oracle, shape, Nm):
             if scale == 0:
                 continue
             err = np.abs(getattr(sim.fld.interp[m], k) - orc.interp[m][k]).max() / scale
-            achieved(None, err, 2e-11, 'fields')
+            achieved(None, err, 5e-12, 'fields')          # measured <= 6.7e-13
     s, o = sim.ptcl[0], orc.species[0]
     got = np.array([getattr(s, k) for k in PTCL[:8]])
     ref = np.array([o[k] for k in PTCL[:8]])
     o1 = np.lexsort((ref[2], ref[1], ref[0], ref[7]))
     o2 = np.lexsort((got[2], got[1], got[0], got[7]))
     for j, k in enumerate(PTCL[:8]):
-        achieved(None, np.abs(got[j][o2] - ref[j][o1]).max() / np.abs(ref[j]).max(), 1e-11, 'particles')
+        achieved(None, np.abs(got[j][o2] - ref[j][o1]).max() / np.abs(ref[j]).max(), 1e-14, 'particles')      # 5.3e-16
 
 
 def _plasma_wave(shape, Nz=64, Nr=64, Nm=2, ppc=(2, 2, 8), n_periods=1, n_order=-1):
@@ -243,7 +247,7 @@ def test_headline_size_properties():
         rho0 = sim.fld.interp[0].rho.cpu().numpy()
     vol = 1. / sim.fld.interp[0].invvol
     q_grid = (rho0.real * vol[None, :]).sum()
-    achieved(None, abs(q_grid - q_tot) / abs(q_tot), 1e-12, 'charge on the grid')
+    achieved(None, abs(q_grid - q_tot) / abs(q_tot), 2e-14, 'charge on the grid')      # 1.2e-15
     assert np.abs(rho0.imag).max() == 0.                  # mode 0 is real
     # (d) linearity of the spectral solve: transform round trip is the identity
     with GpuMemoryManager(sim):
@@ -251,7 +255,7 @@ def test_headline_size_properties():
         sim.fld.interp2spect('E')
         sim.fld.spect2interp('E')
         err = (sim.fld.interp[1].Er - E0).abs().max().item() / max(E0.abs().max().item(), 1e-300)
-    achieved(None, err, 1e-11, 'transform round trip')
+    achieved(None, err, 2e-13, 'transform round trip')      # 1.5e-14
 
 
 def test_empty_and_tiny_species_step():
@@ -314,12 +318,12 @@ def test_reference_sequence_equals_fused_sequence(oracle, shape):
             ea = np.abs(getattr(a.fld.interp[m], k) - orc.interp[m][k]).max() / scale
             eb = np.abs(getattr(b.fld.interp[m], k) - orc.interp[m][k]).max() / scale
             worst = max(worst, ea, eb)
-            achieved(None, max(ea, eb), 2e-11, 'fields vs oracle')
+            achieved(None, max(ea, eb), 5e-12, 'fields vs oracle')      # measured 4.8e-13
     for sa, sb in zip(a.ptcl, b.ptcl):
         ga = np.array([getattr(sa, k) for k in PTCL[:8]])
         gb = np.array([getattr(sb, k) for k in PTCL[:8]])
         o1 = np.lexsort((ga[2], ga[1], ga[0], ga[7]))
         o2 = np.lexsort((gb[2], gb[1], gb[0], gb[7]))
         for j, k in enumerate(PTCL[:8]):
-            achieved(None, np.abs(ga[j][o1] - gb[j][o2]).max() / np.abs(ga[j]).max(), 1e-11, 'particles fused vs reference sequence')
+            achieved(None, np.abs(ga[j][o1] - gb[j][o2]).max() / np.abs(ga[j]).max(), 1e-14, 'particles fused vs reference sequence')
     print('reference vs fused sequence (%s): worst deviation from the oracle %.2e' % (shape, worst))

@@ -25,7 +25,7 @@ def test_field_and_particle_dumps(tmp_path):
     for m in range(2):
         for k in ('Er', 'Ez', 'Bt', 'Jz', 'rho'):
             a, b = getattr(sim.fld.interp[m], k), getattr(ref.fld.interp[m], k)
-            achieved(None, np.abs(a - b).max() / max(np.abs(b).max(), 1e-300), 1e-12, 'run with hooks vs without')
+            achieved(None, np.abs(a - b).max() / max(np.abs(b).max(), 1e-300), 4e-13, 'run with hooks vs without')
     files = sorted(p.name for p in (tmp_path / 'npz').iterdir())
     assert files == ['checkpoint00000004.npz', 'fields00000000.npz', 'fields00000002.npz',
                      'fields00000004.npz', 'particles_electrons00000000.npz',
@@ -38,7 +38,7 @@ def test_field_and_particle_dumps(tmp_path):
     for m in range(2):
         for key, attr in (('E_r', 'Er'), ('E_z', 'Ez'), ('B_t', 'Bt'), ('rho', 'rho')):
             b = getattr(ref2.fld.interp[m], attr)
-            achieved(None, np.abs(d[key][m] - b).max() / max(np.abs(b).max(), 1e-300), 1e-11, 'dump vs run stopped there')
+            achieved(None, np.abs(d[key][m] - b).max() / max(np.abs(b).max(), 1e-300), 5e-13, 'dump vs run stopped there')
     p = np.load(tmp_path / 'npz' / 'particles_electrons00000003.npz')
     assert p['x'].shape == (sim.ptcl[0].Ntot,) and set(p.files) >= {'ux', 'w', 'Ex', 'Ez'}
     c = np.load(tmp_path / 'npz' / 'checkpoint00000004.npz')
@@ -85,7 +85,7 @@ def test_restart_periodic_run6_equals_run3_restart_run3(tmp_path):
     assert it == 3 and b.iteration == 3 and abs(b.time - 3 * b.dt) < 1e-30
     b.step(3)
     assert b.iteration == a.iteration == 6
-    _assert_same(_state(b), _state(a), 1e-12)
+    _assert_same(_state(b), _state(a), 2e-13)          # measured 1.6e-14
     # the latest checkpoint is picked when no iteration is given
     c = uniform_plasma_sim(32, 16, 2, (2, 2, 4), 'cubic', seed=98)
     assert restart_from_checkpoint(c, checkpoint_dir=str(tmp_path)) == 6
@@ -122,7 +122,7 @@ def test_restart_lwfa_moving_window(tmp_path):
     np.random.seed(5)
     b.step(7)
     assert b.fld.interp[0].zmin == a.fld.interp[0].zmin and b.ptcl[0].Ntot == a.ptcl[0].Ntot
-    _assert_same(_state(b), _state(a), 1e-10)
+    _assert_same(_state(b), _state(a), 7e-13)          # measured 6.5e-14
 
 
 def test_field_dump_against_oracle(oracle, tmp_path):
@@ -143,4 +143,4 @@ def test_field_dump_against_oracle(oracle, tmp_path):
             for k in attrs:
                 name = 'rho' if key == 'rho' else '%s_%s' % (key, k[-1])
                 err = np.abs(d[name][m] - orc.interp[m][k]).max() / scale
-                achieved(None, err, 2e-11, 'dump vs oracle')
+                achieved(None, err, 5e-13, 'dump vs oracle')

@@ -54,9 +54,10 @@ def test_lwfa_moving_window_vs_reference(shape):
     for j, k in enumerate(PTCL[:8]):
         assert np.array_equal(getattr(sim.ptcl[0], k), g['s0_ptcl0'][j]), k
     # laser fields on the grid (device FFT + Hankel, host algebra in spectral space)
-    _compare_fields(sim, g, 's0', 1e-11, groups=('E', 'B'))
+    _compare_fields(sim, g, 's0', 2e-13, groups=('E', 'B'))      # measured 1.2e-14
     done = 0
-    for upto, tol in ((6, 1e-9), (14, 1e-8)):
+    # (measured: fields 1.9e-13 / 1.3e-13, particles 1.4e-13 / 6.2e-13 after 6 / 14 steps)
+    for upto, tol in ((6, 2e-12), (14, 6e-12)):
         sim.step(upto - done)
         done = upto
         tag = 's%d' % upto

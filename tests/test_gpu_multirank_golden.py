@@ -186,9 +186,10 @@ def test_decomposed_periodic_vs_reference_ranks(name, world):
         last = upto == steps[-1]
         # rounding differences (summation order of the deposition, FFT, GEMM) grow through the
         # PIC loop as in the single-domain trajectories: 5e-13 after 1 step, 2e-11 after 5
-        tol = 5e-13 if upto == 1 else 2e-11
+        # measured on MI355X: fields <= 2.6e-14 / 1.3e-14, particles 3.5e-16
+        tol = 2.5e-13 if upto == 1 else 2e-13
         for r in range(world):
-            _compare(got[r], g, 's%d' % upto, r, tol, tol, ptcl=last, worst=worst)
+            _compare(got[r], g, 's%d' % upto, r, tol, 1e-14, ptcl=last, worst=worst)
     print('%s: worst field error %.2e, worst particle error %.2e' % (name, worst[0], worst[1]))
 
 
@@ -207,7 +208,7 @@ def test_decomposed_with_second_stream_vs_reference_ranks(kind, name, mode):
         del os.environ['FBPIC_AMD_OVERLAP']
     steps = [int(v) for v in g['nsteps']]
     for upto in steps:
-        tol = (5e-13 if upto == 1 else 2e-11) if kind == 'periodic' else 1e-9
+        tol = (2.5e-13 if upto == 1 else 2e-13) if kind == 'periodic' else 2.5e-12
         for r in range(2):
             _compare(got[r], g, 's%d' % upto, r, tol, tol, ptcl=(upto == steps[-1]))
 
@@ -219,11 +220,12 @@ def test_decomposed_lwfa_vs_reference_ranks():
     got = _launch('lwfa', name, 2)
     worst = [0., 0.]
     for r in range(2):
-        _compare(got[r], g, 's0', r, 1e-11, 1e-11, nfields=6, ptcl=False, worst=worst)
+        _compare(got[r], g, 's0', r, 2.5e-13, 2.5e-13, nfields=6, ptcl=False, worst=worst)
     steps = [int(v) for v in g['nsteps']]
     for upto in steps:
         for r in range(2):
-            _compare(got[r], g, 's%d' % upto, r, 1e-9, 1e-9, ptcl=(upto == steps[-1]), worst=worst)
+            # measured: fields 1.1e-13, particles 2.5e-13
+            _compare(got[r], g, 's%d' % upto, r, 2.5e-12, 2.5e-12, ptcl=(upto == steps[-1]), worst=worst)
     print('%s: worst field error %.2e, worst particle error %.2e' % (name, worst[0], worst[1]))
 
 
@@ -242,6 +244,6 @@ def test_decomposed_on_real_gpus(kind, name, world, backend):
     got = _launch(kind, name, world, backend)
     steps = [int(v) for v in g['nsteps']]
     for upto in steps:
-        tol = (5e-13 if upto == 1 else 2e-11) if kind == 'periodic' else 1e-9
+        tol = (2.5e-13 if upto == 1 else 2e-13) if kind == 'periodic' else 2.5e-12
         for r in range(world):
             _compare(got[r], g, 's%d' % upto, r, tol, tol, ptcl=(upto == steps[-1]))
