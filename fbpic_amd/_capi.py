@@ -35,7 +35,7 @@ _SIGNATURES = {
                                      P, P, P, P, P, P, D, D, D, D, D, D, D, D, D, D, D, I, P, Z, I, P]),
     'fb_gather_push_rank_next_range': (I, [I, I, L, P, P, P, P, P, P, P, D, D, D, I, D, D, I, _PP, L,
                                            P, P, P, P, P, P, D, D, D, D, D, D, D, D, D, D, D, I, P, Z, I,
-                                           P, P, I, P, P]),
+                                           P, P, I, P]),
     'fb_cell_index': (I, [L, P, P, P, D, D, I, D, D, I, P, P, P]),
     'fb_sort_workspace_bytes': (Z, [L, I]),
     'fb_sort_by_cell': (I, [L, I, P, P, P, P, ctypes.POINTER(I), P, P, Z, P]),

@@ -586,58 +586,6 @@ __device__ __forceinline__ double other_xor16(double v)
     return odd ? __hiloint2double(b[0], a[0]) : __hiloint2double(b[1], a[1]);
 }
 
-// Order in which a wave visits the (cell-sorted) particles.
-//   linear : `cpw` consecutive chunks of 64 particles (cells in r-fastest order along one z row);
-//   tiled  : the particles of a TZ x TR tile of cells, row by row (bounds from the per-cell prefix
-//            sum: 2 lanes-worth of integers per wave).
-// Why tiles: a wave that sweeps 64 cells along r needs (64 + 3) x 4 node columns of every field
-// and shares them with the waves of the neighbouring z rows only if those run at the same time;
-// with the cubic shape, Nm = 4 and Nr = 512 (BASELINE C5) the node rows of ONE cell row are 6.3 MB
-// against 4 MB of L2 per XCD, and rocprofv3 counted 18.4 GB of HBM traffic per launch for 7.5 GB of
-// particle streams (profiles/r03_v1_c5_pmc_*).  An 8 x 8 tile needs 11 x 11 node columns, all
-// re-used inside the wave's own short-lived footprint.
-struct ChunkWalk {
-    int nrows, row;
-    long base, end;
-    // rs_ / re_ (returned through the arguments, constant for the life of the wave): lane r holds
-    // [start, end) of row r of this wave's walk (particle indices)
-    __device__ __forceinline__ void init_linear(long chunk0, int cpw, long n, int &rs_, int &re_)
-    {
-        const long b = chunk0 * 64, e = (chunk0 + cpw) * 64;
-        rs_ = (int)(b < n ? b : n); re_ = (int)(e < n ? e : n);
-        nrows = 1; row = -1; base = 0; end = 0;
-    }
-    __device__ __forceinline__ void init_tiled(long tile, long ntiles, int tiles_r, int TZ, int TR,
-                                               int Nz, int Nr, const int *__restrict__ prefix, int lane,
-                                               int &rs_, int &re_)
-    {
-        rs_ = 0; re_ = 0; nrows = 0; row = -1; base = 0; end = 0;
-        if (tile >= ntiles) return;
-        const int tz = (int)(tile / tiles_r), tr = (int)(tile - (long)tz * tiles_r);
-        const int iz0 = tz * TZ, ir0 = tr * TR;
-        nrows = min(TZ, Nz - iz0);
-        if (lane < nrows) {
-            const long c0 = (long)(iz0 + lane) * (Nr + 1) + ir0;
-            const long c1 = (long)(iz0 + lane) * (Nr + 1) + min(ir0 + TR, Nr + 1);
-            rs_ = c0 > 0 ? prefix[c0 - 1] : 0;
-            re_ = prefix[c1 - 1];
-        }
-    }
-    // to the next chunk; false when the walk is over
-    __device__ __forceinline__ bool next(int rs_, int re_)
-    {
-        base += 64;
-        while (base >= end) {
-            row++;
-            if (row >= nrows) return false;
-            const int r = __builtin_amdgcn_readfirstlane(row);
-            base = __builtin_amdgcn_readlane(rs_, r);
-            end = __builtin_amdgcn_readlane(re_, r);
-        }
-        return true;
-    }
-};
-
 template <int NMT> struct GMX {
     static_assert(NMT >= 2 && NMT <= 4, "matrix-core gather: 2 <= Nm <= 4");
     static constexpr int QM = (NMT == 2) ? 2 : 1;      // lane quarters per mode
@@ -676,8 +624,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         GatherGrids G, long rs,
         double *__restrict__ Ex, double *__restrict__ Ey, double *__restrict__ Ez,
         double *__restrict__ Bx, double *__restrict__ By, double *__restrict__ Bz,
-        int chunks_per_wave, PushArgs PA,
-        const int *__restrict__ prefix, int tile_z, int tile_r, int tiles_r, long ntiles)
+        int chunks_per_wave, PushArgs PA)
 {
     using C = GMX<NMT>;
     constexpr int NT = C::NT, FPL = C::FPL, RS = C::RS, NVL = C::NVL, WPAD = C::WPAD;
@@ -712,20 +659,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     // columns no field maps to (Nm = 3: the fourth quarter; Nm = 2: half of the second tile) stay 0
     for (int o = lane; o < 16 * RS; o += 64) panel[o] = 0.;
 
-    ChunkWalk wk, wn;
-    int wrs, wre;
-    {
-        const long unit = xcd_block_id() * nwaves + wave;
-        if (prefix) wk.init_tiled(unit, ntiles, tiles_r, tile_z, tile_r, Nz, Nr, prefix, lane, wrs, wre);
-        else wk.init_linear(unit * chunks_per_wave, chunks_per_wave, n, wrs, wre);
-    }
-    bool have = wk.next(wrs, wre);
+    const long chunk0 = (xcd_block_id() * nwaves + wave) * chunks_per_wave;
     double xn = 0., yn = 0., zn = 0.;
-    if (have && wk.base + lane < wk.end) { xn = x[wk.base + lane]; yn = y[wk.base + lane]; zn = z[wk.base + lane]; }
+    if (chunk0 * 64 + lane < n) { xn = x[chunk0 * 64 + lane]; yn = y[chunk0 * 64 + lane]; zn = z[chunk0 * 64 + lane]; }
     RankPending pend = {-1, 0, 0, 0};
-    while (have) {
-        const long i = wk.base + lane;
-        const bool act = i < wk.end;
+    for (int ch = 0; ch < chunks_per_wave; ch++) {
+        const long base = (chunk0 + ch) * 64;
+        if (base >= n) break;
+        const long i = base + lane;
+        const bool act = i < n;
         double cs = 1., sn = 0., Sz[4] = {0., 0., 0., 0.}, Sr[4] = {0., 0., 0., 0.};
         int kz = G_NOKEY, kr = G_NOKEY;
         bool inside = false;
@@ -736,10 +678,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
             while (zj >= PA.wzmax) zj -= l_box;
             while (zj < PA.wzmin) zj += l_box;
         }
-        // coordinates of the next chunk of the walk: requested now
-        wn = wk;
-        have = wn.next(wrs, wre);
-        if (have && wn.base + lane < wn.end) { xn = x[wn.base + lane]; yn = y[wn.base + lane]; zn = z[wn.base + lane]; }
+        if (ch + 1 < chunks_per_wave && i + 64 < n) { xn = x[i + 64]; yn = y[i + 64]; zn = z[i + 64]; }
         // momenta of the chunk: requested now, used by the push at the end (this kernel's
         // occupancy is set by its LDS panels, the 8 registers are free)
         double mom[4] = {0., 0., 0., 0.};
@@ -896,7 +835,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
         // the pending ranks spill - 5.2 -> 5.6 ms)
         gather_finish<false>(act, i, lane, xj, yj, zj, cs, sn, F, Ex, Ey, Ez, Bx, By, Bz, PA,
                              invdz, zmin, Nz, invdr, rmin, Nr, pend, mom);
-        wk = wn;
     }
 }
 
@@ -960,8 +898,7 @@ template <int NMT>
 static int launch_gather_cubic_mx(long n, const double *x, const double *y, const double *z,
         double rmax_gather, double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
         const GatherGrids &G, long row_stride, double *Ex, double *Ey, double *Ez, double *Bx,
-        double *By, double *Bz, const PushArgs &PA, hipStream_t s, const char *where,
-        const int *prefix_sum = nullptr)
+        double *By, double *Bz, const PushArgs &PA, hipStream_t s, const char *where)
 {
     using C = GMX<NMT>;
     // waves per workgroup so that as many waves as possible share the 160 KB of a CU
@@ -972,31 +909,11 @@ static int launch_gather_cubic_mx(long n, const double *x, const double *y, cons
     int cpw = (int)((nchunks + target_waves - 1) / target_waves);
     if (cpw < 1) cpw = 1;
     if (cpw > 64) cpw = 64;
-    long total_waves = (nchunks + cpw - 1) / cpw;
-    // Tiled walk (ChunkWalk) when the per-cell prefix sum of the sorted arrays is given and the
-    // node rows that one cell row of the r-fastest walk touches do not fit the L2 of an XCD:
-    // 4 node rows x Nr x 6 Nm fields x one 128-B line per 4 nodes of 64 B.  Tiles of 8 z rows;
-    // their width gives a wave about as many particles as the linear walk does.
-    int tile_z = 0, tile_r = 0, tiles_r = 0;
-    long ntiles = 0;
-    const double row_bytes = 4. * Nr * 6 * NMT * 128.;
-    const char *force = getenv("FBPIC_AMD_GATHER_TILES");
-    if (prefix_sum && n > 0 && ((row_bytes > 2.5e6 && !force) || (force && force[0] == '1'))) {
-        const double per_cell = (double)n / ((double)Nz * Nr);
-        tile_z = 8;
-        tile_r = (int)(64. * cpw / (tile_z * (per_cell > 1e-3 ? per_cell : 1e-3)) + 0.5);
-        if (tile_r < 1) tile_r = 1;
-        if (tile_r > Nr + 1) tile_r = Nr + 1;
-        tiles_r = (Nr + 1 + tile_r - 1) / tile_r;
-        ntiles = (long)((Nz + tile_z - 1) / tile_z) * tiles_r;
-        total_waves = ntiles;
-    } else {
-        prefix_sum = nullptr;
-    }
+    const long total_waves = (nchunks + cpw - 1) / cpw;
     dim3 grid((unsigned)xcd_grid((total_waves + nwaves - 1) / nwaves)), block(64 * nwaves);
     hipLaunchKernelGGL((k_gather_cubic_mx<NMT>), grid, block, wave_bytes * nwaves, s, n, x, y, z,
                        rmax_gather, invdz, zmin, Nz, invdr, rmin, Nr, G, row_stride, Ex, Ey, Ez,
-                       Bx, By, Bz, cpw, PA, prefix_sum, tile_z, tile_r, tiles_r, ntiles);
+                       Bx, By, Bz, cpw, PA);
     return check(hipGetLastError(), where);
 }
 
@@ -1004,7 +921,7 @@ static int launch_gather(int shape, int Nm, long n, const double *x, const doubl
         const double *z, double rmax_gather, double invdz, double zmin, int Nz, double invdr,
         double rmin, int Nr, const void *const *grids, long row_stride,
         double *Ex, double *Ey, double *Ez, double *Bx, double *By, double *Bz,
-        const PushArgs &PA, hipStream_t s, const char *where, const int *prefix_sum = nullptr)
+        const PushArgs &PA, hipStream_t s, const char *where)
 {
     if (n <= 0) return 0;
     if (Nm < 1 || Nm > FB_MAX_MODES) { set_error(where, "Nm out of range"); return -1; }
@@ -1017,7 +934,7 @@ static int launch_gather(int shape, int Nm, long n, const double *x, const doubl
     for (int i = 6 * Nm; i < 6 * FB_MAX_MODES; i++) G.g[i] = nullptr;
     if (shape == FB_SHAPE_CUBIC && Nm >= 2 && Nm <= 4 && !getenv("FBPIC_AMD_GATHER_VALU") && !PA.range_mode) {
 #define FB_MX(NMT) launch_gather_cubic_mx<NMT>(n, x, y, z, rmax_gather, invdz, zmin, Nz, invdr, rmin, Nr, G, \
-                                               row_stride, Ex, Ey, Ez, Bx, By, Bz, PA, s, where, prefix_sum)
+                                               row_stride, Ex, Ey, Ez, Bx, By, Bz, PA, s, where)
         return Nm == 2 ? FB_MX(2) : (Nm == 3 ? FB_MX(3) : FB_MX(4));
 #undef FB_MX
     }
@@ -1078,7 +995,7 @@ static int gather_push_impl(const char *who, int shape, int Nm, long n, double *
         double *Ex, double *Ey, double *Ez, double *Bx, double *By, double *Bz,
         double q, double m, double c, double dt, double dt_x, double wrap_zmin, double wrap_zmax,
         const RankNext &RK, void *stream, const int *range_lo = nullptr, const int *range_hi = nullptr,
-        int range_mode = 0, const int *prefix_sum = nullptr)
+        int range_mode = 0)
 {
     PushArgs PA;
     PA.RK = RK;
@@ -1096,8 +1013,7 @@ static int gather_push_impl(const char *who, int shape, int Nm, long n, double *
     }
     if (RK.count && dt_x == 0.) { set_error(who, "ranking needs the position push (dt_x != 0)"); return -1; }
     return launch_gather(shape, Nm, n, x, y, z, rmax_gather, invdz, zmin, Nz, invdr, rmin, Nr,
-                         grids, row_stride, Ex, Ey, Ez, Bx, By, Bz, PA, (hipStream_t)stream, who,
-                         prefix_sum);
+                         grids, row_stride, Ex, Ey, Ez, Bx, By, Bz, PA, (hipStream_t)stream, who);
 }
 
 extern "C" int fb_gather_push(int shape, int Nm, long n, double *x, double *y, double *z,
@@ -1122,7 +1038,7 @@ extern "C" int fb_gather_push_rank_next_range(int shape, int Nm, long n, double 
         double q, double m, double c, double dt, double dt_x, double wrap_zmin, double wrap_zmax,
         double dt_push, double x_push, double y_push, double z_push, int ncell,
         void *sort_workspace, size_t workspace_bytes, int counts_are_zero,
-        const int *range_lo, const int *range_hi, int range_mode, const int *prefix_sum, void *stream)
+        const int *range_lo, const int *range_hi, int range_mode, void *stream)
 {
     const char *who = "fb_gather_push_rank_next";
     hipStream_t s = (hipStream_t)stream;
@@ -1139,7 +1055,7 @@ extern "C" int fb_gather_push_rank_next_range(int shape, int Nm, long n, double 
     return gather_push_impl(who, shape, Nm, n, x, y, z, ux, uy, uz, inv_gamma, rmax_gather,
                             invdz, zmin, Nz, invdr, rmin, Nr, grids, row_stride, Ex, Ey, Ez, Bx, By, Bz,
                             q, m, c, dt, dt_x, wrap_zmin, wrap_zmax, RK, stream, range_lo, range_hi,
-                            range_mode, prefix_sum);
+                            range_mode);
 }
 
 extern "C" int fb_gather_push_rank_next(int shape, int Nm, long n, double *x, double *y, double *z,
@@ -1154,5 +1070,5 @@ extern "C" int fb_gather_push_rank_next(int shape, int Nm, long n, double *x, do
     return fb_gather_push_rank_next_range(shape, Nm, n, x, y, z, ux, uy, uz, inv_gamma, rmax_gather,
             invdz, zmin, Nz, invdr, rmin, Nr, grids, row_stride, Ex, Ey, Ez, Bx, By, Bz, q, m, c, dt,
             dt_x, wrap_zmin, wrap_zmax, dt_push, x_push, y_push, z_push, ncell, sort_workspace,
-            workspace_bytes, counts_are_zero, nullptr, nullptr, 0, nullptr, stream);
+            workspace_bytes, counts_are_zero, nullptr, nullptr, 0, stream);
 }

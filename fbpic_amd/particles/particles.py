@@ -438,24 +438,20 @@ class Particles(object):
                 self.q, self.m, c, self.dt, dt_x, wz[0], wz[1],
                 rank_next[0], rank_next[1], rank_next[2], rank_next[3], self.prefix_sum.shape[0],
                 p(self._sort_ws), self._sort_ws.shape[0], clean, lo_ptr, hi_ptr,
-                1 if part == 'inside' else 2, None, _capi.stream())
+                1 if part == 'inside' else 2, _capi.stream())
             self._counts_clean = False
             _capi.check(rc, 'fb_gather_push_rank_next_range')
             if part == 'inside':
                 return                      # the book-keeping below belongs to the completed pass
         elif ranked:
-            # the prefix sum of the sort that produced the present order of the arrays (if there
-            # was one): the kernel may visit the particles tile by tile instead of linearly
-            ps = p(self.prefix_sum) if self._prefix_valid else None
-            rc = _capi.lib().fb_gather_push_rank_next_range(
+            rc = _capi.lib().fb_gather_push_rank_next(
                 _SHAPE[self.particle_shape], Nm, self.Ntot, p(self.x), p(self.y), p(self.z),
                 p(self.ux), p(self.uy), p(self.uz), p(self.inv_gamma),
                 comm.get_rmax(with_damp=False), g0.invdz, g0.zmin, g0.Nz, g0.invdr, g0.rmin, g0.Nr,
                 _capi.ptr_array(views), _capi.row_stride(views[0]), *eb,
                 self.q, self.m, c, self.dt, dt_x, wz[0], wz[1],
                 rank_next[0], rank_next[1], rank_next[2], rank_next[3], self.prefix_sum.shape[0],
-                p(self._sort_ws), self._sort_ws.shape[0], int(self._counts_clean), None, None, 0,
-                ps, _capi.stream())
+                p(self._sort_ws), self._sort_ws.shape[0], int(self._counts_clean), _capi.stream())
             self._counts_clean = False
             _capi.check(rc, 'fb_gather_push_rank_next')
         else:

@@ -139,13 +139,7 @@ int fb_gather_push_rank_next(int shape, int Nm, long n, double *x, double *y, do
  * the particles whose stencil lies in rows that the pending guard-cell exchange of E, B does not
  * touch while that exchange is in flight on another stream, then the rest.  The two calls of a
  * step share one sort workspace: pass counts_are_zero = 1 to the second.  (Not with the cubic
- * matrix-core gather: returns an error.)
- * prefix_sum: NULL, or the inclusive per-cell particle count of the cell-sorted arrays (what
- * fb_bin_sort_particles / fb_push_x_sort_deposit_* leave in `prefix_sum`; its last entry must be
- * n).  It only lets the kernel choose the ORDER in which it visits the particles: on large grids
- * (cubic shape, node rows of one cell row larger than the L2 of an XCD) tiles of 8 z rows of
- * cells instead of the r-fastest sweep, so that grid nodes are fetched from HBM once.  Results do
- * not depend on it. */
+ * matrix-core gather: returns an error.) */
 int fb_gather_push_rank_next_range(int shape, int Nm, long n, double *x, double *y, double *z,
                              double *ux, double *uy, double *uz, double *inv_gamma,
                              double rmax_gather, double invdz, double zmin, int Nz, double invdr,
@@ -155,8 +149,7 @@ int fb_gather_push_rank_next_range(int shape, int Nm, long n, double *x, double 
                              double wrap_zmin, double wrap_zmax,
                              double dt_push, double x_push, double y_push, double z_push, int ncell,
                              void *sort_workspace, size_t workspace_bytes, int counts_are_zero,
-                             const int *range_lo, const int *range_hi, int range_mode,
-                             const int *prefix_sum, void *stream);
+                             const int *range_lo, const int *range_hi, int range_mode, void *stream);
 
 /* ---- cell sort ---------------------------------------------------------------- */
 /* particles/particles.py:1075-1081 -> get_cell_idx_per_particle

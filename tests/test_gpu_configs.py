@@ -182,13 +182,8 @@ def test_hankel_gemm_large(Nz, Nr):
         achieved(None, err, 2e-14, 'vs np.dot')
 
 
-@pytest.mark.parametrize('tiles', ['auto', 'forced'])
-def test_cycle_cubic_nm4_vs_oracle(oracle, tiles, monkeypatch):
-    """C5's kernels (cubic shape, Nm = 4, p_nt = 16) on a grid the oracle steps in seconds.
-    'forced': the tile-by-tile order of visiting the particles that the matrix-core gather takes
-    on C5-sized grids (ChunkWalk, csrc/particles.hip), forced on this small one."""
-    if tiles == 'forced':
-        monkeypatch.setenv('FBPIC_AMD_GATHER_TILES', '1')
+def test_cycle_cubic_nm4_vs_oracle(oracle):
+    """C5's kernels (cubic shape, Nm = 4, p_nt = 16) on a grid the oracle steps in seconds."""
     sim = helpers.uniform_plasma_sim(64, 48, 4, (2, 2, 16), 'cubic', seed=7, u_th=0.05)
     orc = helpers.oracle_from_sim(oracle, sim, nthreads=4)
     sim.step(3)
