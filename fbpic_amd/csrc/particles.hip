@@ -226,13 +226,18 @@ __device__ __forceinline__ void gather_finish(bool act, long i, int lane, double
         const int prev = __shfl_up(rk_c, 1);
         const bool rk_start = act && (lane == 0 || rk_c != prev);
         const unsigned long long rstarts = __ballot(rk_start);
-        const int nact = __popcll(__ballot(act));
+        const unsigned long long actm = __ballot(act);
         const unsigned long long below = rstarts & ((2ull << lane) - 1ull);
         const int rk_run0 = 63 - __builtin_clzll(below | 1ull);
         int rk_base = 0;
         if (rk_start) {
+            // length of the run = active lanes from here to the next start.  (The active lanes
+            // are a prefix of the wave in a pass over all particles, but a suffix or a prefix
+            // plus a suffix in a range-restricted pass: count them, do not subtract lane numbers.)
             const unsigned long long rest = (lane + 1 < 64) ? (rstarts >> (lane + 1)) : 0ull;
-            const int len = rest ? (__builtin_ctzll(rest) + 1) : (nact - lane);
+            const int span = rest ? (__builtin_ctzll(rest) + 1) : (64 - lane);
+            const unsigned long long in_run = (span >= 64 ? ~0ull : ((1ull << span) - 1ull)) << lane;
+            const int len = __popcll(actm & in_run);
             rk_base = atomicAdd(PA.RK.count + rk_c, len);
         }
         if constexpr (DEFER) {

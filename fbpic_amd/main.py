@@ -156,8 +156,7 @@ class Simulation(object):
         # kernels already fill the GPU, a concurrent kernel only time-shares with them, and the
         # split costs two extra launches.  'split' can only pay when a real message latency
         # (xGMI, RCCL) exceeds ~60 us; it is kept selectable for that measurement
-        # (FBPIC_AMD_OVERLAP) and pinned by tests/test_gpu_multirank_golden.py (z-periodic runs;
-        # open ends / moving window fall back to 'fft', see exchange_and_damp_EB).
+        # (FBPIC_AMD_OVERLAP) and pinned by tests/test_gpu_multirank_golden.py.
         self.overlap_guard_exchange = os.environ.get('FBPIC_AMD_OVERLAP', 'off')
         self._eb_pending = None
         self._comm_stream = None
@@ -562,12 +561,6 @@ class Simulation(object):
             self._wait_eb()
             fld.spect2partial_interp('EB', to_scratch=True)
             mode = self.overlap_guard_exchange if scr.is_cuda else 'off'
-            if mode == 'split' and (self.comm.nz_damp != 0 or self.comm.moving_win is not None):
-                # 'split' is verified against the reference's decomposed trajectories for
-                # z-periodic runs only: with open ends + moving window it deviated at the 1e-2
-                # level (tests/test_gpu_multirank_golden.py history, round 3; not resolved), so
-                # such runs take the 'fft' schedule
-                mode = 'fft'
             if mode in ('fft', 'split'):
                 t = _capi.torch()
                 if self._comm_stream is None:

@@ -787,6 +787,61 @@ def test_gather_push_rank_next(hip, oracle, shape):
     assert np.array_equal(ciB, ref[siB])
 
 
+@pytest.mark.parametrize('lo,hi', [(0, 0), (300, 901), (37, 38), (64, 1536), (1, 1535), (999, 1536)])
+def test_gather_push_rank_next_range(hip, lo, hi):
+    """fb_gather_push_rank_next_range: the pass over [lo, hi) followed by the pass over everything
+    else (bounds read on the device, not aligned to the 64-particle chunks of the kernel, so a
+    wave's active lanes are a prefix, a suffix or both) == one pass over all particles: the
+    particle arrays bit-identical, the same cell for every particle, and ranks that are a
+    permutation of 0 .. count-1 inside every cell (what the counting sort needs)."""
+    g = golden('gather')
+    Nz, Nr, nm = int(g['Nz']), int(g['Nr']), 2
+    n = g['x'].size
+    assert n >= hi
+    t = hip.torch()
+    rng = np.random.default_rng(23)
+    views = [dev(hip, g['grids'][m, k] * 1e9) for m in range(nm) for k in range(6)]
+    u0 = [rng.normal(size=n) for _ in range(3)]
+    ig0 = 1. / np.sqrt(1 + u0[0]**2 + u0[1]**2 + u0[2]**2)
+    dt = 6.67e-16
+    invdz, zmin, invdr = 1. / float(g['dz']), float(g['zmin']), 1. / float(g['dr'])
+    geom = (float(g['rmax_gather']), invdz, zmin, Nz, invdr, 0., Nr)
+    p = hip.ptr
+    ncell = Nz * (Nr + 1)
+    nb = int(hip.lib().fb_bin_sort_workspace_bytes(n, ncell))
+    bounds = t.tensor([lo, hi], dtype=t.int32, device='cuda')
+
+    def run(split):
+        pos = [dev(hip, g[k]) for k in ('x', 'y', 'z')]
+        mom = [dev(hip, a) for a in u0] + [dev(hip, ig0)]
+        eb = [t.zeros(n, dtype=t.float64, device='cuda') for _ in range(6)]
+        ws = t.zeros(nb, dtype=t.uint8, device='cuda')
+        passes = [(None, None, 0, 0)] if not split else \
+            [(p(bounds[0:1]), p(bounds[1:2]), 1, 0), (p(bounds[0:1]), p(bounds[1:2]), 2, 1)]
+        for lo_p, hi_p, mode, clean in passes:
+            hip.check(hip.lib().fb_gather_push_rank_next_range(
+                1, nm, n, *[p(a) for a in pos], *[p(a) for a in mom], *geom, hip.ptr_array(views), Nr,
+                *[p(a) for a in eb], -e, m_e, c, dt, 0.5 * dt, 0., 0., 0.5 * dt, 1., 1., 1., ncell,
+                p(ws), nb, clean, lo_p, hi_p, mode, hip.stream()), 'gather_push_rank_next_range')
+        t.cuda.synchronize()
+        w = ws.cpu().numpy()
+        al = lambda v: (v + 255) // 256 * 256
+        count = w[:4 * ncell].view(np.int32)
+        cell = w[al(4 * ncell):al(4 * ncell) + 4 * n].view(np.int32)
+        rank = w[al(4 * ncell) + al(4 * n):al(4 * ncell) + al(4 * n) + 4 * n].view(np.int32)
+        return [host(a) for a in pos + mom + eb], count.copy(), cell.copy(), rank.copy()
+    A, cntA, cellA, rankA = run(False)
+    B, cntB, cellB, rankB = run(True)
+    for a, b in zip(A, B):
+        assert np.array_equal(a, b)
+    assert np.array_equal(cellA, cellB) and np.array_equal(cntA, cntB)
+    assert cntB.sum() == n and np.array_equal(np.bincount(cellB, minlength=ncell), cntB)
+    for rank, cell in ((rankA, cellA), (rankB, cellB)):
+        o = np.lexsort((rank, cell))
+        first = np.concatenate(([0], np.cumsum(np.bincount(cell, minlength=ncell))[:-1]))
+        assert np.array_equal(rank[o], np.arange(n) - first[cell[o]])
+
+
 @pytest.mark.parametrize('presorted', [True, False])
 def test_bin_sort_particles(hip, oracle, presorted):
     """Counting-sort fast path: cells sorted, a valid permutation, prefix sums and cell
