@@ -111,7 +111,15 @@ def _run(rank, world, port, outdir):
 
 def _worker(rank, world, port, outdir, q):
     try:
+        # a rank that is still running after 75 s writes where it is (a hang of one rank
+        # stalls all the others in their next exchange)
+        import faulthandler
+        tlog = os.path.join(ROOT, 'gpurun_out', 'c4_timing')
+        os.makedirs(tlog, exist_ok=True)
+        stack = open(os.path.join(tlog, 'w%d_r%d_stack.log' % (world, rank)), 'w')
+        faulthandler.dump_traceback_later(75, repeat=False, file=stack)
         _run(rank, world, port, outdir)
+        faulthandler.cancel_dump_traceback_later()
         q.put((rank, 'ok'))
     except Exception:  # pragma: no cover
         import traceback
@@ -132,9 +140,19 @@ def _launch(world, outdir):
     procs = [ctx.Process(target=_worker, args=(r, world, port, outdir, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=1500) for _ in range(world)]
+    import queue
+    res = []
+    try:
+        for _ in range(world):
+            res.append(q.get(timeout=180))
+    except queue.Empty:
+        pass
     for p in procs:
-        p.join(120)
+        p.join(5 if len(res) < world else 120)
+        if p.is_alive():
+            p.kill()
+    assert len(res) == world, ('only %d of %d ranks finished within 3 minutes; stacks of the others: '
+                               'gpurun_out/c4_timing/w%d_r*_stack.log' % (len(res), world, world))
     for rank, msg in res:
         assert msg == 'ok', 'world %d rank %d:\n%s' % (world, rank, msg)
 

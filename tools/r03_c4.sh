@@ -1,4 +1,6 @@
 mkdir -p gpurun_out/r03
-timeout 420 python -m pytest tests/test_gpu_c4.py -q --durations=3 2>&1 | grep -v amdgpu.ids | tail -15
-cat gpurun_out/c4_timing/*.log
-python -m pytest tests/test_gpu_carry.py "tests/test_gpu_multirank_golden.py::test_decomposed_with_second_stream_vs_reference_ranks" -q 2>&1 | grep -v amdgpu.ids | tail -12
+for i in 1 2; do
+  timeout 400 python -m pytest tests/test_gpu_c4.py -q -k c4_lwfa --durations=2 2>&1 | grep -v amdgpu.ids | tail -6
+  tail -n 2 gpurun_out/c4_timing/w8_r0.log
+done
+ls gpurun_out/c4_timing/; for f in gpurun_out/c4_timing/*stack.log; do if [ -s $f ]; then echo "== $f"; head -40 $f; fi; done
