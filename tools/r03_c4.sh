@@ -1,6 +1,6 @@
 mkdir -p gpurun_out/r03
-for i in 1 2; do
-  timeout 400 python -m pytest tests/test_gpu_c4.py -q -k c4_lwfa --durations=2 2>&1 | grep -v amdgpu.ids | tail -6
-  tail -n 2 gpurun_out/c4_timing/w8_r0.log
+for i in 1 2 3; do
+  timeout 300 python -m pytest tests/test_gpu_c4.py -q -s -k c4_lwfa > gpurun_out/r03/c4_try$i.log 2>&1
+  if grep -q "1 failed" gpurun_out/r03/c4_try$i.log; then echo "try $i FAILED"; break; else echo "try $i ok"; fi
 done
-ls gpurun_out/c4_timing/; for f in gpurun_out/c4_timing/*stack.log; do if [ -s $f ]; then echo "== $f"; head -40 $f; fi; done
+dmesg 2>/dev/null | tail -20 > gpurun_out/r03/dmesg.log
