@@ -598,8 +598,6 @@ class Simulation(object):
                 fld.partial2interp('EB')
                 self._eb_pending = (self._ev_done, None, None)
                 return
-            self.comm.exchange_fields(fld.interp, 'EB', 'replace', slab=scr)
-            self.comm.damp_EB_open_boundary(fld.interp, slab=scr)
             fld.partial_interp2spect('EB', from_scratch=True)
             fld.partial2interp('EB')
             return
