@@ -30,6 +30,16 @@ def rel_err(a, b):
 
 
 _ACHIEVED = []
+# Deviations measured on MI355X in round 3 (worst of two full runs on two boxes; run-to-run
+# spread <= 3.1x): every recorded check is also held to 10x that figure (not below 5e-15, a few
+# tens of ulp), whatever wider bound the test states - so that a bound can never again be six
+# orders of magnitude wider than what the kernels deliver (in round 3 such a bound hid an
+# open-boundary damping that was applied twice per step: 4e-8 under a 1e-9 ... 1e-8 bound).
+try:
+    import json as _json
+    _MEASURED = _json.load(open(os.path.join(GOLDEN, 'achieved_r03.json')))
+except (OSError, ValueError):
+    _MEASURED = {}
 
 
 def achieved(name, err, tol, what=''):
@@ -42,6 +52,9 @@ def achieved(name, err, tol, what=''):
         name = name.replace('test_', '', 1)
         if what:
             name += ' ' + what
+    ref = _MEASURED.get(name)
+    if ref is not None:
+        tol = min(float(tol), max(10. * ref, 5e-15))
     _ACHIEVED.append((name, float(err), float(tol)))
     assert err < tol, (name, err, tol)
 
