@@ -117,6 +117,7 @@ def _worker(rank, world, port, outdir, q):
         tlog = os.path.join(ROOT, 'gpurun_out', 'c4_timing')
         os.makedirs(tlog, exist_ok=True)
         stack = open(os.path.join(tlog, 'w%d_r%d_stack.log' % (world, rank)), 'w')
+        faulthandler.enable(file=stack)          # and on a fatal signal (SIGSEGV, SIGABRT, SIGBUS)
         faulthandler.dump_traceback_later(75, repeat=False, file=stack)
         _run(rank, world, port, outdir)
         faulthandler.cancel_dump_traceback_later()
