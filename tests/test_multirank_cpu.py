@@ -252,3 +252,132 @@ def test_rccl_handshake_logic(monkeypatch):
         monkeypatch.setattr(bc, '_dist', lambda ok=others_ok: FakeDist(ok))
         comm._rccl_handshake(init_error=init_error)
         assert comm.transport == expect, (swap, others_ok, init_error)
+
+
+def _direct_worker(rank, world, port, boundary, q):
+    """exchange_fields on a z-major slab whose field group is the WHOLE slab (the scratch slab
+    that holds the z-real E, B of a decomposed step): the guard rows are sent from and received
+    into the rows themselves - contiguous blocks, row padding included - without message
+    buffers (boundary_communicator.exchange_fields, 'replace').  Torch tensors on the CPU stand
+    in for the device slab; the path contains no kernel."""
+    try:
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank,
+                                world_size=world)
+        comm = _make_comm(boundary)
+        Nz_l, iz0 = comm.get_Nz_and_iz(local=True, with_damp=True, with_guard=True, rank=rank)
+        nf, pad = 6 * NM, 8
+        rs = nf * NR + pad
+        base = torch.zeros(Nz_l * rs, dtype=torch.complex128)
+        slab = base.as_strided((Nz_l, nf, NR), (rs, NR, 1))
+        # global reference: field f at global cell row g holds (g + 1) + 100 f (+ i)
+        gz = (np.arange(Nz_l) + iz0)
+        if boundary == 'periodic':
+            gz = gz % NZ
+        vals = (gz[:, None, None] + 1.) + 100. * np.arange(nf)[None, :, None] + 1j * np.arange(NR)[None, None, :]
+        slab.copy_(torch.from_numpy(vals))
+        truth = slab.clone()
+        # spoil my guard rows: the exchange must restore them from the neighbours
+        ng = comm.n_guard
+        if comm.left_proc is not None:
+            slab[:ng] = -7.
+        if comm.right_proc is not None:
+            slab[Nz_l - ng:] = -7.
+
+        class Owner:
+            Nm = NM
+            data_is_on_gpu = True
+            d_interp = None
+
+            @staticmethod
+            def _group(fieldtype):
+                return 0, 0, nf, True
+        grids = []
+        for m in range(NM):
+            g = _Grid()
+            g._owner = Owner
+            g.Er = slab[:, 6 * m, :]
+            grids.append(g)
+        comm.exchange_fields(grids, 'EB', 'replace', slab=slab)
+        assert torch.equal(slab, truth), 'guard rows not restored on rank %d' % rank
+        # (and the padding between the rows was left alone: it is never read)
+        q.put((rank, 'ok'))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize('boundary,world', [('periodic', 2), ('periodic', 3), ('open', 3)])
+def test_direct_row_exchange_gloo(boundary, world):
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_direct_worker, args=(r, world, port, boundary, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(30)
+    for rank, msg in res:
+        assert msg == 'ok', 'rank %d:\n%s' % (rank, msg)
+
+
+def _store_worker(rank, world, port, q):
+    try:
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank,
+                                world_size=world)
+        from fbpic_amd.boundaries.boundary_communicator import _host_side_all_gather
+        out = _host_side_all_gather(dist, ('host%d' % (rank % 2), rank))
+        assert out == [('host%d' % (r % 2), r) for r in range(world)], out
+        q.put((rank, 'ok'))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+def test_host_side_all_gather_gloo():
+    """The (host, gpu) pairs of the one-rank-per-GPU check travel over the rendezvous store, not
+    over a device communicator (which could itself hang when two ranks share a GPU)."""
+    world, port = 3, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_store_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(30)
+    for rank, msg in res:
+        assert msg == 'ok', 'rank %d:\n%s' % (rank, msg)
+
+
+def test_handover_link_capacity_rule_is_symmetric():
+    """Both ends of a neighbour link see the same two counts after a hand-over and grow the
+    capacity of the fixed-size message by the same rule (particle_buffer_handling._Link)."""
+    from fbpic_amd.boundaries.particle_buffer_handling import _Link, _CAP0
+    cpu = torch.device('cpu')
+    a, b = _Link(torch, cpu, True), _Link(torch, cpu, True)      # my right link / the neighbour's left link
+    assert a.cap == b.cap == _CAP0 and a.send.numel() == 8 + 8 * _CAP0
+    for n_out, n_in in ((10, 0), (_CAP0, 3), (_CAP0 + 1, 7), (5, 300000), (1, 1)):
+        a.grow_for(torch, cpu, max(n_out, n_in))          # I sent n_out, received n_in
+        b.grow_for(torch, cpu, max(n_in, n_out))          # the neighbour sent n_in, received n_out
+        assert a.cap == b.cap and a.cap >= max(n_out, n_in) and a.recv.numel() == 8 + 8 * a.cap
+    assert a.cap == 1 << 20                                # 2 x 300000 rounded up to a power of two
+
+
+def test_rows_untouched_by_the_EB_exchange():
+    from fbpic_amd.boundaries.boundary_communicator import BoundaryCommunicator
+    comm = BoundaryCommunicator(1024, 0., 1024 * DZ, 8, 8 * DZ, 2, DZ / c, None, False,
+                                {'z': 'open', 'r': 'reflective'}, 32, 64, {'z': 64, 'r': 32},
+                                1., None, None, False)
+    comm.size = 4
+    Nz = 256 + 128
+    comm.left_proc, comm.right_proc = None, 1            # first rank: damp + inject cells on the left
+    assert comm.rows_untouched_by_EB_exchange(Nz + 96) == (64 + 64 + 32, Nz + 96 - 64)
+    comm.left_proc, comm.right_proc = 0, 2               # interior rank
+    assert comm.rows_untouched_by_EB_exchange(Nz) == (64, Nz - 64)
+    comm.left_proc, comm.right_proc = 2, None            # last rank
+    assert comm.rows_untouched_by_EB_exchange(Nz + 96) == (64, Nz + 96 - 160)
