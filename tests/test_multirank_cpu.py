@@ -119,8 +119,12 @@ def _worker(rank, world, port, boundary, q):
                 assert got.shape == (Nz_g, NR) and np.array_equal(got, G), with_damp
             else:
                 assert got is None
-        # ---------------- particle hand-over
+        # ---------------- particle hand-over (fixed-size messages with the count in the header;
+        # a capacity of 16 particles makes every link overflow: the remainder message and the
+        # growth of the link capacities are exercised too)
+        from fbpic_amd.boundaries import particle_buffer_handling as pbh
         from fbpic_amd.boundaries.particle_buffer_handling import exchange_particles_between_ranks
+        pbh._CAP0 = 16
 
         class _Sp:
             def on_particle_number_changed(self):
@@ -144,6 +148,8 @@ def _worker(rank, world, port, boundary, q):
         g0.zmin, g0.zmax, g0.dz = zmin_l, zmax_l, DZ
         fld.interp = [g0]
         exchange_particles_between_ranks(comm, sp, fld, 0.)
+        links = [sp._handover[k] for k in ('left', 'right')]
+        assert all((not l.present) or l.cap >= 32 for l in links), [l.cap for l in links]
         znew = sp.z.numpy()
         assert sp.Ntot == znew.size == sp.Ex.shape[0] and sp.changed
         assert np.all(znew >= zlo - 1e-12) and np.all(znew <= zhi + 1e-12)
