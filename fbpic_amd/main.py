@@ -183,6 +183,7 @@ class Simulation(object):
                    and self._carry == self._carry_signature())
         self._carry = None
         self._last_call_carried = carried
+        self._data_stays_on_gpu = was_on_gpu
         try:
             self._step_loop(N, correct_currents, use_true_rho, move_positions, move_momenta,
                             carried=carried)
@@ -210,9 +211,9 @@ class Simulation(object):
             return None
         sig = [self.iteration, fld._epoch, fld.d_interp.data_ptr(), fld.d_interp._version,
                fld.d_spect.data_ptr(), fld.d_spect._version, fld.interp[0].zmin,
-               comm._zmin_global_domain, len(self.ptcl)]
+               comm._zmin_global_domain, len(self.ptcl), self.dt, self.filter_currents]
         for sp in self.ptcl:
-            sig.append((id(sp), sp.Ntot, sp._epoch, sp._pending_push, sp._pending_J is None))
+            sig.append((id(sp), sp.Ntot, sp.q, sp.m, sp._epoch, sp._pending_push, sp._pending_J is None))
             for k in ('x', 'y', 'z', 'ux', 'uy', 'uz', 'w', 'inv_gamma'):
                 a = getattr(sp, k)
                 sig.append((a.data_ptr(), a._version))
@@ -408,7 +409,9 @@ class Simulation(object):
         move, positions and momenta both advanced by the fused passes (the deferred evaluation
         steps the positions back by one full push)."""
         comm = self.comm
-        return bool(self.carry_state_between_calls and comm.size == 1 and comm.nz_damp == 0
+        # (a call that copies everything back to the host at its end stores them in the gather)
+        return bool(self.carry_state_between_calls and getattr(self, '_data_stays_on_gpu', False)
+                    and comm.size == 1 and comm.nz_damp == 0
                     and comm.moving_win is None and not self.use_galilean
                     and self.fld.current_correction != 'cross-deposition'
                     and all(sp.use_bin_sort for sp in self.ptcl))

@@ -80,6 +80,12 @@ def test_carry_dropped_when_the_user_touches_the_data():
             sim.ptcl[0].w *= 1.5                       # heavier macroparticles: rho_prev is stale
             sim.step(1)
             assert sim._last_call_carried is False
+            sim.ptcl[0].q *= 1.                        # unchanged value: still carried
+            sim.step(1)
+            assert sim._last_call_carried is carry
+            sim.ptcl[0].q *= 0.5                       # a plain attribute, no tensor: noticed too
+            sim.step(1)
+            assert sim._last_call_carried is False
             sim.step(1)
             assert sim._last_call_carried is carry
             sim.fld.interp[1].Er[3:9, 2:5] += 1.e9     # E changed on the grid: must be re-transformed
@@ -139,6 +145,10 @@ def test_deferred_particle_fields_vs_oracle(oracle, shape):
     sim2 = helpers.uniform_plasma_sim(32, 16, 2, (2, 2, 4), shape, seed=6, u_th=0.05)
     with GpuMemoryManager(sim2):
         sim2.step(3)
+        assert sim2.ptcl[0]._deferred_fields is not None
+        q0 = sim2.ptcl[0].q
+        sim2.ptcl[0].q = 2 * q0          # a plain attribute, no tensor: still noticed
+        sim2.ptcl[0].q = q0
     got2 = np.array([getattr(sim2.ptcl[0], k) for k in helpers.PTCL])
     o3 = np.lexsort((got2[2], got2[1], got2[0], got2[7]))
     for j in range(8, 14):
