@@ -49,6 +49,10 @@ _SIGNATURES = {
                                        _PP, P, P, P, P, Z, I, I, I, D, _PP, L, L, P, P, P]),
     'fb_push_x_sort_deposit_J_rho': (I, [L, I, P, P, P, P, P, P, P, D, D, D, D, D, D, D, I, D, D, I, I, _PP,
                                          _PP, P, P, P, P, Z, I, I, I, D, D, _PP, L, L, _PP, L, L, P, P, P]),
+    'fb_gather_push_deposit_supported': (I, [I, I]),
+    'fb_gather_push_deposit_J_rho': (I, [I, I, L, P, P, P, P, P, P, P, P, P, D, D, D, I, D, D, I, _PP, L,
+                                         P, P, P, P, P, P, D, D, D, D, D, D, D, _PP, L, L, _PP, L, L,
+                                         P, P, P, P]),
     'fb_permute': (I, [L, P, I, _PP, _PP, P]),
     'fb_handover_pack': (I, [L, P, I, _PP, P, L, P]),
     'fb_handover_move': (I, [L, P, P, I, _PP, P]),
@@ -204,7 +208,7 @@ class _TimedLib(object):
         f = getattr(self._real, name)
         if not name.startswith('fb_') or name in ('fb_last_error', 'fb_abi_version',
                                                   'fb_sort_workspace_bytes', 'fb_bin_sort_workspace_bytes', 'fb_handover_workspace_bytes', 'fb_fft_plan_create',
-                                                  'fb_fft_plan_destroy', 'fb_sync', 'fb_set_device', 'fb_comm_unique_id', 'fb_comm_init', 'fb_comm_destroy', 'fb_zfft_supported', 'fb_fft_generic_supported', 'fb_fft_generic_from_records_supported'):
+                                                  'fb_fft_plan_destroy', 'fb_sync', 'fb_set_device', 'fb_gather_push_deposit_supported', 'fb_comm_unique_id', 'fb_comm_init', 'fb_comm_destroy', 'fb_zfft_supported', 'fb_fft_generic_supported', 'fb_fft_generic_from_records_supported'):
             return f
         t = torch()
         recs = self._records.setdefault(name, [])

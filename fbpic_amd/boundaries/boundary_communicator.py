@@ -584,6 +584,7 @@ class BoundaryCommunicator(object):
         """Single periodic domain: wrap z into [zmin, zmax) (particle_buffer_handling.py:
         514-556).  Decomposed domain: hand the particles that left the local physical
         range to the neighbours (boundary_communicator.py:750-826)."""
+        species._touch()
         species.flush_pending_push()
         species._prerank = None
         if self.n_guard == 0:

@@ -290,11 +290,18 @@ def exchange_particles_between_ranks(comm, species, fld, time):
     # sum is no longer exact.
     nearly_sorted = bool(getattr(species, 'sorted', False) and (n_leave + n_in) * 16 < max(n_new, 1))
     moved = getattr(species, '_moved_since_sort', 0.)
+    home = getattr(species, '_home_valid', False) and species.cell_idx is not None
+    home_ptr = species.cell_idx.data_ptr() if home else None
     species.on_particle_number_changed()
     species._prefix_valid = False
     if nearly_sorted:
         species.sorted = True
         species._moved_since_sort = moved
+        # The home cells of the one-pass cycle (Particles.cycle) stay usable as well: a particle
+        # that was moved into a hole or appended meets some other particle's (or no) home cell
+        # and is simply treated as one that has left it - any content gives the same result.
+        species._home_valid = bool(home and species.cell_idx is not None
+                                   and species.cell_idx.data_ptr() == home_ptr)
     # capacities for the next hand-over (same rule, same numbers on both ends of a link)
     L.grow_for(t, dev, max(n_sl, n_rl))
     R.grow_for(t, dev, max(n_sr, n_rr))

@@ -1,0 +1,554 @@
+// The particle work of one PIC step as ONE pass over the particles (gfx950):
+//   gather E,B at x(n) -> Vay push_p -> push_x(dt/2) -> deposit J from x(n+1/2) -> push_x(dt/2)
+//   -> deposit rho from x(n+1)
+// i.e. main.py:469-528 of the reference (gather, push_p, push_x, deposit('J'), push_x,
+// deposit('rho_next')) with every particle attribute read once and written once: 64 B read +
+// 56 B written per particle, where the two-pass sequence (fb_gather_push_rank_next +
+// fb_push_x_sort_deposit_J_rho) moves 252 B and re-sorts the arrays every step.
+//
+// What makes the single pass possible is NOT sorting every step.  The run-based deposition and
+// the segment-based gather need particles of one cell to be contiguous; a plasma changes that
+// order slowly (a 0.01 c thermal plasma: ~1.6 % of the particles change cell per step), so the
+// arrays are counting-sorted every few steps only (fb_bin_sort_particles, which also records the
+// cell of every particle at that moment: `home`), and in between
+//   * the runs / segments of a wave are those of the HOME cells - contiguous by construction, 2-3
+//     per 64 particles at 32 ppc, found with one ballot on `home`;
+//   * a particle that still has the stencil of its home cell takes part in the run (matrix-core
+//     reduction, one flush per cell) or reads the segment's staged node values;
+//   * a particle that has left its home cell (a "stray") does not break the run of its
+//     neighbours: the deposition writes its (Sz Sr) x amplitude products directly (lane = node x
+//     amplitude, one atomic instruction per engine, DepEngine::scatter_one), the gather stages
+//     its own stencil as one more segment of the same L2 round trip.
+// Correctness never depends on the order (every particle is deposited / gathered exactly once
+// either way); only the share of strays - reported in `stats` for the host's sort policy - does.
+//
+// Per-particle arithmetic is that of the separate entry points (k_gather / vay / k_push_x /
+// DepEngine::stage): momenta and positions are bit-identical to the four-call sequence, the
+// deposited sums differ by summation order only.
+#include <cstdlib>
+#include "fb_common.h"
+#include "push_common.h"
+#include "dep_engine.h"
+
+namespace fb {
+
+struct CycleArgs {
+    long n;
+    double *x, *y, *z, *ux, *uy, *uz, *ig;
+    const double *w;
+    const int *home;                           // cell ir_upper + iz_upper (Nr+1) at the last sort
+    double *Ex, *Ey, *Ez, *Bx, *By, *Bz;       // optional: gathered fields stored
+    double invdz, zmin;
+    int Nz;
+    double invdr, rmin;
+    int Nr;
+    double inv_ncol;                           // 1 / (Nr + 1)
+    double rmax_gather;
+    GatherGrids G;
+    long rsG;
+    const cplx *baseG;                         // lowest of the grids (all within 4 GiB of it)
+    double econst, bconst, chdt;               // q dt/(m c), q dt/(2 m), c dt_x
+    double wzmin, wzmax;                       // periodic wrap of z before the gather (off: max <= min)
+    double q, c_light;
+    DepGrids GJ;
+    long rsJ;
+    DepGrids GR;
+    long rsR;
+    cplx *baseJ, *baseR;                       // dep_grids_base() of the two targets
+    const double *beta0, *betah;               // Ruyten coefficients, mode 0 / modes >= 1
+    int chunks_per_wave;
+    unsigned long long *stats;                 // optional: [1024] strays of the J deposition
+};
+
+// PIPE: the node values of chunk c+1 are requested right after the stencil sums of chunk c and
+// travel during its push and depositions (own LDS panel: 12.5 KB per wave at Nm = 2, 3 waves per
+// SIMD); !PIPE: they are requested at the end of chunk c into a panel that shares its LDS with the
+// deposition engines (7.8 KB per wave, 4 waves per SIMD).
+template <int NM, bool PIPE> struct CyclePlan {
+    static constexpr int S = 2;
+    static constexpr int NV = S * S * 6 * NM;              // complex node values of a segment
+    static constexpr int NVL = (NV + 63) / 64;             // ... per lane
+    static constexpr int NSEG = (NVL == 1) ? 6 : 3;        // segments staged per round
+    // panel stride in doubles: load j of a segment fills the 16-B slots 64 j ... of its lanes
+    // (only NV of them in all), + a 16-B pad (segments start on different banks)
+    static constexpr int PSTR = 2 * NV + 2;
+    using EJ = DepEngine<FB_SHAPE_LINEAR, 3, NM, true, true>;
+    using ER = DepEngine<FB_SHAPE_LINEAR, 1, NM, true, true>;
+    static constexpr int DEP_DOUBLES = EJ::L::WAVE_DOUBLES > ER::L::WAVE_DOUBLES ? EJ::L::WAVE_DOUBLES
+                                                                                 : ER::L::WAVE_DOUBLES;
+    static constexpr int GATHER_DOUBLES = NSEG * PSTR;
+    // the two panels do not share LDS: the node values of chunk c+1 arrive while chunk c deposits
+    static constexpr int WAVE_DOUBLES = PIPE ? GATHER_DOUBLES + DEP_DOUBLES
+                                             : (GATHER_DOUBLES > DEP_DOUBLES ? GATHER_DOUBLES : DEP_DOUBLES);
+};
+
+// Array pointers are fetched from the kernel-argument segment where they are used (one scalar
+// load each) instead of living in scalar registers across the whole chunk loop: with ~20 array
+// pointers on top of the geometry, the two engines' state and the lane masks the kernel needs
+// more than the 102 SGPRs of a wave, and every spilled one costs v_readlane / v_writelane
+// instructions on the VALU - the unit this kernel is bound by.
+template <class T>
+__device__ __forceinline__ T *karg_ptr(int byte_offset)
+{
+    T *p;
+    asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
+                 : "=s"(p) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "n"(byte_offset));
+    return p;
+}
+#ifdef FB_ISA_MARKS
+#define FB_MARK(x) asm volatile("; MARK " x)
+#else
+#define FB_MARK(x)
+#endif
+#define KP(T, field) karg_ptr<T>((int)__builtin_offsetof(CycleArgs, field))
+
+// Front half of a chunk: what can be done as soon as the positions are there - the keys of the
+// home runs, the stencil origin of every particle, which particles are strays, the segment of
+// every lane - and the node values of the first round of segments REQUESTED (not waited for):
+// `global_load_lds` puts them straight into the wave's gather panel, no registers in between.
+// cycle_linear_body runs it for chunk c+1 right after the stencil sums of chunk c have left
+// the panel: the L2 round trip overlaps the push and both depositions of chunk c.
+struct CycleFront {
+    double x, y, z, rj;               // position (z wrapped into the periodic box), radius
+    int hkz, hkr, hnb;                // stencil key of the lane's home run
+    int kz, kr, myseg;                // own stencil origin; segment holding this lane's node values
+    unsigned long long runstarts, insidem;
+    int nseg, cnt;
+    unsigned long long rem_r, rem_s;  // segments not requested yet (runs / strays)
+};
+
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *glb_ptr_t;
+
+template <int NM, bool PIPE>
+__device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
+{
+    using P = CyclePlan<NM, PIPE>;
+    using EJ = typename P::EJ;
+    using ER = typename P::ER;
+    constexpr int S = 2, NV = P::NV, NVL = P::NVL, NSEG = P::NSEG, PSTR = P::PSTR;
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // per wave: the gather panel (node values of the segments, written by the loads themselves)
+    // and, behind it, the panel of the deposition engines
+    double *gpanel = lds + (size_t)wave * P::WAVE_DOUBLES;
+    double *dpanel = PIPE ? gpanel + P::GATHER_DOUBLES : gpanel;
+    const long n = A.n;
+    const int Nz = A.Nz, Nr = A.Nr, ncol = Nr + 1;
+    const long rs = A.rsG;
+    EJ ej;
+    ER er;
+    ej.init(dpanel, lane, A.GJ, A.rsJ, 0, Nz, Nr, A.baseJ);
+    er.init(dpanel, lane, A.GR, A.rsR, 0, Nz, Nr, A.baseR);
+    const DepGeom geom = {A.invdz, A.zmin, Nz, A.invdr, A.rmin, Nr};
+    const bool store_eb = A.Ex != nullptr;
+    const unsigned long long le = (2ull << lane) - 1ull, lt = (1ull << lane) - 1ull;
+
+    // staging role of this lane in the gather: node value o = lane + 64 j of every segment
+    // (node (jz, jr) = the two low bits of the lane, field lane / 4 + 16 j)
+    const int st_jr = lane & 1, st_jz = (lane >> 1) & 1;
+    // its field as a 32-bit byte offset from the lowest of the grids (scalar base + lane offset
+    // addressing; the host has checked that all of them lie within 4 GiB)
+    unsigned st_rel[NVL];
+    unsigned st_on = 0u;
+    const char *gbase = (const char *)A.baseG;
+    const int rsB = (int)(16 * rs);
+#pragma unroll
+    for (int j = 0; j < NVL; j++) {
+        const int o = lane + 64 * j;
+        const bool on = o < NV;
+        st_rel[j] = (unsigned)((const char *)A.G.g[on ? o / (S * S) : 0] - gbase);
+        st_on |= on ? (1u << j) : 0u;
+    }
+    // request the node values of the next (up to NSEG) segments of `f`: runs first, then strays
+    auto request = [&](CycleFront &f, int ns) {
+#pragma unroll
+        for (int u = 0; u < NSEG; u++) {
+            if (u < ns) {
+                int skz, skr;
+                if (f.rem_r) {
+                    const int l = __builtin_ctzll(f.rem_r);
+                    f.rem_r &= f.rem_r - 1ull;
+                    skz = __builtin_amdgcn_readlane(f.hkz, l);
+                    skr = __builtin_amdgcn_readlane(f.hkr, l);
+                } else {
+                    const int l = __builtin_ctzll(f.rem_s);
+                    f.rem_s &= f.rem_s - 1ull;
+                    skz = __builtin_amdgcn_readlane(f.kz, l);
+                    skr = __builtin_amdgcn_readlane(f.kr, l);
+                }
+                // z wrap, mirror below the axis (its sign is applied to the weights, see the
+                // stencil sums), clamp at the outer edge (gathering/inline_functions.py:20-90)
+                int row = skz + st_jz, col = skr + st_jr;
+                if (row < 0) row += Nz; else if (row > Nz - 1) row -= Nz;
+                if (col < 0) col = -col - 1; else if (col > Nr - 1) col = Nr - 1;
+                const unsigned off = (unsigned)(row * rsB + col * 16);
+#pragma unroll
+                for (int j = 0; j < NVL; j++) {
+                    // lane l of the wave -> 16 bytes at (LDS base) + 16 l
+                    if ((st_on >> j) & 1u)
+                        __builtin_amdgcn_global_load_lds((glb_ptr_t)(gbase + (st_rel[j] + off)),
+                                                         (lds_ptr_t)(gpanel + u * PSTR + 128 * j), 16, 0, 0);
+                }
+            }
+        }
+    };
+    auto front = [&](CycleFront &f, long base, double xj, double yj, double zj, int hn) {
+        // (Lanes beyond the last particle hold a copy of it - load_pos - and compute along: only
+        // the masks, the stores and the deposited weight know that they are not particles.  The
+        // chunk loop then has no divergent region around its arithmetic.)
+        const bool act = base + lane < n;
+        f.cnt = (int)min((long)64, n - base);
+        if (A.wzmax > A.wzmin) {
+            // boundaries/particle_buffer_handling.py:536-556 (k_shift_periodic): one step of each
+            // of its two loops, the loops themselves only if a particle is further out than a box
+            const double l_box = A.wzmax - A.wzmin;
+            zj = (zj >= A.wzmax) ? zj - l_box : zj;
+            zj = (zj < A.wzmin) ? zj + l_box : zj;
+            if (__ballot(zj >= A.wzmax || zj < A.wzmin)) {
+                while (zj >= A.wzmax) zj -= l_box;
+                while (zj < A.wzmin) zj += l_box;
+            }
+        }
+        f.x = xj; f.y = yj; f.z = zj;
+        // home cell -> stencil key of the lane's run (linear shape: lowest node of the 2 x 2
+        // stencil = (iz_upper - 1, ir_upper - 1), the same for gather and deposition).
+        // hc / ncol: (hc + 0.5) / ncol is at least 0.5 / ncol away from an integer, so the floor
+        // of the rounded product is the quotient for any int hc.
+        const int hc = hn;
+        const int hzu = (int)floor(((double)hc + 0.5) * A.inv_ncol);
+        const int hru = hc - hzu * ncol;
+        f.hkz = hzu - 1; f.hkr = hru - 1; f.hnb = 1 - hru;
+        const int hprev = __shfl_up(hc, 1);
+        f.runstarts = __ballot(act && (lane == 0 || hc != hprev));
+        // own stencil origin (threading_methods.py:108-117)
+        const double rj = sqrt(xj * xj + yj * yj);
+        f.rj = rj;
+        const double r_cell = A.invdr * (rj - A.rmin) - 0.5;
+        const double z_cell = A.invdz * (zj - A.zmin) - 0.5;
+        const bool inside = act && rj < A.rmax_gather;
+        const int kr = (int)floor(r_cell), kz = (int)floor(z_cell);
+        f.kz = kz; f.kr = kr;
+        const bool g_home = inside && kz == f.hkz && kr == f.hkr;
+        const unsigned long long g_homem = __ballot(g_home);
+        f.insidem = __ballot(inside);
+        const unsigned long long straym = __ballot(inside && !g_home);
+        // Segments of the runs: only runs that still hold a particle of their own cell are staged
+        // (an emptied run would be staged for nothing - and from whatever `home` holds: the
+        // result must not depend on it).  One bit per such run, at its first home lane.
+        const int mystart = 63 - __builtin_clzll((f.runstarts & le) | 1ull);
+        const bool g_first = g_home && ((g_homem & lt) >> mystart) == 0ull;
+        const unsigned long long g_runs = __ballot(g_first);
+        const int ngruns = __popcll(g_runs);
+        f.nseg = ngruns + __popcll(straym);
+        // segment of this lane: its run, or - a stray - one of its own behind the runs
+        f.myseg = g_home ? __popcll(g_runs & le) - 1 : ngruns + __popcll(straym & lt);
+        f.rem_r = g_runs; f.rem_s = straym;
+        request(f, min(NSEG, f.nseg));
+    };
+
+    const long chunk0 = (xcd_block_id() * nwaves + wave) * A.chunks_per_wave;
+    long base = chunk0 * 64;
+    if (base >= n) return;
+    // software pipeline: positions and home cell two chunks ahead, node values one chunk ahead
+    double xn, yn, zn;
+    int hn;
+    auto load_pos = [&](long b) {
+        const long i = min(b + lane, n - 1);
+        xn = KP(const double, x)[i]; yn = KP(const double, y)[i]; zn = KP(const double, z)[i];
+        hn = KP(const int, home)[i];
+    };
+    load_pos(base);
+    CycleFront fr;
+    front(fr, base, xn, yn, zn, hn);
+    if (A.chunks_per_wave > 1) load_pos(base + 64);
+    unsigned int nstray_J = 0;
+    for (int ch = 0; ch < A.chunks_per_wave; ch++) {
+        const long i = min(base + lane, n - 1);
+        const bool act = base + lane < n;
+        const int cnt = fr.cnt;
+        const double xj = fr.x, yj = fr.y, zj = fr.z;
+        const int hkz = fr.hkz, hkr = fr.hkr, hnb = fr.hnb, myseg = fr.myseg, nseg = fr.nseg;
+        const unsigned long long runstarts = fr.runstarts;
+        const bool inside = (fr.insidem >> lane) & 1ull;
+        FB_MARK("M_TOP");
+        // momenta and weight of this chunk: in flight during the stencil phase
+        double pux = KP(const double, ux)[i], puy = KP(const double, uy)[i], puz = KP(const double, uz)[i];
+        double pig = KP(const double, ig)[i];
+        const double pw = KP(const double, w)[i];
+        // ---- gather: shape factors (threading_methods.py:108-117), cos, sin
+        double cs, sn, Sz[S], Sr[S];
+        bool axis;
+        {
+            const double rj = fr.rj;
+            const double r_cell = A.invdr * (rj - A.rmin) - 0.5;
+            const double z_cell = A.invdz * (zj - A.zmin) - 0.5;
+            const int kr = fr.kr, kz = fr.kz;
+            Sr[0] = (kr + 1) - r_cell; Sr[1] = r_cell - kr;
+            Sz[0] = (kz + 1) - z_cell; Sz[1] = z_cell - kz;
+            axis = kr < 0;
+            const double invr = 1. / rj;
+            cs = (rj != 0.) ? xj * invr : 1.;
+            sn = (rj != 0.) ? yj * invr : 0.;
+        }
+        // Weights of the 2 x 2 nodes.  Stencil column 0 of a particle in the first half cell lies
+        // below the axis: its node values are those of the mirror node times -(-1)^m (r, t
+        // components) or +(-1)^m (z) (gathering/inline_functions.py:70-79) - the sign goes to the
+        // weight here ((-w) v = -(w v) exactly: the same sums as k_gather's signed panel values)
+        double wp[S][S], wm[S];
+#pragma unroll
+        for (int jz = 0; jz < S; jz++) {
+            wp[jz][0] = Sz[jz] * Sr[0];
+            wp[jz][1] = Sz[jz] * Sr[1];
+            wm[jz] = axis ? -wp[jz][0] : wp[jz][0];
+        }
+        FB_MARK("M_EVAL");
+        double F[6] = {0., 0., 0., 0., 0., 0.};
+        for (int s0 = 0; s0 < nseg; s0 += NSEG) {
+            const int ns = min(NSEG, nseg - s0);
+            // more segments than one round holds (a badly out-of-date order): requested here
+            if (s0 > 0) request(fr, ns);
+            // the node values requested one iteration ago (or just now) have landed
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wave_lds_release();
+            if (inside && myseg >= s0 && myseg < s0 + ns) {
+                const double *Pp = (const double *)__builtin_assume_aligned(gpanel + (size_t)(myseg - s0) * PSTR, 16);
+                double er_ = 1., ei_ = 0.;            // exptheta_m = (cos - i sin)^m
+#pragma unroll
+                for (int m = 0; m < NM; m++) {
+                    const double factor = (m == 0) ? 1. : 2.;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+                        const double *Pf = Pp + 2 * (m * 6 + k) * S * S;
+                        // mirror sign of this field: (k % 3 == 2) ? (-1)^m : -(-1)^m
+                        const bool neg = ((k % 3 == 2) ? (m & 1) : !(m & 1));
+                        double fr_ = 0., fi_ = 0.;
+#pragma unroll
+                        for (int jz = 0; jz < S; jz++)
+#pragma unroll
+                            for (int jr = 0; jr < S; jr++) {
+                                const double2 v = *(const double2 *)(Pf + 2 * (jz * S + jr));
+                                const double w_ = (jr == 0 && neg) ? wm[jz] : wp[jz][jr];
+                                fr_ = __builtin_fma(w_, v.x, fr_); fi_ = __builtin_fma(w_, v.y, fi_);
+                            }
+                        // m = 0: exptheta = 1 + 0i and factor = 1 (as in k_gather)
+                        if (m == 0) F[k] += fr_;
+                        else F[k] += factor * (fr_ * er_ - fi_ * ei_);
+                    }
+                    const double nr_ = er_ * cs - ei_ * (-sn);
+                    const double ni_ = er_ * (-sn) + ei_ * cs;
+                    er_ = nr_; ei_ = ni_;
+                }
+            }
+            // every read of the panel has returned before it is written again
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            wave_lds_acquire();
+        }
+        FB_MARK("M_FRONT");
+        // ---- front half of the next chunk: its node loads travel during the rest of this one
+        const long nbase = base + 64;
+        const bool more = (ch + 1 < A.chunks_per_wave) && nbase < n;
+        if (PIPE && more) {
+            front(fr, nbase, xn, yn, zn, hn);
+            if (ch + 2 < A.chunks_per_wave) load_pos(nbase + 64);
+        }
+
+        FB_MARK("M_VAY");
+        // ---- (r,t) -> (x,y), Vay push, first half push of the position (gather_finish)
+        const double ex = cs * F[0] - sn * F[1], ey = sn * F[0] + cs * F[1], ez = F[2];
+        const double bx = cs * F[3] - sn * F[4], by = sn * F[3] + cs * F[4], bz = F[5];
+        vay(pux, puy, puz, pig, ex, ey, ez, bx, by, bz, A.econst, A.bconst);
+        // push/numba_methods.py:28-30 with push_x = push_y = push_z = 1
+        const double xh = xj + A.chdt * pig * 1. * pux;
+        const double yh = yj + A.chdt * pig * 1. * puy;
+        const double zh = zj + A.chdt * pig * 1. * puz;
+        // second half push: the positions are written once
+        const double x1 = xh + A.chdt * pig * 1. * pux;
+        const double y1 = yh + A.chdt * pig * 1. * puy;
+        const double z1 = zh + A.chdt * pig * 1. * puz;
+        if (act) {
+            if (store_eb) {
+                KP(double, Ex)[i] = ex; KP(double, Ey)[i] = ey; KP(double, Ez)[i] = ez;
+                KP(double, Bx)[i] = bx; KP(double, By)[i] = by; KP(double, Bz)[i] = bz;
+            }
+            KP(double, ux)[i] = pux; KP(double, uy)[i] = puy; KP(double, uz)[i] = puz; KP(double, ig)[i] = pig;
+            KP(double, x)[i] = x1; KP(double, y)[i] = y1; KP(double, z)[i] = z1;
+        }
+        const double wj = act ? A.q * pw : 0.;       // a lane without a particle deposits nothing
+
+        FB_MARK("M_JSTAGE");
+        // ---- J from x(n+1/2)
+        int dkz, dkr, dnb;
+        ej.stage(true, xh, yh, zh, wj, pux, puy, puz, pig, A.c_light, geom, KP(const double, beta0),
+                 KP(const double, betah), dkz, dkr, dnb);
+        {
+            const bool home = act && dkz == hkz && dkr == hkr && dnb == hnb;
+            const unsigned long long hm = __ballot(home), sm = __ballot(act && !home);
+            nstray_J += __popcll(sm);
+            wave_lds_release();
+        FB_MARK("M_JREDUCE");
+            ej.reduce_home(cnt, runstarts, hm, hkz, hkr, hnb);
+        FB_MARK("M_JSCATTER");
+            ej.scatter_strays(sm, dkz, dkr, dnb);
+            wave_lds_acquire();
+        }
+        FB_MARK("M_RSTAGE");
+        // ---- rho from x(n+1)
+        er.stage(true, x1, y1, z1, wj, 0., 0., 0., 0., 0., geom, KP(const double, beta0), KP(const double, betah),
+                 dkz, dkr, dnb);
+        {
+            const bool home = act && dkz == hkz && dkr == hkr && dnb == hnb;
+            const unsigned long long hm = __ballot(home), sm = __ballot(act && !home);
+            wave_lds_release();
+        FB_MARK("M_RREDUCE");
+            er.reduce_home(cnt, runstarts, hm, hkz, hkr, hnb);
+        FB_MARK("M_RSCATTER");
+            er.scatter_strays(sm, dkz, dkr, dnb);
+            wave_lds_acquire();
+        }
+        FB_MARK("M_END");
+        if (!more) break;
+        if (!PIPE) {
+            // the deposition panel is free again: the next chunk's node values may land in it
+            front(fr, nbase, xn, yn, zn, hn);
+            if (ch + 2 < A.chunks_per_wave) load_pos(nbase + 64);
+        }
+        base = nbase;
+    }
+    ej.flush(false);
+    er.flush(false);
+    if (A.stats && lane == 0)
+        atomicAdd(A.stats + ((blockIdx.x * nwaves + wave) & 1023), (unsigned long long)nstray_J);
+}
+
+// Builds of the same body: pipelined node loads (PIPE) or the shared panel, each with the register
+// allocation the compiler picks and forced to 128 registers (4 waves per SIMD);
+// FBPIC_AMD_CYCLE_PIPE=0 / FBPIC_AMD_CYCLE_WPE=4 select (measurements in profiles/README.md).
+template <int NM, bool PIPE>
+__global__ __launch_bounds__(256) void k_cycle_linear(CycleArgs A) { cycle_linear_body<NM, PIPE>(A); }
+template <int NM, bool PIPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_cycle_linear_w4(CycleArgs A)
+{
+    cycle_linear_body<NM, PIPE>(A);
+}
+
+static int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+template <int NM, bool PIPE>
+static int launch_cycle_linear(const CycleArgs &A0, hipStream_t s, bool w4)
+{
+    using P = CyclePlan<NM, PIPE>;
+    CycleArgs A = A0;
+    const size_t wave_bytes = 8 * (size_t)P::WAVE_DOUBLES;
+    const int nwaves = lds_waves_per_workgroup(wave_bytes);
+    const long nchunks = (A.n + 63) / 64;
+    const long target_waves = 256L * 64;
+    int cpw = (int)((nchunks + target_waves - 1) / target_waves);
+    if (cpw < 1) cpw = 1;
+    if (cpw > 64) cpw = 64;
+    A.chunks_per_wave = cpw;
+    const long total_waves = (nchunks + cpw - 1) / cpw;
+    const long nblocks = xcd_grid((total_waves + nwaves - 1) / nwaves);
+    if (w4)
+        hipLaunchKernelGGL((k_cycle_linear_w4<NM, PIPE>), dim3((unsigned)nblocks), dim3(64 * nwaves),
+                           wave_bytes * nwaves, s, A);
+    else
+        hipLaunchKernelGGL((k_cycle_linear<NM, PIPE>), dim3((unsigned)nblocks), dim3(64 * nwaves),
+                           wave_bytes * nwaves, s, A);
+    return check(hipGetLastError(), "fb_gather_push_deposit_J_rho");
+}
+
+template <int NM>
+static int launch_cycle(const CycleArgs &A, hipStream_t s)
+{
+    static const int pipe = env_int("FBPIC_AMD_CYCLE_PIPE", 1), wpe = env_int("FBPIC_AMD_CYCLE_WPE", 0);
+    return pipe ? launch_cycle_linear<NM, true>(A, s, wpe == 4) : launch_cycle_linear<NM, false>(A, s, wpe == 4);
+}
+
+}  // namespace fb
+
+using namespace fb;
+
+extern "C" int fb_gather_push_deposit_supported(int shape, int Nm)
+{
+    return shape == FB_SHAPE_LINEAR && Nm >= 1 && Nm <= 4;
+}
+
+extern "C" int fb_gather_push_deposit_J_rho(int shape, int Nm, long n,
+        double *x, double *y, double *z, double *ux, double *uy, double *uz, double *inv_gamma,
+        const double *w, const int *home_cell,
+        double rmax_gather, double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
+        const void *const *grids, long row_stride,
+        double *Ex, double *Ey, double *Ez, double *Bx, double *By, double *Bz,
+        double q, double m, double c, double dt, double dt_x, double wrap_zmin, double wrap_zmax,
+        void *const *J, long J_row_stride, long J_col_stride,
+        void *const *rho, long rho_row_stride, long rho_col_stride,
+        const double *ruyten_m0, const double *ruyten_mh, unsigned long long *stats, void *stream)
+{
+    const char *who = "fb_gather_push_deposit_J_rho";
+    if (n <= 0) return 0;
+    if (!fb_gather_push_deposit_supported(shape, Nm)) {
+        set_error(who, "linear shape, Nm = 1..4 (use the separate entry points otherwise)");
+        return -1;
+    }
+    if (!home_cell) { set_error(who, "home_cell (cell of every particle at the last sort) is required"); return -1; }
+    CycleArgs A;
+    A.n = n;
+    A.x = x; A.y = y; A.z = z; A.ux = ux; A.uy = uy; A.uz = uz; A.ig = inv_gamma; A.w = w;
+    A.home = home_cell;
+    A.Ex = Ex; A.Ey = Ey; A.Ez = Ez; A.Bx = Bx; A.By = By; A.Bz = Bz;
+    A.invdz = invdz; A.zmin = zmin; A.Nz = Nz; A.invdr = invdr; A.rmin = rmin; A.Nr = Nr;
+    A.inv_ncol = 1. / (double)(Nr + 1);
+    A.rmax_gather = rmax_gather;
+    for (int i = 0; i < 6 * FB_MAX_MODES; i++) A.G.g[i] = i < 6 * Nm ? (const cplx *)grids[i] : nullptr;
+    A.rsG = row_stride;
+    {
+        uintptr_t lo = ~(uintptr_t)0, hi = 0;
+        for (int i = 0; i < 6 * Nm; i++) {
+            const uintptr_t a = (uintptr_t)grids[i];
+            if (a < lo) lo = a;
+            if (a > hi) hi = a;
+        }
+        if ((double)(hi - lo) + 16. * (double)row_stride * (double)(Nz + 1) >= 4294967296.) {
+            set_error(who, "the E, B grids must lie within 4 GiB of each other (one slab): 32-bit "
+                           "offsets in the node loads");
+            return -1;
+        }
+        A.baseG = (const cplx *)lo;
+    }
+    // fbpic/particles/push/numba_methods.py:41-42, 24-30
+    A.econst = q * dt / (m * c);
+    A.bconst = 0.5 * q * dt / m;
+    A.chdt = c * dt_x;
+    A.wzmin = wrap_zmin; A.wzmax = wrap_zmax;
+    A.q = q; A.c_light = c;
+    A.GJ.cs = J_col_stride > 0 ? J_col_stride : 1;
+    A.GR.cs = rho_col_stride > 0 ? rho_col_stride : 1;
+    for (int i = 0; i < 3 * FB_MAX_MODES; i++) {
+        A.GJ.g[i] = i < 3 * Nm ? (cplx *)J[i] : nullptr;
+        A.GR.g[i] = i < Nm ? (cplx *)rho[i] : nullptr;
+    }
+    A.rsJ = J_row_stride; A.rsR = rho_row_stride;
+    A.baseJ = dep_grids_base(A.GJ, 3 * Nm, J_row_stride, Nz);
+    A.baseR = dep_grids_base(A.GR, Nm, rho_row_stride, Nz);
+    if (!A.baseJ || !A.baseR) {
+        set_error(who, "the J (and the rho) arrays must lie within 4 GiB of each other: node-major "
+                       "records or the fields of one slab (32-bit offsets in the flush)");
+        return -1;
+    }
+    A.beta0 = ruyten_m0; A.betah = ruyten_mh;
+    A.chunks_per_wave = 1;
+    A.stats = stats;
+    hipStream_t s = (hipStream_t)stream;
+    switch (Nm) {
+    case 1: return launch_cycle<1>(A, s);
+    case 2: return launch_cycle<2>(A, s);
+    case 3: return launch_cycle<3>(A, s);
+    default: return launch_cycle<4>(A, s);
+    }
+}

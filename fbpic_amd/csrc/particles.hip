@@ -3,6 +3,7 @@
 // float64 streams, coalesced; grid-stride over a capped grid (256 CUs x 8 blocks).
 #include <cstdlib>
 #include "fb_common.h"
+#include "push_common.h"
 
 namespace fb {
 
@@ -39,29 +40,7 @@ __global__ __launch_bounds__(256) void k_push_x(long nvec, double *__restrict__ 
     }
 }
 
-// ------------------------------------------------------------------ push_p
-// Vay pusher, fbpic/particles/push/inline_functions.py:11-48.  112 B / particle.
-__device__ __forceinline__ void vay(double &ux, double &uy, double &uz, double &ig,
-        double Ex, double Ey, double Ez, double Bx, double By, double Bz,
-        double econst, double bconst)
-{
-    double taux = bconst * Bx, tauy = bconst * By, tauz = bconst * Bz;
-    double tau2 = taux * taux + tauy * tauy + tauz * tauz;
-    double uxp = ux + econst * Ex + ig * (uy * tauz - uz * tauy);
-    double uyp = uy + econst * Ey + ig * (uz * taux - ux * tauz);
-    double uzp = uz + econst * Ez + ig * (ux * tauy - uy * taux);
-    double sigma = 1 + uxp * uxp + uyp * uyp + uzp * uzp - tau2;
-    double utau = uxp * taux + uyp * tauy + uzp * tauz;
-    double igf = sqrt(2. / (sigma + sqrt(sigma * sigma + 4 * (tau2 + utau * utau))));
-    double tx = igf * taux, ty = igf * tauy, tz = igf * tauz;
-    double ut = igf * utau;
-    double s = 1. / (1 + tau2 * (igf * igf));
-    ux = s * (uxp + tx * ut + uyp * tz - uzp * ty);
-    uy = s * (uyp + ty * ut + uzp * tx - uxp * tz);
-    uz = s * (uzp + tz * ut + uxp * ty - uyp * tx);
-    ig = igf;
-}
-
+// ------------------------------------------------------------------ push_p (vay(): push_common.h)
 template <int V>
 __global__ __launch_bounds__(256) void k_push_p(long nvec, double *__restrict__ ux,
         double *__restrict__ uy, double *__restrict__ uz, double *__restrict__ ig,
@@ -123,7 +102,6 @@ __global__ __launch_bounds__(256) void k_shift_periodic(long n, double *__restri
 //      ds_read_b128 (256 B/clk), so the kernel is bound by the particle streams
 //      (24 B read + 48 B written per particle).
 // Any order of particles gives the same result; an unsorted stream just has more segments.
-struct GatherGrids { const cplx *g[6 * FB_MAX_MODES]; };
 
 // Optional fusion of the two kernels that follow the gather in the PIC cycle
 // (main.py:469-490): Vay push_p with the fields still in registers, then push_x over dt_x.
@@ -147,7 +125,6 @@ struct PushArgs {
     int range_mode;
 };
 
-__device__ __forceinline__ double2 ldc(const cplx *p) { return *(const double2 *)p; }
 
 template <int SHAPE> struct GShape;
 template <> struct GShape<FB_SHAPE_LINEAR> { static constexpr int S = 2, OFF = 0; };

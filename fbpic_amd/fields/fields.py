@@ -84,6 +84,13 @@ class Fields(object):
         self._deferred_sources = None    # see defer_sources
 
     # ---------------------------------------------------------------- deferred J / rho
+    def _touch(self):
+        """Start of a public method that modifies the grids: calls from outside Simulation.step are
+        counted (the state carried between step() calls is keyed on the count: the kernels
+        write through raw pointers, which torch's version counters do not see)."""
+        if not getattr(self, '_in_step', False):
+            self._ext_gen = getattr(self, '_ext_gen', 0) + 1
+
     def defer_sources(self, bring_back):
         """Simulation.step ends with J and rho_prev going from spectral space to the
         interpolation grid (main.py:572-586): two inverse transforms per call that only matter
@@ -266,6 +273,7 @@ class Fields(object):
         the divide-by-volume pass (it commutes with the z-FFT) and the spectral filter pass
         into the Hankel GEMM (fb_hankel_scaled) instead of two extra sweeps over the grids;
         with `fuse_divide_by_volume` the interpolation-grid arrays are left un-normalised."""
+        self._touch()
         self._need_gpu()
         fi, fs, nf, vec = self._group(fieldtype)
         Nz, Nr = self.Nz, self.Nr
@@ -385,6 +393,7 @@ class Fields(object):
 
     def spect2interp(self, fieldtype):
         """inverse DHT(r) then inverse FFT(z) (reference: fields.py:370-429)."""
+        self._touch()
         self._need_gpu()
         fi, fs, nf, vec = self._group(fieldtype)
         Nz, Nr = self.Nz, self.Nr
@@ -414,6 +423,7 @@ class Fields(object):
         """inverse FFT only: spectral (p,m,z) -> interpolation-grid storage (r,t,z slots),
         reference fields.py:431-483.  `to_scratch`: the z-real / r-spectral fields go to the
         scratch slab instead (fields 0 .. nf-1), for `partial2interp`."""
+        self._touch()
         self._need_gpu()
         fi, fs, nf, _ = self._group(fieldtype)
         dst = self.d_scratch[:, 0, :] if to_scratch else self.d_interp[:, fi, :]
@@ -421,6 +431,7 @@ class Fields(object):
 
     def partial_interp2spect(self, fieldtype, from_scratch=False):
         """forward FFT only, reference fields.py:485-536."""
+        self._touch()
         self._need_gpu()
         fi, fs, nf, _ = self._group(fieldtype)
         src = self.d_scratch[:, 0, :] if from_scratch else self.d_interp[:, fi, :]
@@ -460,6 +471,7 @@ class Fields(object):
 
     # ---------------------------------------------------------------- solver steps
     def push(self, use_true_rho=False, check_exchanges=False):
+        self._touch()
         self._need_gpu()
         if check_exchanges:
             assert self.exchanged_source['J'] is True
@@ -478,6 +490,7 @@ class Fields(object):
         (correction of all modes, one launch), then correct_currents=False (push + rho
         shift of all modes, one launch).  `n_move` != 0: the moving window's translation of
         E, B, rho_prev and J by n_move cells rides along (fb_psatd_step_standard_shift)."""
+        self._touch()
         self._need_gpu()
         from scipy.constants import c, epsilon_0, mu_0
         fields, tables = [], []
@@ -501,6 +514,7 @@ class Fields(object):
         _capi.check(rc, 'fb_psatd_step_standard')
 
     def correct_currents(self, check_exchanges=False):
+        self._touch()
         self._need_gpu()
         if check_exchanges:
             assert self.exchanged_source['rho_prev'] is False
@@ -517,6 +531,7 @@ class Fields(object):
 
     def erase(self, fieldtype):
         """Zero a field group on the interpolation grid, all modes in one launch."""
+        self._touch()
         self._need_gpu()
         if fieldtype not in ('E', 'B', 'J', 'rho', 'J+rho'):
             raise ValueError('Invalid string for fieldtype: %s' % fieldtype)
@@ -536,11 +551,13 @@ class Fields(object):
         return
 
     def filter_spect(self, fieldtype):
+        self._touch()
         self._need_gpu()
         for m in range(self.Nm):
             self.spect[m].filter(fieldtype)
 
     def divide_by_volume(self, fieldtype):
+        self._touch()
         self._need_gpu()
         for m in range(self.Nm):
             self.interp[m].divide_by_volume(fieldtype)

@@ -158,6 +158,10 @@ class Simulation(object):
         # (xGMI, RCCL) exceeds ~60 us; it is kept selectable for that measurement
         # (FBPIC_AMD_OVERLAP) and pinned by tests/test_gpu_multirank_golden.py.
         self.overlap_guard_exchange = os.environ.get('FBPIC_AMD_OVERLAP', 'off')
+        # The particle work of an iteration as ONE pass (Particles.cycle, csrc/cycle.hip) with a
+        # re-sort every few steps only, where the conditions of _one_pass_ok hold; else the
+        # two-pass sequence (gather + push + rank | deposit J + push + sort + deposit rho).
+        self.one_pass_cycle = os.environ.get('FBPIC_AMD_ONE_PASS', '1') != '0'
         self._eb_pending = None
         self._comm_stream = None
 
@@ -179,6 +183,9 @@ class Simulation(object):
         was_on_gpu = fld.data_is_on_gpu and all(s.data_is_on_gpu for s in ptcl)
         send_data_to_gpu(self)
         self._in_step = True
+        fld._in_step = True
+        for species in ptcl:
+            species._in_step = True
         carried = (was_on_gpu and self._carry is not None and N > 0
                    and self._carry == self._carry_signature())
         self._carry = None
@@ -189,6 +196,9 @@ class Simulation(object):
                             carried=carried)
         finally:
             self._in_step = False
+            fld._in_step = False
+            for species in ptcl:
+                species._in_step = False
         if not was_on_gpu:
             receive_data_from_gpu(self)
         elif self.carry_state_between_calls and N > 0:
@@ -203,17 +213,23 @@ class Simulation(object):
         boundary is damped again at the start of every call in the reference (main.py:403-411),
         which this keeps."""
         fld, comm = self.fld, self.comm
+        if comm.size > 1:
+            # every rank would have to take the same decision (a rank that re-exchanges while its
+            # neighbour carries on posts messages nobody receives): not carried when decomposed
+            return None
         if not self.carry_state_between_calls or comm.nz_damp != 0 or comm.moving_win is not None \
                 or self.use_galilean or self.external_fields or self.mirrors or self.laser_antennas \
                 or self.reference_sequence or fld.current_correction == 'cross-deposition':
             return None
         if not (fld.data_is_on_gpu and all(s.data_is_on_gpu for s in self.ptcl)):
             return None
-        sig = [self.iteration, fld._epoch, fld.d_interp.data_ptr(), fld.d_interp._version,
+        sig = [self.iteration, fld._epoch, getattr(fld, '_ext_gen', 0), fld.d_interp.data_ptr(),
+               fld.d_interp._version,
                fld.d_spect.data_ptr(), fld.d_spect._version, fld.interp[0].zmin,
                comm._zmin_global_domain, len(self.ptcl), self.dt, self.filter_currents]
         for sp in self.ptcl:
-            sig.append((id(sp), sp.Ntot, sp.q, sp.m, sp._epoch, sp._pending_push, sp._pending_J is None))
+            sig.append((id(sp), sp.Ntot, sp.q, sp.m, sp._epoch, sp._ext_gen, sp._pending_push,
+                        sp._pending_J is None))
             for k in ('x', 'y', 'z', 'ux', 'uy', 'uz', 'w', 'inv_gamma'):
                 a = getattr(sp, k)
                 sig.append((a.data_ptr(), a._version))
@@ -221,6 +237,10 @@ class Simulation(object):
 
     def _step_loop(self, N, correct_currents, use_true_rho, move_positions, move_momenta,
                    carried=False):
+        """The N iterations of one step() call.  Per iteration: particle exchange / rho_prev
+        (_start_of_iteration), the particle work in one of three forms (_particles_one_pass,
+        _particles_two_pass, _particles_reference_order), the field update (_field_update), the
+        E, B tail (exchange_and_damp_EB)."""
         ptcl, fld, dt = self.ptcl, self.fld, self.dt
         # J / rho (and the particles' E, B) of the previous call that nobody read are not brought
         # back any more
@@ -237,26 +257,7 @@ class Simulation(object):
             diag_due = any(getattr(d, 'due', lambda it: True)(self.iteration) for d in self.diags)
             fused = (self.fuse_gather_push and move_momenta and move_positions
                      and not self.external_fields and not diag_due)
-            wrap_z = None
-            if self.iteration % self.comm.exchange_period == 0 or first:
-                need_rho_prev = (first or self.comm.n_guard != 0
-                                 or self.redeposit_rho_prev_every_step or use_true_rho)
-                if fused and not need_rho_prev and self.comm.n_guard == 0:
-                    # single periodic domain: the wrap of z into the box rides along in the
-                    # gather+push launch that comes next (nothing reads z in between)
-                    wrap_z = (fld.interp[0].zmin, fld.interp[0].zmax)
-                else:
-                    self._wait_eb()      # one exchange at a time on the communicator
-                    for species in ptcl:
-                        self.comm.exchange_particles(species, fld, self.time)
-                if need_rho_prev:
-                    self.deposit('rho_prev', exchange=(use_true_rho is True))
-            if first and (diag_due or self.reference_sequence or not self.skip_unobserved_first_J):
-                # "For the field diagnostics of the first step: deposit J" (reference main.py:
-                # 448-451; not the corrected current).  Nothing else reads it - the J of this step
-                # is erased and deposited again below - so it is only launched when a diagnostic
-                # is due at this iteration (or the reference launch sequence is asked for).
-                self.deposit('J', exchange=True)
+            wrap_z = self._start_of_iteration(first, fused, diag_due, use_true_rho)
             for species in ptcl:
                 species.keep_fields_sorted = True
             lazy_eb = False
@@ -267,123 +268,24 @@ class Simulation(object):
                 # and evaluate species.Ex ... on first use (Particles.defer_fields).
                 fld.snapshot_EB()
                 lazy_eb = True
-            if fused:
-                # nothing observes the particles between gather and the half position push:
-                # one pass instead of three (gather, push_p, push_x)
-                # the gathered E, B are consumed in registers; the per-particle Ex..Bz arrays
-                # are only materialised where something can observe them: on the last
-                # iteration of this call (they then hold the fields of that gather, as after
-                # the reference's step) - diagnostics take the unfused branch below
-                # ... and ranks the particles for the sort after the second half push (not with a
-                # Galilean grid: zmin moves in between; not with cross-deposition: other pushes)
-                cross_ = bool(correct_currents) and fld.current_correction == 'cross-deposition'
-                hint = (0.5 * dt, 1., 1., 1.) if (self.prerank_in_deposit and not self.use_galilean
-                                                  and not cross_) else None
-                pend = self._eb_pending
-                if pend is not None and pend[1] is not None and hint is not None and wrap_z is None \
-                        and all(sp.can_split_gather(fld.Nm) for sp in ptcl):
-                    # the rows [lo, hi) of the interpolation grid are final; a particle of cell
-                    # row iz_upper reads rows iz_upper - 2 ... iz_upper + 1 at most (cubic shape)
-                    rows = (pend[1] + 2, pend[2] - 2)
-                    for species in ptcl:
-                        species.gather_push(fld.interp, self.comm, 0.5 * dt,
-                                            store_fields=(i_step == N - 1 and not lazy_eb),
-                                            rank_next=hint, part='inside', rows=rows)
-                    self._wait_eb()
-                    for species in ptcl:
-                        species.gather_push(fld.interp, self.comm, 0.5 * dt,
-                                            store_fields=(i_step == N - 1 and not lazy_eb),
-                                            rank_next=hint, part='outside', rows=rows)
-                else:
-                    self._wait_eb(rows_only=True)
-                    for species in ptcl:
-                        species.gather_push(fld.interp, self.comm, 0.5 * dt,
-                                            store_fields=(i_step == N - 1 and not lazy_eb),
-                                            wrap_z=wrap_z, rank_next=hint)
-            else:
-                self._wait_eb()
-                for species in ptcl:
-                    species.gather(fld.interp, self.comm)
-                for ext_field in self.external_fields:
-                    ext_field.apply_expression(ptcl, self.time)
-                for diag in self.diags:
-                    diag.write(self.iteration)
-                if move_momenta:
-                    for species in ptcl:
-                        species.push_p(self.time + 0.5 * dt)
-                if move_positions:
-                    for species in ptcl:
-                        species.push_x(0.5 * dt)
-            if self.use_galilean:
-                self.shift_galilean_boundaries(0.5 * dt)
-            for species in ptcl:
-                species.handle_elementary_processes(self.time + 0.5 * dt)
-            for species in ptcl:
-                species.keep_fields_sorted = False
+            store = (i_step == N - 1 and not lazy_eb)
             cross = bool(correct_currents) and fld.current_correction == 'cross-deposition'
-            shifted_by = None       # cells by which the field push has already moved the window
-            if move_positions and not self.use_galilean and not cross and self.prerank_in_deposit:
-                # the J deposition also ranks the particles for the sort after the push below
-                # (not with a Galilean grid: zmin moves between this deposit and that sort)
-                for species in ptcl:
-                    species.push_after_deposit_J = (0.5 * dt, 1., 1., 1.)
-            self._defer_J_ok = (move_positions and not self.use_galilean and not cross
-                                and self.fuse_J_into_rho)
-            self.deposit('J', exchange=(correct_currents is False),
-                         defer_transform=(not cross) and not self.reference_sequence)
-            self._defer_J_ok = False
+            one_pass = fused and self._one_pass_ok(correct_currents, use_true_rho, cross)
+            # An iteration that has to re-sort runs the two-pass sequence instead: its second pass
+            # walks the particles in destination order anyway and records the home cells for the
+            # one-pass iterations that follow (a stand-alone sort moves 176 B per particle)
+            sorting = one_pass and any(sp.cycle_wants_sort(fld) for sp in ptcl)
             for species in ptcl:
-                species.push_after_deposit_J = None
-            if cross:
-                self.cross_deposit(move_positions)
-            if move_positions:
-                # deferred: the push is folded into the sort that deposit('rho_next') triggers
-                for species in ptcl:
-                    species.push_x(0.5 * dt, defer=not self.reference_sequence)
-            if self.use_galilean:
-                self.shift_galilean_boundaries(0.5 * dt)
-            self.deposit('rho_next', exchange=(use_true_rho is True))
-            for species in ptcl:
-                species.flush_pending_push()      # species that did not deposit
-            if self.v_comoving is not None:
-                # Galilean / comoving scheme: per-mode correction and push (complex tables)
-                if correct_currents:
-                    fld.correct_currents(check_exchanges=(self.comm.size > 1))
-                    if self.comm.size > 1:
-                        fld.spect2partial_interp('J')
-                        self.comm.exchange_fields(fld.interp, 'J', 'add')
-                        fld.partial_interp2spect('J')
-                    fld.exchanged_source['J'] = True
-                fld.push(use_true_rho, check_exchanges=(self.comm.size > 1))
-            elif self.comm.size == 1 and self.reference_sequence:
-                if correct_currents:
-                    fld.correct_currents()
-                    fld.exchanged_source['J'] = True
-                fld.push(use_true_rho)
-            elif self.comm.size == 1:
-                # single domain: correction, push and rho shift are cell-local -> one launch,
-                # which also translates the fields when the moving window advances right after
-                if cross:
-                    fld.correct_currents()
-                if self.comm.moving_win is not None:
-                    shifted_by = self.comm.moving_win.peek_n_move(self.comm, self.time)
-                fld.psatd_step(correct_currents and not cross, use_true_rho,
-                               n_move=(shifted_by or 0))
-                if correct_currents:
-                    fld.exchanged_source['J'] = True
+                species.record_home_in_sort_pass = sorting
+            if one_pass and not sorting:
+                self._particles_one_pass(store, wrap_z, correct_currents, use_true_rho)
             else:
-                if correct_currents:
-                    assert fld.exchanged_source['J'] is False
-                    if cross:
-                        fld.correct_currents(check_exchanges=True)
-                    else:
-                        fld.psatd_step(use_true_rho=use_true_rho, only_correct=True)
-                    fld.spect2partial_interp('J')
-                    self.comm.exchange_fields(fld.interp, 'J', 'add')
-                    fld.partial_interp2spect('J')
-                    fld.exchanged_source['J'] = True
-                assert fld.exchanged_source['J'] is True
-                fld.psatd_step(correct_currents=False, use_true_rho=use_true_rho)
+                if fused:
+                    self._gather_push_fused(store, wrap_z, cross)
+                else:
+                    self._gather_push_reference_order(move_momenta, move_positions)
+                self._deposit_push_deposit(correct_currents, use_true_rho, move_positions, cross)
+            shifted_by = self._field_update(correct_currents, use_true_rho, cross)
             if self.comm.moving_win is not None:
                 self.comm.move_grids(fld, ptcl, dt, self.time, spect_shifted_by=shifted_by)
             self.exchange_and_damp_EB()
@@ -403,6 +305,191 @@ class Simulation(object):
             fld.defer_sources(self._sources_to_interp)
         else:
             self._sources_to_interp()
+
+    def _start_of_iteration(self, first, fused, diag_due, use_true_rho):
+        """Particle exchange, rho_prev and the diagnostics-only J of main.py:435-451.  Returns the
+        periodic box (zmin, zmax) when the wrap of z is left to the particle pass that follows."""
+        ptcl, fld = self.ptcl, self.fld
+        wrap_z = None
+        if self.iteration % self.comm.exchange_period == 0 or first:
+            need_rho_prev = (first or self.comm.n_guard != 0
+                             or self.redeposit_rho_prev_every_step or use_true_rho)
+            if fused and not need_rho_prev and self.comm.n_guard == 0:
+                # single periodic domain: the wrap of z into the box rides along in the
+                # gather+push launch that comes next (nothing reads z in between)
+                wrap_z = (fld.interp[0].zmin, fld.interp[0].zmax)
+            else:
+                self._wait_eb()      # one exchange at a time on the communicator
+                for species in ptcl:
+                    self.comm.exchange_particles(species, fld, self.time)
+            if need_rho_prev:
+                self.deposit('rho_prev', exchange=(use_true_rho is True))
+        if first and (diag_due or self.reference_sequence or not self.skip_unobserved_first_J):
+            # "For the field diagnostics of the first step: deposit J" (reference main.py:
+            # 448-451; not the corrected current).  Nothing else reads it - the J of this step
+            # is erased and deposited again below - so it is only launched when a diagnostic
+            # is due at this iteration (or the reference launch sequence is asked for).
+            self.deposit('J', exchange=True)
+        return wrap_z
+
+    def _one_pass_ok(self, correct_currents, use_true_rho, cross):
+        """Whether the particle work of this iteration can be the single pass of
+        Particles.cycle: grids that do not move between the gather and the depositions, the
+        in-step (record) deposition target, nothing on a second stream waiting for a split
+        gather, every species supported by the kernel."""
+        fld, comm = self.fld, self.comm
+        if not (self.one_pass_cycle and not self.reference_sequence and not cross
+                and not self.use_galilean and comm.moving_win is None
+                and self.particle_shape == 'linear'):
+            return False
+        if comm.size > 1 and ((correct_currents is False) or (use_true_rho is True)):
+            return False             # those deposits exchange their guard cells on the interpolation grid
+        pend = self._eb_pending
+        if pend is not None and pend[1] is not None:
+            return False
+        return all(sp.cycle_supported(fld.Nm) for sp in self.ptcl)
+
+    def _particles_one_pass(self, store_fields, wrap_z, correct_currents, use_true_rho):
+        """gather, push_p, push_x, deposit('J'), push_x, deposit('rho_next') (main.py:469-528) as
+        one pass per species; J and rho_next are then transformed together."""
+        fld = self.fld
+        self._wait_eb()
+        self._flush_J_transform()
+        fld.erase_source_records()
+        for species in self.ptcl:
+            species.cycle(fld, self.comm, self.dt, store_fields=store_fields, wrap_z=wrap_z)
+            species.keep_fields_sorted = False
+        fld.interp2spect_J_and_rho_next(fuse_filter=self.filter_currents, from_records=True)
+        # (what deposit() records: single domain only when these are True, see _one_pass_ok)
+        fld.exchanged_source['J'] = (correct_currents is False)
+        fld.exchanged_source['rho_next'] = (use_true_rho is True)
+
+    def _gather_push_fused(self, store_fields, wrap_z, cross):
+        """gather + push_p + push_x(dt/2) of main.py:469-490 as one launch per species: nothing
+        observes the particles in between.  The gathered E, B are consumed in registers; the
+        per-particle Ex..Bz arrays are only materialised where something can observe them (the
+        last iteration of a call; diagnostics take _gather_push_reference_order).  The pass also
+        ranks the particles for the sort after the second half push (not with a Galilean grid:
+        zmin moves in between; not with cross-deposition: other pushes)."""
+        ptcl, fld, dt = self.ptcl, self.fld, self.dt
+        hint = (0.5 * dt, 1., 1., 1.) if (self.prerank_in_deposit and not self.use_galilean
+                                          and not cross) else None
+        pend = self._eb_pending
+        if pend is not None and pend[1] is not None and hint is not None and wrap_z is None \
+                and all(sp.can_split_gather(fld.Nm) for sp in ptcl):
+            # the rows [lo, hi) of the interpolation grid are final; a particle of cell
+            # row iz_upper reads rows iz_upper - 2 ... iz_upper + 1 at most (cubic shape)
+            rows = (pend[1] + 2, pend[2] - 2)
+            for species in ptcl:
+                species.gather_push(fld.interp, self.comm, 0.5 * dt, store_fields=store_fields,
+                                    rank_next=hint, part='inside', rows=rows)
+            self._wait_eb()
+            for species in ptcl:
+                species.gather_push(fld.interp, self.comm, 0.5 * dt, store_fields=store_fields,
+                                    rank_next=hint, part='outside', rows=rows)
+        else:
+            self._wait_eb(rows_only=True)
+            for species in ptcl:
+                species.gather_push(fld.interp, self.comm, 0.5 * dt, store_fields=store_fields,
+                                    wrap_z=wrap_z, rank_next=hint)
+
+    def _gather_push_reference_order(self, move_momenta, move_positions):
+        """main.py:469-490 launch by launch (external fields, diagnostics in between)."""
+        ptcl, fld, dt = self.ptcl, self.fld, self.dt
+        self._wait_eb()
+        for species in ptcl:
+            species.gather(fld.interp, self.comm)
+        for ext_field in self.external_fields:
+            ext_field.apply_expression(ptcl, self.time)
+        for diag in self.diags:
+            diag.write(self.iteration)
+        if move_momenta:
+            for species in ptcl:
+                species.push_p(self.time + 0.5 * dt)
+        if move_positions:
+            for species in ptcl:
+                species.push_x(0.5 * dt)
+
+    def _deposit_push_deposit(self, correct_currents, use_true_rho, move_positions, cross):
+        """deposit('J'), push_x(dt/2), deposit('rho_next') of main.py:492-528 (with the Galilean
+        shifts and the cross-deposition in between); in the default sequence the three ride in
+        one destination-ordered pass (Particles.deposit decides)."""
+        ptcl, fld, dt = self.ptcl, self.fld, self.dt
+        if self.use_galilean:
+            self.shift_galilean_boundaries(0.5 * dt)
+        for species in ptcl:
+            species.handle_elementary_processes(self.time + 0.5 * dt)
+        for species in ptcl:
+            species.keep_fields_sorted = False
+        if move_positions and not self.use_galilean and not cross and self.prerank_in_deposit:
+            # the J deposition also ranks the particles for the sort after the push below
+            # (not with a Galilean grid: zmin moves between this deposit and that sort)
+            for species in ptcl:
+                species.push_after_deposit_J = (0.5 * dt, 1., 1., 1.)
+        self._defer_J_ok = (move_positions and not self.use_galilean and not cross
+                            and self.fuse_J_into_rho)
+        self.deposit('J', exchange=(correct_currents is False),
+                     defer_transform=(not cross) and not self.reference_sequence)
+        self._defer_J_ok = False
+        for species in ptcl:
+            species.push_after_deposit_J = None
+        if cross:
+            self.cross_deposit(move_positions)
+        if move_positions:
+            # deferred: the push is folded into the sort that deposit('rho_next') triggers
+            for species in ptcl:
+                species.push_x(0.5 * dt, defer=not self.reference_sequence)
+        if self.use_galilean:
+            self.shift_galilean_boundaries(0.5 * dt)
+        self.deposit('rho_next', exchange=(use_true_rho is True))
+        for species in ptcl:
+            species.flush_pending_push()      # species that did not deposit
+
+    def _field_update(self, correct_currents, use_true_rho, cross):
+        """Current correction, J guard exchange, PSATD push of E, B (main.py:530-557).  Returns the
+        number of cells by which the push has already moved the window (or None)."""
+        fld = self.fld
+        shifted_by = None
+        if self.v_comoving is not None:
+            # Galilean / comoving scheme: per-mode correction and push (complex tables)
+            if correct_currents:
+                fld.correct_currents(check_exchanges=(self.comm.size > 1))
+                if self.comm.size > 1:
+                    fld.spect2partial_interp('J')
+                    self.comm.exchange_fields(fld.interp, 'J', 'add')
+                    fld.partial_interp2spect('J')
+                fld.exchanged_source['J'] = True
+            fld.push(use_true_rho, check_exchanges=(self.comm.size > 1))
+        elif self.comm.size == 1 and self.reference_sequence:
+            if correct_currents:
+                fld.correct_currents()
+                fld.exchanged_source['J'] = True
+            fld.push(use_true_rho)
+        elif self.comm.size == 1:
+            # single domain: correction, push and rho shift are cell-local -> one launch,
+            # which also translates the fields when the moving window advances right after
+            if cross:
+                fld.correct_currents()
+            if self.comm.moving_win is not None:
+                shifted_by = self.comm.moving_win.peek_n_move(self.comm, self.time)
+            fld.psatd_step(correct_currents and not cross, use_true_rho,
+                           n_move=(shifted_by or 0))
+            if correct_currents:
+                fld.exchanged_source['J'] = True
+        else:
+            if correct_currents:
+                assert fld.exchanged_source['J'] is False
+                if cross:
+                    fld.correct_currents(check_exchanges=True)
+                else:
+                    fld.psatd_step(use_true_rho=use_true_rho, only_correct=True)
+                fld.spect2partial_interp('J')
+                self.comm.exchange_fields(fld.interp, 'J', 'add')
+                fld.partial_interp2spect('J')
+                fld.exchanged_source['J'] = True
+            assert fld.exchanged_source['J'] is True
+            fld.psatd_step(correct_currents=False, use_true_rho=use_true_rho)
+        return shifted_by
 
     def _can_defer_particle_fields(self):
         """Same conditions as the carried state: a z-periodic single domain whose grid does not

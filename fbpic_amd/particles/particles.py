@@ -122,6 +122,27 @@ class Particles(object):
         # `prefix_sum` is the exact inclusive per-cell count of the arrays as they are now (set by
         # the sorts, dropped when particles are added / removed)
         self._prefix_valid = False
+        # One-pass particle cycle (Particles.cycle, csrc/cycle.hip): the arrays are re-sorted only
+        # every few steps; `cell_idx` then holds the HOME cell of every particle (its cell at that
+        # sort) and stays valid while nothing permutes or re-sizes the arrays.  Re-sort policy:
+        # after `cycle_sort_period` passes, or earlier when the share of particles that have left
+        # their home cell (counted by the pass itself, read back one step late) exceeds
+        # `cycle_stray_limit`.
+        # Calls of the public compute methods from OUTSIDE Simulation.step (a script that pushes,
+        # gathers, deposits or sorts by hand) change the particle data through raw pointers, which
+        # torch's version counters do not see: `_ext_gen` counts them, and the state that step()
+        # carries from one call to the next is keyed on it (Simulation._carry_signature).
+        self._in_step = False
+        self._ext_gen = 0
+        self._home_valid = False
+        self.record_home_in_sort_pass = False     # set by Simulation.step for its sorting iterations
+        self.cycle_sort_period = int(os.environ.get('FBPIC_AMD_SORT_PERIOD', '3'))
+        self.cycle_stray_limit = float(os.environ.get('FBPIC_AMD_STRAY_LIMIT', '0.12'))
+        self._cycle_since_sort = 0
+        self._cycle_stats = None          # device counters / pinned host copy / pending event
+        self.cycle_sorts = 0              # diagnostics: sorts and passes of the one-pass cycle
+        self.cycle_passes = 0
+        self.cycle_stray_fraction = None  # latest measured share of strays (J deposition)
 
     # ---------------------------------------------------------------- host <-> device
     def _alloc_device_helpers(self):
@@ -193,6 +214,7 @@ class Particles(object):
             self._alloc_device_helpers()
         self.sorted = False
         self._prefix_valid = False
+        self._home_valid = False
         self._moved_since_sort = np.inf
         self._pending_push = None
         self._prerank = None
@@ -278,10 +300,20 @@ class Particles(object):
         """Re-size the device helpers after particles were added / removed."""
         self.sorted = False
         self._prefix_valid = False
+        self._home_valid = False
         self._moved_since_sort = np.inf
         self._prerank = None
         if self.data_is_on_gpu and self.x.is_cuda:
             self._alloc_device_helpers()
+
+    def _touch(self):
+        """Start of a public method that modifies (or re-orders) the particle data."""
+        if not self._in_step:
+            self._ext_gen += 1
+            if self.__dict__.get('_deferred_fields') is not None:
+                # E, B on the particles that step() left to their first read belong to the
+                # positions and momenta as they are now: evaluate them before these change
+                self._materialize_fields()
 
     def _need_gpu(self):
         if not self.data_is_on_gpu:
@@ -296,6 +328,7 @@ class Particles(object):
     # ---------------------------------------------------------------- pushers
     def push_p(self, t):
         """Vay push of (ux, uy, uz, inv_gamma) by one step (reference :557-636)."""
+        self._touch()
         if self.q == 0:
             return
         self._need_gpu()
@@ -312,6 +345,7 @@ class Particles(object):
         `deposit` (fb_push_x_bin_sort_particles), or launched by `flush_pending_push`,
         whichever comes first.  Simulation.step uses it for the half push that precedes
         deposit('rho_next'), main.py:519-528."""
+        self._touch()
         self._need_gpu()
         if not (defer and self.use_bin_sort and self._pending_push is None):
             self.flush_pending_push()
@@ -362,6 +396,7 @@ class Particles(object):
     # ---------------------------------------------------------------- gather
     def gather(self, grid, comm):
         """Interpolate E, B of all modes onto the particles (reference :673-837)."""
+        self._touch()
         if self.q == 0:
             return
         self._need_gpu()
@@ -398,6 +433,7 @@ class Particles(object):
         `part` = 'inside' / 'outside' with `rows` = (a, b): only the particles whose (sorted) cell
         row is / is not in [a, b) - Simulation.step runs the inside part while the guard-cell
         exchange of E, B is in flight and the outside part after it (can_split_gather)."""
+        self._touch()
         self._need_gpu()
         self.drop_deferred_fields()
         self.flush_pending_push()
@@ -467,11 +503,121 @@ class Particles(object):
         dmin = min(self._cell_size) if self._cell_size else 0.
         self._moved_since_sort += (c * abs(dt_x) / dmin if dmin > 0 else np.inf)
 
-    # ---------------------------------------------------------------- sort
-    def sort_particles(self, fld):
-        """Cell index -> stable radix sort -> per-cell prefix sum -> permutation
-        (reference :1049-1094)."""
+    # ---------------------------------------------------------------- one-pass cycle
+    def cycle_supported(self, Nm):
+        """Whether Particles.cycle has a kernel for this species (else: the separate calls)."""
+        return bool(self.use_bin_sort and not self.is_tracer
+                    and (self.q == 0 or _capi.lib().fb_gather_push_deposit_supported(
+                        _SHAPE[self.particle_shape], Nm)))
+
+    def _cycle_poll(self):
+        """Pick up the stray count of an earlier pass if its copy has landed."""
+        st = self._cycle_stats
+        if st is not None and st[2] is not None and st[2][0].query():
+            total = int(st[1].sum())
+            self.cycle_stray_fraction = float(total - st[3]) / max(st[2][1], 1)
+            st[3] = total
+            st[2] = None
+
+    def _after_home_sort(self):
+        """Book-keeping of a sort that has recorded the home cells in `cell_idx`."""
+        self._cycle_since_sort = 0
+        if self._cycle_stats is not None and self._cycle_stats[2] is not None:
+            self._cycle_stats[2][0].synchronize()      # (a copy issued at least one pass ago)
+            self._cycle_poll()
+        self.cycle_stray_fraction = None
+        self.cycle_sorts += 1
+
+    def cycle_wants_sort(self, fld):
+        """True when the next Particles.cycle of this species would start with a sort."""
+        return bool(self.q != 0 and self.Ntot > 0 and self._cycle_needs_sort(fld.interp[0]))
+
+    def _cycle_needs_sort(self, g0):
+        if not self._home_valid or self._cycle_since_sort >= self.cycle_sort_period:
+            return True
+        if self._home_geom != (g0.zmin, g0.invdz, g0.Nz, g0.rmin, g0.invdr, g0.Nr):
+            return True                      # the grid moved: the recorded cells are not cells any more
+        self._cycle_poll()
+        return (self.cycle_stray_fraction is not None
+                and self.cycle_stray_fraction > self.cycle_stray_limit)
+
+    def cycle(self, fld, comm, dt, store_fields=True, wrap_z=None):
+        """gather -> push_p -> push_x(dt/2) -> deposit('J') -> push_x(dt/2) -> deposit('rho') of
+        Simulation.step (main.py:469-528) in ONE pass over the particles
+        (fb_gather_push_deposit_J_rho): identical to the separate calls, every attribute read and
+        written once.  J and rho go to the node-major records of `fld` (already erased by the
+        caller).  The arrays are re-sorted first when the policy asks for it (see __init__)."""
+        self._touch()
         self._need_gpu()
+        self.drop_deferred_fields()
+        self.flush_pending_push()
+        lib, p, st = _capi.lib(), _capi.ptr, _capi.stream()
+        if self.q == 0 or self.Ntot == 0:
+            # no gather, no momentum push, no deposition (reference :575, :697, :866)
+            if wrap_z is not None and self.Ntot > 0:
+                _capi.check(lib.fb_shift_periodic(self.Ntot, p(self.z), float(wrap_z[0]),
+                                                  float(wrap_z[1]), st), 'fb_shift_periodic')
+            self.push_x(0.5 * dt)
+            self.push_x(0.5 * dt)
+            return
+        grid = fld.interp
+        Nm = len(grid)
+        g0 = grid[0]
+        if self._cycle_needs_sort(g0):
+            # (Simulation.step avoids this stand-alone sort: an iteration that needs one runs the
+            # two-pass sequence, whose second pass sorts and records the home cells as it goes)
+            kfs, self.keep_fields_sorted = self.keep_fields_sorted, False
+            self.sort_particles(fld, record_home=True)
+            self.keep_fields_sorted = kfs
+            self.sorted = True
+            self._after_home_sort()
+        t = _capi.torch()
+        if self._cycle_stats is None or self._cycle_stats[0].device != self.x.device:
+            # device counters, pinned host copy, (event, Ntot) of a pending read, total last read
+            self._cycle_stats = [t.zeros(1024, dtype=t.int64, device=self.x.device),
+                                 t.zeros(1024, dtype=t.int64).pin_memory(), None, 0]
+        views = []
+        for m in range(Nm):
+            views += [grid[m].Er, grid[m].Et, grid[m].Ez, grid[m].Br, grid[m].Bt, grid[m].Bz]
+        eb = [p(getattr(self, k)) if store_fields else None for k in _FIELDS]
+        wz = (0., 0.) if wrap_z is None else (float(wrap_z[0]), float(wrap_z[1]))
+        jv, rv = fld.record_views('J'), fld.record_views('rho')
+        ruy0 = grid[0].d_ruyten_linear_coef
+        ruyh = grid[1 if Nm > 1 else 0].d_ruyten_linear_coef
+        stats = self._cycle_stats
+        # (the counters are cumulative - the pass adds to them - and read back every fourth pass:
+        # one small copy, no memset launch)
+        measure = stats[2] is None and self._cycle_since_sort % 4 == 3
+        rc = lib.fb_gather_push_deposit_J_rho(
+            _SHAPE[self.particle_shape], Nm, self.Ntot, p(self.x), p(self.y), p(self.z),
+            p(self.ux), p(self.uy), p(self.uz), p(self.inv_gamma), p(self.w), p(self.cell_idx),
+            comm.get_rmax(with_damp=False), g0.invdz, g0.zmin, g0.Nz, g0.invdr, g0.rmin, g0.Nr,
+            _capi.ptr_array(views), _capi.row_stride(views[0]), *eb,
+            self.q, self.m, c, self.dt, 0.5 * dt, wz[0], wz[1],
+            _capi.ptr_array(jv), jv[0].stride(0), jv[0].stride(1),
+            _capi.ptr_array(rv), rv[0].stride(0), rv[0].stride(1), p(ruy0), p(ruyh),
+            p(stats[0]) if measure else None, st)
+        _capi.check(rc, 'fb_gather_push_deposit_J_rho')
+        if measure:
+            stats[1].copy_(stats[0], non_blocking=True)
+            ev = t.cuda.Event()
+            ev.record()
+            stats[2] = (ev, self.Ntot)
+        self._cycle_since_sort += 1
+        self.cycle_passes += 1
+        self._prerank = None
+        self.sorted = False
+        dmin = min(self._cell_size) if self._cell_size else 0.
+        self._moved_since_sort += (c * abs(dt) / dmin if dmin > 0 else np.inf)
+
+    # ---------------------------------------------------------------- sort
+    def sort_particles(self, fld, record_home=False):
+        """Cell index -> stable radix sort -> per-cell prefix sum -> permutation
+        (reference :1049-1094).  `record_home`: `cell_idx` receives the cell of every sorted
+        particle (the home cells of Particles.cycle)."""
+        self._touch()
+        self._need_gpu()
+        self._home_valid = False
         self.flush_pending_J()          # a deferred J deposition belongs to the unsorted state
         g0 = fld.interp[0]
         lib = _capi.lib()
@@ -482,7 +628,7 @@ class Particles(object):
             names = list(_STATE) + (list(_FIELDS) if self.keep_fields_sorted else [])
             src = [getattr(self, k) for k in names]
             dst = self._alt[:len(names)]
-            p_cell = p(self.cell_idx) if self.keep_sort_outputs else None
+            p_cell = p(self.cell_idx) if (self.keep_sort_outputs or record_home) else None
             p_sidx = p(self.sorted_idx) if self.keep_sort_outputs else None
             pend, self._pending_push = self._pending_push, None
             preranked = int(pend is not None and self._prerank == pend)
@@ -514,6 +660,8 @@ class Particles(object):
             self.prefix_sum_shift = 0
             self._cell_size = (g0.dz, g0.dr)
             self._moved_since_sort = 0.
+            self._home_valid = bool(record_home)
+            self._home_geom = (g0.zmin, g0.invdz, g0.Nz, g0.rmin, g0.invdr, g0.Nr)
             return
         self.flush_pending_push()
         self._prerank = None
@@ -536,6 +684,8 @@ class Particles(object):
         self._cell_size = (g0.dz, g0.dr)
         self._moved_since_sort = 0.
         self.rearrange_particle_arrays()
+        self._home_valid = True           # the radix sort leaves the sorted keys in cell_idx
+        self._home_geom = (g0.zmin, g0.invdz, g0.Nz, g0.rmin, g0.invdr, g0.Nr)
 
     def _push_sort_deposit_rho(self, fld, records):
         """fb_push_x_sort_deposit_rho: the deferred push_x, the counting sort and the charge
@@ -547,6 +697,8 @@ class Particles(object):
         names = list(_STATE) + (list(_FIELDS) if self.keep_fields_sorted else [])
         src = [getattr(self, k) for k in names]
         dst = self._alt[:len(names)]
+        self._home_valid = False
+        record_home = self.record_home_in_sort_pass
         pj = self._pending_J
         if pj is not None and (pj[0] is not fld or pj[1] != records):
             # different target: J on its own, then as usual.  That deposit may re-sort the
@@ -574,7 +726,7 @@ class Particles(object):
                 p(self.ux), p(self.uy), p(self.uz), p(self.inv_gamma), c, pend[0], pend[1], pend[2],
                 pend[3], g0.invdz, g0.zmin, g0.Nz, g0.invdr, g0.rmin, g0.Nr,
                 len(names), _capi.ptr_array(src), _capi.ptr_array(dst),
-                p(self.cell_idx) if self.keep_sort_outputs else None, p(self.sorted_idx),
+                p(self.cell_idx) if (self.keep_sort_outputs or record_home) else None, p(self.sorted_idx),
                 p(self.prefix_sum), p(self._sort_ws), self._sort_ws.shape[0], preranked,
                 _SHAPE[self.particle_shape], Nm, self.q, g0.zmin, _capi.ptr_array(jviews),
                 jviews[0].stride(0), jviews[0].stride(1), _capi.ptr_array(views),
@@ -586,7 +738,7 @@ class Particles(object):
                 p(self.ux), p(self.uy), p(self.uz), p(self.inv_gamma), c, pend[0], pend[1], pend[2],
                 pend[3], g0.invdz, g0.zmin, g0.Nz, g0.invdr, g0.rmin, g0.Nr,
                 len(names), _capi.ptr_array(src), _capi.ptr_array(dst),
-                p(self.cell_idx) if self.keep_sort_outputs else None, p(self.sorted_idx),
+                p(self.cell_idx) if (self.keep_sort_outputs or record_home) else None, p(self.sorted_idx),
                 p(self.prefix_sum), p(self._sort_ws), self._sort_ws.shape[0], preranked,
                 _SHAPE[self.particle_shape], Nm, self.q, _capi.ptr_array(views),
                 views[0].stride(0), views[0].stride(1), p(ruy0), p(ruyh), st)
@@ -603,9 +755,16 @@ class Particles(object):
         self.sorted = True
         self._deposits_since_sort = 0
         self._runs_latest = None
+        if record_home:
+            # `cell_idx` now holds the cell of every particle at its sorted slot
+            self._home_valid = True
+            self._home_geom = (g0.zmin, g0.invdz, g0.Nz, g0.rmin, g0.invdr, g0.Nr)
+            self._after_home_sort()
 
     def rearrange_particle_arrays(self):
         """Apply sorted_idx to every particle attribute in one launch (ping-pong buffers)."""
+        self._touch()
+        self._home_valid = False
         names = list(_STATE)
         if self.keep_fields_sorted:
             names += list(_FIELDS)
@@ -660,6 +819,7 @@ class Particles(object):
         """Deposit rho or J of this species on the interpolation grid (reference :839-1046).
         `records` (Simulation.step): deposit into the node-major record array of the Fields
         object instead (Fields.source_records), which the z-FFT reads directly."""
+        self._touch()
         if self.q == 0:
             return
         assert fieldtype in ['rho', 'J']

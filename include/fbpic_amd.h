@@ -350,6 +350,35 @@ int fb_push_x_sort_deposit_J_rho(long n, int ncell, const double *x, const doubl
                                  long row_stride, long col_stride, const double *ruyten_m0,
                                  const double *ruyten_mh, void *stream);
 
+/* The particle work of a whole PIC step in ONE pass (csrc/cycle.hip): identical result to
+ *   fb_gather_push(shape, Nm, n, x .. inv_gamma, ..., dt, dt_x, wrap_zmin, wrap_zmax)   main.py:469-490
+ *   fb_deposit_J(shape, Nm, n, x, y, z, w, q, ux, uy, uz, inv_gamma, c, ..., J, ...)    main.py:515-517
+ *   fb_push_x(n, x, y, z, ux, uy, uz, inv_gamma, c, dt_x, 1, 1, 1)                      main.py:519-522
+ *   fb_deposit_rho(shape, Nm, n, x, y, z, w, q, ..., rho, ...)                          main.py:528
+ * (momenta and positions bit-identical, deposited sums equal up to summation order): every particle
+ * attribute is read once and written once, 64 B + 56 B per particle.  The arrays are NOT re-sorted
+ * by this call.  `home_cell[i]` = cell (ir_upper + iz_upper (Nr + 1), the `cell_idx_sorted` output
+ * of fb_bin_sort_particles) of particle i at the last sort: runs of equal home cells replace the
+ * runs of equal cells of the sorted depositions, and particles that have since left their home
+ * cell are gathered / deposited on their own.  Any `home_cell` content gives the same result; how
+ * many particles take the slow path is what changes, and `stats` (optional, 1024 counters that
+ * the call ADDS to) receives their number for the caller's re-sort policy.
+ * Linear shape, Nm <= 4 (fb_gather_push_deposit_supported). */
+int fb_gather_push_deposit_supported(int shape, int Nm);
+int fb_gather_push_deposit_J_rho(int shape, int Nm, long n,
+                                 double *x, double *y, double *z, double *ux, double *uy,
+                                 double *uz, double *inv_gamma, const double *w,
+                                 const int *home_cell, double rmax_gather,
+                                 double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
+                                 const void *const *grids, long row_stride,
+                                 double *Ex, double *Ey, double *Ez, double *Bx, double *By, double *Bz,
+                                 double q, double m, double c, double dt, double dt_x,
+                                 double wrap_zmin, double wrap_zmax,
+                                 void *const *J, long J_row_stride, long J_col_stride,
+                                 void *const *rho, long rho_row_stride, long rho_col_stride,
+                                 const double *ruyten_m0, const double *ruyten_mh,
+                                 unsigned long long *stats, void *stream);
+
 /* fb_deposit_J that also prepares the counting sort which Simulation.step runs after the
  * next push_x (main.py:515-528: deposit J, push_x(dt/2), re-sort for deposit rho_next): for
  * every particle, the cell of the position pushed by (dt_push, x_push, y_push, z_push) and

@@ -1,0 +1,244 @@
+"""The one-pass particle cycle (csrc/cycle.hip, fb_gather_push_deposit_J_rho; Particles.cycle):
+the kernel against the four entry points it fuses - bit-identical particles, J and rho to 1e-13
+(the reference's own CPU <-> GPU bound, tests/test_cpu_gpu_deposition.py:96) and against the
+oracle's depositions - for fresh, stale and meaningless home cells; Simulation.step through it
+against the two-pass sequence and against the oracle."""
+import numpy as np
+import pytest
+from scipy.constants import c, e, m_e
+from conftest import rel_err, achieved
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from fbpic_amd import _capi
+    _capi.require_device()
+    return _capi
+
+
+def dev(hip, a, dtype=None):
+    return hip.to_device(np.ascontiguousarray(a, dtype=dtype))
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def _plasma(rng, n, Nz, Nr, dzc):
+    """Particles over the whole grid, some beyond rmax, some on the axis, a few exactly on nodes."""
+    r = rng.uniform(0, 1.03 * Nr * dzc, n)
+    r[:50] = rng.uniform(0, 0.6 * dzc, 50)            # inside the first cell: mirror below the axis
+    th = rng.uniform(0, 2 * np.pi, n)
+    x, y = r * np.cos(th), r * np.sin(th)
+    z = rng.uniform(0., Nz * dzc, n)
+    z[50:80] = rng.uniform(0., 0.6 * dzc, 30)         # periodic wrap of the stencil
+    z[80:110] = Nz * dzc - rng.uniform(0., 0.6 * dzc, 30)
+    x[110:114] = (np.arange(4) + 0.5) * dzc           # exactly on nodes
+    y[110:114] = 0.
+    z[110:114] = (np.arange(4) + 2.5) * dzc
+    return x, y, z
+
+
+@pytest.mark.parametrize('Nm,records,stale', [(2, True, 0.0), (2, True, 0.25), (2, True, 'garbage'),
+                                              (1, False, 0.25), (3, True, 0.25), (4, False, 0.6),
+                                              (2, True, 'unsorted')])
+def test_one_pass_equals_the_four_entry_points(hip, oracle, Nm, records, stale):
+    rng = np.random.default_rng(7 + Nm)
+    n, Nz, Nr = 100003, 36, 20
+    dzc = 0.2e-6
+    geom = (1. / dzc, 0., Nz, 1. / dzc, 0., Nr)
+    rmax_gather = Nr * dzc
+    x, y, z = _plasma(rng, n, Nz, Nr, dzc)
+    ux, uy, uz = (rng.normal(size=n) * 0.4 for _ in range(3))
+    ig = 1. / np.sqrt(1. + ux**2 + uy**2 + uz**2)
+    w = rng.uniform(0.5, 1.5, n)
+    dt = dzc / c
+    q, m = -e, m_e
+    t = hip.torch()
+    p = hip.ptr
+    ncell = Nz * (Nr + 1)
+    # ---- the sort that records the home cells, then (stale) the particles move on
+    src = [dev(hip, a) for a in (x, y, z, ux, uy, uz, w, ig)]
+    dst = [t.empty_like(a) for a in src]
+    home = t.empty(n, dtype=t.int32, device='cuda')
+    pre = t.empty(ncell, dtype=t.int32, device='cuda')
+    nb = int(hip.lib().fb_bin_sort_workspace_bytes(n, ncell))
+    ws = t.empty(nb, dtype=t.uint8, device='cuda')
+    if stale == 'unsorted':
+        dst = src
+        home.copy_(t.from_numpy(oracle.cell_index(x, y, z, *geom).astype(np.int32)))
+    else:
+        hip.check(hip.lib().fb_bin_sort_particles(n, ncell, p(src[0]), p(src[1]), p(src[2]), *geom, 8,
+                                                  hip.ptr_array(src), hip.ptr_array(dst), p(home), None,
+                                                  p(pre), p(ws), nb, hip.stream()), 'bin_sort')
+    hx, hy, hz = host(dst[0]).copy(), host(dst[1]).copy(), host(dst[2]).copy()
+    assert stale == 'unsorted' or np.all(np.diff(host(home)) >= 0)
+    if stale == 'garbage':
+        home.copy_(t.from_numpy(rng.integers(-2**31, 2**31 - 1, n).astype(np.int32)))
+    elif isinstance(stale, float) and stale > 0:
+        hx += rng.normal(size=n) * stale * dzc
+        hy += rng.normal(size=n) * stale * dzc
+        hz += rng.normal(size=n) * stale * dzc
+    state = [hx, hy, hz] + [host(a).copy() for a in dst[3:]]          # x y z ux uy uz w ig
+    # field grids: six per mode
+    views = [dev(hip, (rng.normal(size=(Nz, Nr)) + 1j * rng.normal(size=(Nz, Nr))) * 1e9)
+             for _ in range(6 * Nm)]
+    ruy0 = dev(hip, rng.uniform(-0.05, 0.05, Nr + 1))
+    ruyh = dev(hip, rng.uniform(-0.05, 0.05, Nr + 1))
+    zlo, zhi = 0., Nz * dzc
+
+    def target():
+        if records:
+            rec = t.zeros((Nz, Nr, 4 * Nm), dtype=t.complex128, device='cuda')
+            return rec, [rec[:, :, 4 * mm + k] for mm in range(Nm) for k in range(3)], \
+                [rec[:, :, 4 * mm + 3] for mm in range(Nm)]
+        g = t.zeros((Nz, 4 * Nm, Nr), dtype=t.complex128, device='cuda')
+        return g, [g[:, 4 * mm + k, :] for mm in range(Nm) for k in range(3)], \
+            [g[:, 4 * mm + 3, :] for mm in range(Nm)]
+
+    # ---- one pass
+    a = [dev(hip, v) for v in state]
+    F = [t.zeros(n, dtype=t.float64, device='cuda') for _ in range(6)]
+    stats = t.zeros(1024, dtype=t.int64, device='cuda')
+    base, jv, rv = target()
+    hip.check(hip.lib().fb_gather_push_deposit_J_rho(
+        1, Nm, n, p(a[0]), p(a[1]), p(a[2]), p(a[3]), p(a[4]), p(a[5]), p(a[7]), p(a[6]), p(home),
+        rmax_gather, *geom, hip.ptr_array(views), Nr, *[p(f) for f in F], q, m, c, dt, 0.5 * dt, zlo, zhi,
+        hip.ptr_array(jv), jv[0].stride(0), jv[0].stride(1), hip.ptr_array(rv), rv[0].stride(0),
+        rv[0].stride(1), p(ruy0), p(ruyh), p(stats), hip.stream()), 'one pass')
+    # ---- the sequence it replaces
+    b = [dev(hip, v) for v in state]
+    F2 = [t.zeros(n, dtype=t.float64, device='cuda') for _ in range(6)]
+    base2, jv2, rv2 = target()
+    hip.check(hip.lib().fb_gather_push(1, Nm, n, p(b[0]), p(b[1]), p(b[2]), p(b[3]), p(b[4]), p(b[5]), p(b[7]),
+                                       rmax_gather, *geom, hip.ptr_array(views), Nr, *[p(f) for f in F2],
+                                       q, m, c, dt, 0.5 * dt, zlo, zhi, hip.stream()), 'gather_push')
+    xh, yh, zh = host(b[0]).copy(), host(b[1]).copy(), host(b[2]).copy()
+    hip.check(hip.lib().fb_deposit_J(1, Nm, n, p(b[0]), p(b[1]), p(b[2]), p(b[6]), q, p(b[3]), p(b[4]),
+                                     p(b[5]), p(b[7]), c, *geom, hip.ptr_array(jv2), jv2[0].stride(0),
+                                     jv2[0].stride(1), None, p(ruy0), p(ruyh), None, hip.stream()), 'deposit_J')
+    hip.check(hip.lib().fb_push_x(n, p(b[0]), p(b[1]), p(b[2]), p(b[3]), p(b[4]), p(b[5]), p(b[7]), c,
+                                  0.5 * dt, 1., 1., 1., hip.stream()), 'push_x')
+    hip.check(hip.lib().fb_deposit_rho(1, Nm, n, p(b[0]), p(b[1]), p(b[2]), p(b[6]), q, *geom,
+                                       hip.ptr_array(rv2), rv2[0].stride(0), rv2[0].stride(1), None,
+                                       p(ruy0), p(ruyh), None, hip.stream()), 'deposit_rho')
+    for k, (u, v) in enumerate(zip(a + F, b + F2)):
+        assert np.array_equal(host(u), host(v)), k
+    scJ = max(np.abs(host(v)).max() for v in jv2)
+    scR = max(np.abs(host(v)).max() for v in rv2)
+    errJ = max(np.abs(host(u) - host(v)).max() for u, v in zip(jv, jv2)) / scJ
+    errR = max(np.abs(host(u) - host(v)).max() for u, v in zip(rv, rv2)) / scR
+    achieved(None, errJ, 1e-13, 'J vs sequence')
+    achieved(None, errR, 1e-13, 'rho vs sequence')
+    # ---- the oracle's depositions of the same particles
+    um = [host(b[k]) for k in (3, 4, 5)]
+    gl = oracle.deposit_J_global('linear', Nm, xh, yh, zh, state[6], q, um[0], um[1], um[2], host(b[7]),
+                                 *geom, host(ruy0), host(ruyh), 1)
+    gr = np.zeros((1, Nm, Nz + 4, Nr + 4), dtype=np.complex128)
+    oracle.deposit_rho_global('linear', Nm, host(b[0]), host(b[1]), host(b[2]), state[6], q, *geom,
+                              host(ruy0), host(ruyh), 1, gr)
+    worst = 0.
+    for mm in range(Nm):
+        for k in range(3):
+            red = np.zeros((Nz, Nr), dtype=np.complex128)
+            oracle.sum_reduce(gl[k], mm, red)
+            sc = max(np.abs(gl[kk]).max() for kk in range(3))
+            worst = max(worst, np.abs(host(jv[3 * mm + k]) - red).max() / sc)
+        red = np.zeros((Nz, Nr), dtype=np.complex128)
+        oracle.sum_reduce(gr, mm, red)
+        worst = max(worst, np.abs(host(rv[mm]) - red).max() / np.abs(gr).max())
+    achieved(None, worst, 1e-13, 'J, rho vs oracle')
+    # the pass counted the particles it deposited on their own
+    nstray = int(host(stats).sum())
+    if stale == 0.0:
+        assert nstray < 0.5 * n           # those that leave their cell within the half push (u ~ 0.4)
+    elif stale == 'garbage':
+        assert nstray > 0.99 * n
+    else:
+        assert 0 < nstray < n
+
+
+def test_one_pass_without_wrap_and_without_stored_fields(hip):
+    """wrap off (z beyond the box is deposited through the periodic fold, gathered through the
+    row wrap) and Ex..Bz = NULL: same particles as with stored fields."""
+    rng = np.random.default_rng(3)
+    n, Nz, Nr, Nm = 20011, 24, 12, 2
+    dzc = 0.2e-6
+    geom = (1. / dzc, 0., Nz, 1. / dzc, 0., Nr)
+    x, y, z = _plasma(rng, n, Nz, Nr, dzc)
+    z[200:260] = Nz * dzc + rng.uniform(0., 0.4 * dzc, 60)     # not wrapped: beyond zmax
+    ux, uy, uz = (rng.normal(size=n) * 0.1 for _ in range(3))
+    ig = 1. / np.sqrt(1. + ux**2 + uy**2 + uz**2)
+    w = rng.uniform(0.5, 1.5, n)
+    dt = dzc / c
+    t = hip.torch()
+    p = hip.ptr
+    home = dev(hip, rng.integers(0, Nz * (Nr + 1), n).astype(np.int32))
+    views = [dev(hip, (rng.normal(size=(Nz, Nr)) + 1j * rng.normal(size=(Nz, Nr))) * 1e9)
+             for _ in range(6 * Nm)]
+    ruy = dev(hip, np.zeros(Nr + 1))
+    out = []
+    for store, wrap in ((True, False), (False, False)):
+        a = [dev(hip, v) for v in (x, y, z, ux, uy, uz, w, ig)]
+        F = [t.zeros(n, dtype=t.float64, device='cuda') for _ in range(6)]
+        rec = t.zeros((Nz, Nr, 4 * Nm), dtype=t.complex128, device='cuda')
+        jv = [rec[:, :, 4 * mm + k] for mm in range(Nm) for k in range(3)]
+        rv = [rec[:, :, 4 * mm + 3] for mm in range(Nm)]
+        hip.check(hip.lib().fb_gather_push_deposit_J_rho(
+            1, Nm, n, p(a[0]), p(a[1]), p(a[2]), p(a[3]), p(a[4]), p(a[5]), p(a[7]), p(a[6]), p(home),
+            Nr * dzc, *geom, hip.ptr_array(views), Nr, *[p(f) if store else None for f in F], -e, m_e, c,
+            dt, 0.5 * dt, 0., 0., hip.ptr_array(jv), jv[0].stride(0), jv[0].stride(1), hip.ptr_array(rv),
+            rv[0].stride(0), rv[0].stride(1), p(ruy), p(ruy), None, hip.stream()), 'one pass')
+        out.append(([host(v) for v in a], host(rec)))
+    for u, v in zip(out[0][0], out[1][0]):
+        assert np.array_equal(u, v)
+    assert rel_err(out[1][1], out[0][1]) < 1e-13
+    assert np.isfinite(out[0][1]).all() and np.abs(out[0][1]).max() > 0
+
+
+@pytest.mark.parametrize('Nm,period', [(2, 3), (3, 1), (1, 50)])
+def test_step_one_pass_equals_two_pass_and_oracle(hip, oracle, Nm, period):
+    """Simulation.step through Particles.cycle (re-sort every `period` steps) against the
+    two-pass sequence and the oracle: fields 5e-13 after 7 steps, same particle set."""
+    import helpers
+    res = []
+    for one in (True, False):
+        sim = helpers.uniform_plasma_sim(32, 16, Nm, (2, 2, 4), 'linear', seed=4, u_th=0.1)
+        sim.one_pass_cycle = one
+        for s in sim.ptcl:
+            s.cycle_sort_period = period
+        if one:
+            ref = helpers.oracle_from_sim(oracle, sim)
+        sim.step(4)
+        sim.step(3)
+        s = sim.ptcl[0]
+        assert (s.cycle_passes > 0) == one
+        if one:
+            # every call starts with a sorting (two-pass) iteration: the arrays come from the host;
+            # `period` one-pass iterations follow each of them
+            assert (s.cycle_sorts, s.cycle_passes) == {3: (2, 5), 1: (4, 3), 50: (2, 5)}[period]
+        res.append(sim)
+    ref.step(7)
+    a, b = res
+    scale = {}
+    for grp in ('E', 'B', 'J', 'r'):
+        scale[grp] = max(np.abs(ref.interp[m][k]).max() for m in range(Nm) for k in helpers.INTERP if k[0] == grp)
+    e_two = e_orc = 0.
+    for m in range(Nm):
+        for k in helpers.INTERP:
+            fa, fb = getattr(a.fld.interp[m], k), getattr(b.fld.interp[m], k)
+            e_two = max(e_two, np.abs(fa - fb).max() / scale[k[0]])
+            e_orc = max(e_orc, np.abs(fa - ref.interp[m][k]).max() / scale[k[0]])
+    achieved(None, e_two, 5e-12, 'fields vs two-pass s7')
+    achieved(None, e_orc, 5e-12, 'fields vs oracle s7')
+    # same particles (the order differs with the sort history): compare through a sort on w, x
+    def canon(sim):
+        s = sim.ptcl[0]
+        A = np.stack([np.asarray(getattr(s, k)) for k in ('x', 'y', 'z', 'ux', 'uy', 'uz', 'inv_gamma', 'w')])
+        return A[:, np.lexsort((A[0], A[7]))]
+    pa, pb = canon(a), canon(b)
+    # identify particles by (w, x): unique to rounding in this lattice + thermal state
+    pe = max(np.abs(pa[i] - pb[i]).max() / max(np.abs(pb[i]).max(), 1e-300) for i in range(8))
+    achieved(None, pe, 5e-11, 'particles vs two-pass s7')
