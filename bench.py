@@ -54,6 +54,10 @@ WORK = {
     # the first pass of the two-pass step: the same 112 B (the 8 B of cell + rank it also writes
     # are sort bytes: OVERHEAD below)
     'fb_gather_push_rank_next': ('hbm', lambda a: (160.0 if a[19] is not None else 112.0) * a[2]),
+    # the one-pass cycle: gather + push_p + push_x + deposit J + push_x + deposit rho with every
+    # attribute read once (x, y, z, ux, uy, uz, inv_gamma, w: 64 B) and written once (all but w:
+    # 56 B) - the union rule of SURVEY.md 8d over the six operations; + 48 B when E, B are stored
+    'fb_gather_push_deposit_J_rho': ('hbm', lambda a: (168.0 if a[21] is not None else 120.0) * a[2]),
     'fb_deposit_rho': ('hbm', lambda a: 32.0 * a[2]),
     'fb_deposit_J': ('hbm', lambda a: 64.0 * a[2]),
     'fb_deposit_J_rank_next': ('hbm', lambda a: 64.0 * a[2]),
@@ -78,6 +82,7 @@ WORK = {
 # work - report separately"): reported as `overhead_bytes` per launch and in
 # `frac_incl_overhead`, never in `frac`.
 OVERHEAD = {
+    'fb_gather_push_deposit_J_rho': lambda a: 4.0 * a[2],      # home cell of every particle, read
     'fb_gather_push_rank_next': lambda a: 8.0 * a[2],          # cell + rank of the next sort, written
     'fb_deposit_J_rank_next': lambda a: 8.0 * a[2],
     # the sort pass re-writes the 5 arrays the push does not change (40 B) + reads cell and rank
@@ -159,8 +164,11 @@ def bench_c3(args, torch, world, rank):
     print(json.dumps(out))
 
 
-_TWO_PASS = ('two-pass MI355X sequence: gather+push_p+push_x(+rank for the sort) one pass, '
-             'J deposit+push_x+sort+rho deposit one pass; the timed call continues from the device state of '
+_TWO_PASS = ('one-pass MI355X sequence: gather+push_p+push_x+J deposit+push_x+rho deposit of an iteration '
+             'in ONE pass over the particles, whose arrays are re-sorted every 4th iteration only - '
+             'that iteration runs the two-pass sequence (gather+push(+rank) | J deposit+push_x+sort+rho '
+             'deposit) - both kinds inside the timed region (extra.particle_passes); forward Hankel of '
+             'J,rho + PSATD step + inverse Hankel of E,B one launch; the timed call continues from the device state of '
              'the warm-up call (nobody touched the tensors in between), so its first iteration is an '
              'interior one; J, rho on the interpolation grid and E,B on the particles, which step() defers '
              'to their first read, ARE read inside the timed region; sanctioned skips inside the timed '
@@ -282,11 +290,23 @@ def main():
     with GpuMemoryManager(sim):
         sim.step(warm)
         barrier()
+        clocks_before = device_clocks()
         t0 = time.perf_counter()
         sim.step(args.steps)
         finish_outputs(sim)
         barrier()
         dt_wall = time.perf_counter() - t0
+        # the same timed call twice more, back to back (the headline stays the first): tells a slow
+        # box / clock state from a slow build when the line moves between runs of unchanged kernels
+        repeats = [1e3 * dt_wall / args.steps]
+        for _ in range(2 if world == 1 else 0):
+            barrier()
+            t1 = time.perf_counter()
+            sim.step(args.steps)
+            finish_outputs(sim)
+            barrier()
+            repeats.append(1e3 * (time.perf_counter() - t1) / args.steps)
+        clocks_after = device_clocks()
         kern = None
         if not args.no_kernel_timing:
             _capi.enable_timing()
@@ -314,6 +334,11 @@ def main():
                    'particles': n_total, 'parallelism': 'z-slab x%d' % world,
                    'sequence': 'reference' if args.reference_sequence else 'fused'},
     }
+    out['extra'] = {'repeat_ms_per_step': repeats, 'device': device_identity(torch),
+                    'clocks_before': clocks_before, 'clocks_after': clocks_after,
+                    'particle_passes': {'one_pass': sum(s.cycle_passes for s in sim.ptcl),
+                                        'sorting_two_pass': sum(s.cycle_sorts for s in sim.ptcl),
+                                        'sort_period': sim.ptcl[0].cycle_sort_period if sim.ptcl else None}}
     if kern:
         ceil = measured_ceilings(torch)
         out['roofline'], out['kernels'] = roofline(kern, ceil, {'C2': True, 'C5': 'c5'}.get(config_name(args, ppc, world), False))
@@ -321,6 +346,44 @@ def main():
     if cpu_base:
         out['cpu_baseline'] = cpu_base
     print(json.dumps(out))
+
+
+def _rocm_smi(*flags):
+    """Best-effort `rocm-smi <flags> --json` of the first device ({} when the tool is missing)."""
+    import subprocess
+    try:
+        r = subprocess.run(['rocm-smi', *flags, '--json'], capture_output=True, text=True, timeout=20)
+        d = json.loads(r.stdout)
+        return d.get('card0', next(iter(d.values()))) if isinstance(d, dict) and d else {}
+    except Exception:
+        return {}
+
+
+def device_clocks():
+    """sclk / mclk as rocm-smi reports them at this moment (between timed regions: an idle GPU
+    reads its idle state, so both ends of the timed calls are recorded)."""
+    d = _rocm_smi('--showclocks')
+    out = {}
+    for k, v in d.items():
+        kl = k.lower()
+        if 'sclk' in kl and 'level' in kl:
+            out['sclk'] = v
+        elif 'mclk' in kl and 'level' in kl:
+            out['mclk'] = v
+    return out
+
+
+def device_identity(torch):
+    p = torch.cuda.get_device_properties(torch.cuda.current_device())
+    ident = {'name': p.name, 'compute_units': p.multi_processor_count,
+             'hip': getattr(torch.version, 'hip', None)}
+    d = _rocm_smi('--showuniqueid', '--showserial')
+    for k, v in d.items():
+        if 'unique' in k.lower():
+            ident['unique_id_suffix'] = str(v)[-6:]
+        elif 'serial' in k.lower():
+            ident['serial_suffix'] = str(v)[-6:]
+    return ident
 
 
 def finish_outputs(sim):
@@ -445,6 +508,7 @@ _KERNEL_OF = {
     'fb_gather_push': ('k_gather<',), 'fb_gather': ('k_gather<',),
     'fb_gather_push_rank_next': ('k_gather',),
     'fb_push_x_sort_deposit_J_rho': ('k_perm_deposit_J_rho<',),
+    'fb_gather_push_deposit_J_rho': ('k_cycle_linear<',),
     'fb_deposit_J_rank_next': ('k_deposit<', ', 3, ', 'true, true>'),
     'fb_deposit_J': ('k_deposit<', ', 3, '), 'fb_deposit_rho': ('k_deposit<', ', 1, '),
     'fb_push_x_bin_sort_particles': ('k_scatter<true>',), 'fb_push_x': ('k_push_x',),

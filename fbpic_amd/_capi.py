@@ -98,6 +98,9 @@ _SIGNATURES = {
     'fb_hankel_scaled': (I, [I, _PP, L, _PP, L, _PP, _PP, _PP, _PP, D, I, I, P]),
     'fb_hankel_pm_to_rt': (I, [I, _PP, _PP, L, _PP, _PP, L, _PP, _PP, D, I, I, P]),
     'fb_hankel_rt_to_pm_scaled': (I, [I, _PP, _PP, P, L, _PP, L, _PP, _PP, _PP, _PP, D, I, I, P]),
+    'fb_spect_cycle_supported': (I, [I, I]),
+    'fb_spect_cycle_standard': (I, [I, _PP, L, _PP, _PP, _PP, _PP, _PP, _PP, L, _PP, D, I, I, D, D, D,
+                                    _PP, L, I, I, P]),
     'fb_psatd_step_standard': (I, [I, _PP, L, _PP, D, I, I, D, D, D, I, I, P]),
     'fb_psatd_step_standard_shift': (I, [I, _PP, L, _PP, D, I, I, D, D, D, I, I, P, I, P]),
 }
@@ -208,7 +211,7 @@ class _TimedLib(object):
         f = getattr(self._real, name)
         if not name.startswith('fb_') or name in ('fb_last_error', 'fb_abi_version',
                                                   'fb_sort_workspace_bytes', 'fb_bin_sort_workspace_bytes', 'fb_handover_workspace_bytes', 'fb_fft_plan_create',
-                                                  'fb_fft_plan_destroy', 'fb_sync', 'fb_set_device', 'fb_gather_push_deposit_supported', 'fb_comm_unique_id', 'fb_comm_init', 'fb_comm_destroy', 'fb_zfft_supported', 'fb_fft_generic_supported', 'fb_fft_generic_from_records_supported'):
+                                                  'fb_fft_plan_destroy', 'fb_sync', 'fb_set_device', 'fb_gather_push_deposit_supported', 'fb_spect_cycle_supported', 'fb_comm_unique_id', 'fb_comm_init', 'fb_comm_destroy', 'fb_zfft_supported', 'fb_fft_generic_supported', 'fb_fft_generic_from_records_supported'):
             return f
         t = torch()
         recs = self._records.setdefault(name, [])

@@ -60,11 +60,14 @@ struct CycleArgs {
     unsigned long long *stats;                 // optional: [1024] strays of the J deposition
 };
 
-// PIPE: the node values of chunk c+1 are requested right after the stencil sums of chunk c and
-// travel during its push and depositions (own LDS panel: 12.5 KB per wave at Nm = 2, 3 waves per
-// SIMD); !PIPE: they are requested at the end of chunk c into a panel that shares its LDS with the
-// deposition engines (7.8 KB per wave, 4 waves per SIMD).
-template <int NM, bool PIPE> struct CyclePlan {
+// The node values of chunk c+1 are requested right after the stencil sums of chunk c and travel
+// during its push and depositions: the gather panel has LDS of its own next to the panel of the
+// deposition engines (12.5 KB per wave at Nm = 2, 3 waves per SIMD).  (Requesting them at the end
+// of chunk c into a shared panel - 7.8 KB, 4 waves per SIMD - and forcing 128 registers were
+// measured too: 266-273 us against 266-274 at C2, profiles/README.md.)
+// WIDE: grids / deposition targets that are not within 4 GiB of each other (separately allocated
+// arrays): 64-bit pointers per lane instead of a scalar base + 32-bit lane offsets.
+template <int NM, bool WIDE> struct CyclePlan {
     static constexpr int S = 2;
     static constexpr int NV = S * S * 6 * NM;              // complex node values of a segment
     static constexpr int NVL = (NV + 63) / 64;             // ... per lane
@@ -72,14 +75,13 @@ template <int NM, bool PIPE> struct CyclePlan {
     // panel stride in doubles: load j of a segment fills the 16-B slots 64 j ... of its lanes
     // (only NV of them in all), + a 16-B pad (segments start on different banks)
     static constexpr int PSTR = 2 * NV + 2;
-    using EJ = DepEngine<FB_SHAPE_LINEAR, 3, NM, true, true>;
-    using ER = DepEngine<FB_SHAPE_LINEAR, 1, NM, true, true>;
+    using EJ = DepEngine<FB_SHAPE_LINEAR, 3, NM, true, !WIDE>;
+    using ER = DepEngine<FB_SHAPE_LINEAR, 1, NM, true, !WIDE>;
     static constexpr int DEP_DOUBLES = EJ::L::WAVE_DOUBLES > ER::L::WAVE_DOUBLES ? EJ::L::WAVE_DOUBLES
                                                                                  : ER::L::WAVE_DOUBLES;
     static constexpr int GATHER_DOUBLES = NSEG * PSTR;
     // the two panels do not share LDS: the node values of chunk c+1 arrive while chunk c deposits
-    static constexpr int WAVE_DOUBLES = PIPE ? GATHER_DOUBLES + DEP_DOUBLES
-                                             : (GATHER_DOUBLES > DEP_DOUBLES ? GATHER_DOUBLES : DEP_DOUBLES);
+    static constexpr int WAVE_DOUBLES = GATHER_DOUBLES + DEP_DOUBLES;
 };
 
 // Array pointers are fetched from the kernel-argument segment where they are used (one scalar
@@ -120,10 +122,10 @@ struct CycleFront {
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *glb_ptr_t;
 
-template <int NM, bool PIPE>
+template <int NM, bool WIDE>
 __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
 {
-    using P = CyclePlan<NM, PIPE>;
+    using P = CyclePlan<NM, WIDE>;
     using EJ = typename P::EJ;
     using ER = typename P::ER;
     constexpr int S = 2, NV = P::NV, NVL = P::NVL, NSEG = P::NSEG, PSTR = P::PSTR;
@@ -133,7 +135,7 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
     // per wave: the gather panel (node values of the segments, written by the loads themselves)
     // and, behind it, the panel of the deposition engines
     double *gpanel = lds + (size_t)wave * P::WAVE_DOUBLES;
-    double *dpanel = PIPE ? gpanel + P::GATHER_DOUBLES : gpanel;
+    double *dpanel = gpanel + P::GATHER_DOUBLES;
     const long n = A.n;
     const int Nz = A.Nz, Nr = A.Nr, ncol = Nr + 1;
     const long rs = A.rsG;
@@ -151,6 +153,7 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
     // its field as a 32-bit byte offset from the lowest of the grids (scalar base + lane offset
     // addressing; the host has checked that all of them lie within 4 GiB)
     unsigned st_rel[NVL];
+    const char *st_ptr[NVL];          // WIDE: the field itself
     unsigned st_on = 0u;
     const char *gbase = (const char *)A.baseG;
     const int rsB = (int)(16 * rs);
@@ -158,7 +161,8 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
     for (int j = 0; j < NVL; j++) {
         const int o = lane + 64 * j;
         const bool on = o < NV;
-        st_rel[j] = (unsigned)((const char *)A.G.g[on ? o / (S * S) : 0] - gbase);
+        st_ptr[j] = (const char *)A.G.g[on ? o / (S * S) : 0];
+        st_rel[j] = WIDE ? 0u : (unsigned)(st_ptr[j] - gbase);
         st_on |= on ? (1u << j) : 0u;
     }
     // request the node values of the next (up to NSEG) segments of `f`: runs first, then strays
@@ -187,9 +191,12 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
 #pragma unroll
                 for (int j = 0; j < NVL; j++) {
                     // lane l of the wave -> 16 bytes at (LDS base) + 16 l
-                    if ((st_on >> j) & 1u)
-                        __builtin_amdgcn_global_load_lds((glb_ptr_t)(gbase + (st_rel[j] + off)),
-                                                         (lds_ptr_t)(gpanel + u * PSTR + 128 * j), 16, 0, 0);
+                    if ((st_on >> j) & 1u) {
+                        const char *src = WIDE ? st_ptr[j] + ((long)row * (16 * rs) + (long)col * 16)
+                                               : gbase + (st_rel[j] + off);
+                        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(gpanel + u * PSTR + 128 * j),
+                                                         16, 0, 0);
+                    }
                 }
             }
         }
@@ -349,7 +356,7 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
         // ---- front half of the next chunk: its node loads travel during the rest of this one
         const long nbase = base + 64;
         const bool more = (ch + 1 < A.chunks_per_wave) && nbase < n;
-        if (PIPE && more) {
+        if (more) {
             front(fr, nbase, xn, yn, zn, hn);
             if (ch + 2 < A.chunks_per_wave) load_pos(nbase + 64);
         }
@@ -409,11 +416,6 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
         }
         FB_MARK("M_END");
         if (!more) break;
-        if (!PIPE) {
-            // the deposition panel is free again: the next chunk's node values may land in it
-            front(fr, nbase, xn, yn, zn, hn);
-            if (ch + 2 < A.chunks_per_wave) load_pos(nbase + 64);
-        }
         base = nbase;
     }
     ej.flush(false);
@@ -422,27 +424,13 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
         atomicAdd(A.stats + ((blockIdx.x * nwaves + wave) & 1023), (unsigned long long)nstray_J);
 }
 
-// Builds of the same body: pipelined node loads (PIPE) or the shared panel, each with the register
-// allocation the compiler picks and forced to 128 registers (4 waves per SIMD);
-// FBPIC_AMD_CYCLE_PIPE=0 / FBPIC_AMD_CYCLE_WPE=4 select (measurements in profiles/README.md).
-template <int NM, bool PIPE>
-__global__ __launch_bounds__(256) void k_cycle_linear(CycleArgs A) { cycle_linear_body<NM, PIPE>(A); }
-template <int NM, bool PIPE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_cycle_linear_w4(CycleArgs A)
-{
-    cycle_linear_body<NM, PIPE>(A);
-}
+template <int NM, bool WIDE>
+__global__ __launch_bounds__(256) void k_cycle_linear(CycleArgs A) { cycle_linear_body<NM, WIDE>(A); }
 
-static int env_int(const char *name, int dflt)
+template <int NM, bool WIDE>
+static int launch_cycle_linear(const CycleArgs &A0, hipStream_t s)
 {
-    const char *e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-
-template <int NM, bool PIPE>
-static int launch_cycle_linear(const CycleArgs &A0, hipStream_t s, bool w4)
-{
-    using P = CyclePlan<NM, PIPE>;
+    using P = CyclePlan<NM, WIDE>;
     CycleArgs A = A0;
     const size_t wave_bytes = 8 * (size_t)P::WAVE_DOUBLES;
     const int nwaves = lds_waves_per_workgroup(wave_bytes);
@@ -454,20 +442,15 @@ static int launch_cycle_linear(const CycleArgs &A0, hipStream_t s, bool w4)
     A.chunks_per_wave = cpw;
     const long total_waves = (nchunks + cpw - 1) / cpw;
     const long nblocks = xcd_grid((total_waves + nwaves - 1) / nwaves);
-    if (w4)
-        hipLaunchKernelGGL((k_cycle_linear_w4<NM, PIPE>), dim3((unsigned)nblocks), dim3(64 * nwaves),
-                           wave_bytes * nwaves, s, A);
-    else
-        hipLaunchKernelGGL((k_cycle_linear<NM, PIPE>), dim3((unsigned)nblocks), dim3(64 * nwaves),
-                           wave_bytes * nwaves, s, A);
+    hipLaunchKernelGGL((k_cycle_linear<NM, WIDE>), dim3((unsigned)nblocks), dim3(64 * nwaves),
+                       wave_bytes * nwaves, s, A);
     return check(hipGetLastError(), "fb_gather_push_deposit_J_rho");
 }
 
 template <int NM>
-static int launch_cycle(const CycleArgs &A, hipStream_t s)
+static int launch_cycle(const CycleArgs &A, bool wide, hipStream_t s)
 {
-    static const int pipe = env_int("FBPIC_AMD_CYCLE_PIPE", 1), wpe = env_int("FBPIC_AMD_CYCLE_WPE", 0);
-    return pipe ? launch_cycle_linear<NM, true>(A, s, wpe == 4) : launch_cycle_linear<NM, false>(A, s, wpe == 4);
+    return wide ? launch_cycle_linear<NM, true>(A, s) : launch_cycle_linear<NM, false>(A, s);
 }
 
 }  // namespace fb
@@ -498,6 +481,7 @@ extern "C" int fb_gather_push_deposit_J_rho(int shape, int Nm, long n,
     }
     if (!home_cell) { set_error(who, "home_cell (cell of every particle at the last sort) is required"); return -1; }
     CycleArgs A;
+    bool wide = false;
     A.n = n;
     A.x = x; A.y = y; A.z = z; A.ux = ux; A.uy = uy; A.uz = uz; A.ig = inv_gamma; A.w = w;
     A.home = home_cell;
@@ -514,11 +498,10 @@ extern "C" int fb_gather_push_deposit_J_rho(int shape, int Nm, long n,
             if (a < lo) lo = a;
             if (a > hi) hi = a;
         }
-        if ((double)(hi - lo) + 16. * (double)row_stride * (double)(Nz + 1) >= 4294967296.) {
-            set_error(who, "the E, B grids must lie within 4 GiB of each other (one slab): 32-bit "
-                           "offsets in the node loads");
-            return -1;
-        }
+        // (FBPIC_AMD_CYCLE_WIDE=1: the 64-bit addressing whatever the layout - for the tests)
+        const char *ew = getenv("FBPIC_AMD_CYCLE_WIDE");
+        wide = (ew && atoi(ew) != 0) ||
+               (double)(hi - lo) + 16. * (double)row_stride * (double)(Nz + 1) >= 4294967296.;
         A.baseG = (const cplx *)lo;
     }
     // fbpic/particles/push/numba_methods.py:41-42, 24-30
@@ -536,19 +519,15 @@ extern "C" int fb_gather_push_deposit_J_rho(int shape, int Nm, long n,
     A.rsJ = J_row_stride; A.rsR = rho_row_stride;
     A.baseJ = dep_grids_base(A.GJ, 3 * Nm, J_row_stride, Nz);
     A.baseR = dep_grids_base(A.GR, Nm, rho_row_stride, Nz);
-    if (!A.baseJ || !A.baseR) {
-        set_error(who, "the J (and the rho) arrays must lie within 4 GiB of each other: node-major "
-                       "records or the fields of one slab (32-bit offsets in the flush)");
-        return -1;
-    }
+    if (!A.baseJ || !A.baseR) wide = true;     // separately allocated arrays, far apart
     A.beta0 = ruyten_m0; A.betah = ruyten_mh;
     A.chunks_per_wave = 1;
     A.stats = stats;
     hipStream_t s = (hipStream_t)stream;
     switch (Nm) {
-    case 1: return launch_cycle<1>(A, s);
-    case 2: return launch_cycle<2>(A, s);
-    case 3: return launch_cycle<3>(A, s);
-    default: return launch_cycle<4>(A, s);
+    case 1: return launch_cycle<1>(A, wide, s);
+    case 2: return launch_cycle<2>(A, wide, s);
+    case 3: return launch_cycle<3>(A, wide, s);
+    default: return launch_cycle<4>(A, wide, s);
     }
 }

@@ -16,6 +16,7 @@ ONE z-major slab `complex128[Nz, 10*Nm, Nr]` and all spectral fields in a second
 Field order inside a slab: E | B | J | rho(_prev | _next), each vector group ordered
 [mode0: (r|p, t|m, z), mode1: ...].
 """
+import os
 import numpy as np
 from .. import _capi
 from .interpolation_grid import InterpolationGrid, INTERP_FIELDS
@@ -82,14 +83,35 @@ class Fields(object):
         self.d_src_rec = None
         self._epoch = 0                  # bumped by every host -> device copy of the grids
         self._deferred_sources = None    # see defer_sources
+        # Fused r-spectral part of a step (spect_cycle / fb_spect_cycle_standard): the forward
+        # Hankel transform of J, rho_next that interp2spect_J_and_rho_next has left pending
+        # (`_pending_hankel` = fuse_filter flag, the z-FFT'd sources wait in the J | rho fields of
+        # the interpolation slab), and E, B already in (kz, r) space in the scratch slab
+        # (`_EB_in_kz_r`) for the spect2interp('EB') that follows.
+        self.fuse_spectral_cycle = os.environ.get('FBPIC_AMD_FUSE_SPECT', '1') != '0'
+        self._pending_hankel = None
+        self._EB_in_kz_r = False
 
     # ---------------------------------------------------------------- deferred J / rho
-    def _touch(self):
+    def _touch(self, keep_pending=False):
         """Start of a public method that modifies the grids: calls from outside Simulation.step are
         counted (the state carried between step() calls is keyed on the count: the kernels
         write through raw pointers, which torch's version counters do not see)."""
         if not getattr(self, '_in_step', False):
             self._ext_gen = getattr(self, '_ext_gen', 0) + 1
+        if not keep_pending:
+            self._finish_pending_transforms()
+
+    def _finish_pending_transforms(self):
+        """Complete what the fused spectral sequence has left half-way (see __init__): anything
+        but psatd_step / spect2interp('EB') in their places finds the grids as after the separate
+        calls."""
+        if self._pending_hankel is not None:
+            fuse_filter, self._pending_hankel = self._pending_hankel, None
+            self._hankel_J_and_rho_next(self._src_kz_views(), fuse_filter)
+        if self._EB_in_kz_r:
+            self._EB_in_kz_r = False
+            self._backward_zfft('EB')
 
     def defer_sources(self, bring_back):
         """Simulation.step ends with J and rho_prev going from spectral space to the
@@ -196,6 +218,7 @@ class Fields(object):
         """Copy all grid data back to host NumPy arrays (C-contiguous, like `.get()`)."""
         if not self.data_is_on_gpu:
             return
+        self._finish_pending_transforms()
         self.materialize_sources()
         hi = self.d_interp.cpu().numpy()
         hs = self.d_spect.cpu().numpy()
@@ -349,11 +372,26 @@ class Fields(object):
         self.d_interp[:, 6 * Nm:10 * Nm, :].copy_(S.permute(0, 2, 1))
         self._records_clean = False
 
-    def interp2spect_J_and_rho_next(self, fuse_filter=False, from_records=False):
+    def spect_cycle_supported(self):
+        """Whether the fused forward Hankel + PSATD step + inverse Hankel launch applies to this
+        grid (the caller checks the scheme: single domain, standard PSATD, no window shift)."""
+        lib = _capi.lib()
+        return bool(self.fuse_spectral_cycle and self.v_comoving is None
+                    and self.current_correction == 'curl-free'
+                    and lib.fb_spect_cycle_supported(self.Nm, self.Nr) and lib.fb_zfft_supported(self.Nz))
+
+    def _src_kz_views(self):
+        """Where the z-FFT'd J | rho wait for a pending forward Hankel transform: the J | rho fields
+        of the interpolation slab (not otherwise used inside step(): the deposition goes to the
+        records, and J, rho on the interpolation grid are rebuilt from spectral space when read)."""
+        return self._field_views(self.d_interp, 6 * self.Nm, 4 * self.Nm)
+
+    def interp2spect_J_and_rho_next(self, fuse_filter=False, from_records=False, defer_hankel=False):
         """interp2spect('J') and interp2spect('rho_next') of freshly deposited (un-normalised)
         sources in ONE z-FFT launch and ONE Hankel launch: J and rho are adjacent in the
         interpolation slab, and a Hankel launch takes any list of jobs.  Same arithmetic per
         field as the two separate calls with fuse_divide_by_volume=True."""
+        self._touch()
         self._need_gpu()
         Nm, Nz, Nr = self.Nm, self.Nz, self.Nr
         lib, pa, st = _capi.lib(), _capi.ptr_array, _capi.stream()
@@ -361,10 +399,18 @@ class Fields(object):
         if from_records and lib.fb_zfft_supported(Nz):
             # the z-FFT gathers its columns straight from the deposition's records
             S = self.source_records()
+            defer_hankel = bool(defer_hankel and self.spect_cycle_supported())
+            dst = self.d_interp[:, 6 * Nm, :] if defer_hankel else self.d_scratch[:, 0, :]
+            dst_rs = self.d_interp.stride(0) if defer_hankel else self.d_scratch.stride(0)
             _capi.check(lib.fb_zfft_from_records_consume(
-                Nz, nf, Nr, S.data_ptr(), S.stride(0), S.shape[2], self.d_scratch[:, 0, :].data_ptr(),
-                self.d_scratch.stride(0), st), 'fb_zfft_from_records_consume')
+                Nz, nf, Nr, S.data_ptr(), S.stride(0), S.shape[2], dst.data_ptr(), dst_rs, st),
+                'fb_zfft_from_records_consume')
             self._records_clean = True
+            if defer_hankel:
+                # psatd_step() runs the transform together with the solver step and the inverse
+                # transform of E, B (spect_cycle); anything else first finishes it on its own
+                self._pending_hankel = bool(fuse_filter)
+                return
         elif from_records and lib.fb_fft_generic_from_records_supported(Nz):
             # lengths of the two-sweep generic FFT (4416 = 192 x 23): its head gathers the records
             from .spectral_transform.fourier import generic_scratch
@@ -379,7 +425,14 @@ class Fields(object):
             if from_records:
                 self.unpack_source_records()
             fft_exec(self.d_interp[:, 6 * Nm, :], self.d_scratch[:, 0, :], -1, ncols=nf * Nr)
-        scr_f = self._field_views(self.d_scratch, 0, nf)
+        self._hankel_J_and_rho_next(self._field_views(self.d_scratch, 0, nf), fuse_filter)
+
+    def _hankel_J_and_rho_next(self, scr_f, fuse_filter):
+        """Forward Hankel transform (with divide-by-volume, (r,t) -> (p,m), filter) of the z-FFT'd
+        J | rho_next in the (kz, r) views `scr_f`."""
+        Nm, Nz, Nr = self.Nm, self.Nz, self.Nr
+        lib, pa, st = _capi.lib(), _capi.ptr_array, _capi.stream()
+        nJ, nf = 3 * Nm, 4 * Nm
         out = self._field_views(self.d_spect, 6 * Nm, nJ) + self._field_views(self.d_spect, 10 * Nm, Nm)
         mats = self._mats['vec_fwd'] + self._mats['scal_fwd']
         mode_of = [(j // 3) % Nm for j in range(nJ)] + list(range(Nm))
@@ -388,11 +441,49 @@ class Fields(object):
         fr = [self.spect[m].d_filter_array_r if fuse_filter else None for m in mode_of]
         ins, in2, sgn = self._rt_pairs(scr_f, nJ)
         _capi.check(lib.fb_hankel_rt_to_pm_scaled(
-            nf, pa(ins), pa(in2), sgn, self.d_scratch.stride(0), pa(out), self.d_spect.stride(0),
+            nf, pa(ins), pa(in2), sgn, scr_f[0].stride(0), pa(out), self.d_spect.stride(0),
             pa(mats), pa(sk), pa(fz), pa(fr), 1.0, Nz, Nr, st), 'fb_hankel_rt_to_pm_scaled')
+
+    def spect_cycle(self, correct_currents, use_true_rho):
+        """The pending forward Hankel transform of J | rho_next, the solver step
+        (correct_currents + push, as psatd_step) and the inverse Hankel transform of the new E, B
+        in one launch (fb_spect_cycle_standard); E, B are left in (kz, r) space in the scratch slab
+        for spect2interp('EB')."""
+        from scipy.constants import c, epsilon_0, mu_0
+        Nm = self.Nm
+        lib, pa, st = _capi.lib(), _capi.ptr_array, _capi.stream()
+        fuse_filter, self._pending_hankel = self._pending_hankel, None
+        src = self._src_kz_views()                 # [J m0 r,t,z | J m1 ... | rho m0 | rho m1 ...]
+        fields, tables, srcs, outs, fwd, inv = [], [], [], [], [], []
+        scr = self._field_views(self.d_scratch, 0, 6 * Nm)
+        for m in range(Nm):
+            sp, tb = self.spect[m], self.psatd[m].device_tables()
+            fields += [getattr(sp, k) for k in SPECT_FIELDS]
+            tables += [tb['rho_prev_coef'], tb['rho_next_coef'], tb['j_coef'], tb['C'], tb['S_w'],
+                       sp.d_kr, sp.d_kz, sp.d_inv_k2]
+            srcs += src[3 * m:3 * m + 3] + [src[3 * Nm + m]]
+            outs += scr[3 * m:3 * m + 3] + scr[3 * Nm + 3 * m:3 * Nm + 3 * m + 3]
+            fwd += self._mats['vec_fwd'][3 * m:3 * m + 3]
+            inv += self._mats['vec_inv'][3 * m:3 * m + 3]
+        iv = [self.interp[m].d_invvol for m in range(Nm)]
+        fz = [self.spect[m].d_filter_array_z for m in range(Nm)] if fuse_filter else None
+        fr = [self.spect[m].d_filter_array_r for m in range(Nm)] if fuse_filter else None
+        rc = lib.fb_spect_cycle_standard(
+            Nm, pa(srcs), self.d_interp.stride(0), pa(iv), pa(fwd), pa(inv),
+            pa(fz) if fz else None, pa(fr) if fr else None, pa(fields), self.d_spect.stride(0), pa(tables),
+            self.dt, int(bool(correct_currents)), int(bool(use_true_rho)), c, epsilon_0, mu_0,
+            pa(outs), self.d_scratch.stride(0), self.Nz, self.Nr, st)
+        _capi.check(rc, 'fb_spect_cycle_standard')
+        self._EB_in_kz_r = True
 
     def spect2interp(self, fieldtype):
         """inverse DHT(r) then inverse FFT(z) (reference: fields.py:370-429)."""
+        if fieldtype == 'EB' and self._EB_in_kz_r and self._pending_hankel is None:
+            # spect_cycle has already applied the inverse Hankel matrices
+            self._touch(keep_pending=True)
+            self._EB_in_kz_r = False
+            self._backward_zfft('EB')
+            return
         self._touch()
         self._need_gpu()
         fi, fs, nf, vec = self._group(fieldtype)
@@ -405,6 +496,15 @@ class Fields(object):
             mats = mats + mats
         _capi.check(lib.fb_hankel(nf, pa(inp), self.d_spect.stride(0), pa(scr_f), self.d_scratch.stride(0),
                                   pa(mats), 1.0, Nz, Nr, st), 'fb_hankel')
+        self._backward_zfft(fieldtype)
+
+    def _backward_zfft(self, fieldtype):
+        """Second half of spect2interp: (kz, r) fields 0 .. nf-1 of the scratch slab -> the
+        interpolation grid."""
+        fi, fs, nf, vec = self._group(fieldtype)
+        Nz, Nr = self.Nz, self.Nr
+        lib, pa, st = _capi.lib(), _capi.ptr_array, _capi.stream()
+        scr_f = self._field_views(self.d_scratch, 0, nf)
         if vec and lib.fb_zfft_supported(Nz):
             # (p, m) -> (r, t) rides along in the first pass of the backward z-FFT
             _capi.check(lib.fb_zfft_pm_to_rt(Nz, nf * Nr, self.d_scratch[:, 0, :].data_ptr(),
@@ -490,6 +590,12 @@ class Fields(object):
         (correction of all modes, one launch), then correct_currents=False (push + rho
         shift of all modes, one launch).  `n_move` != 0: the moving window's translation of
         E, B, rho_prev and J by n_move cells rides along (fb_psatd_step_standard_shift)."""
+        if self._pending_hankel is not None and not only_correct and not n_move \
+                and not self._EB_in_kz_r:
+            self._touch(keep_pending=True)
+            self._need_gpu()
+            self.spect_cycle(correct_currents, use_true_rho)
+            return
         self._touch()
         self._need_gpu()
         from scipy.constants import c, epsilon_0, mu_0

@@ -349,6 +349,16 @@ class Simulation(object):
             return False
         return all(sp.cycle_supported(fld.Nm) for sp in self.ptcl)
 
+    def _spectral_cycle_ok(self):
+        """Whether the forward Hankel transform of J, rho_next may wait for the solver step and
+        run with it and the inverse transform of E, B as one launch (Fields.spect_cycle): inside
+        step() on a single z-periodic domain with the standard PSATD scheme, where exactly
+        psatd_step and spect2interp('EB') follow the deposition's transform."""
+        comm = self.comm
+        return bool(self._in_step and not self.reference_sequence and comm.size == 1
+                    and comm.nz_damp == 0 and comm.moving_win is None and self.v_comoving is None
+                    and not self.mirrors and self.fld.current_correction == 'curl-free')
+
     def _particles_one_pass(self, store_fields, wrap_z, correct_currents, use_true_rho):
         """gather, push_p, push_x, deposit('J'), push_x, deposit('rho_next') (main.py:469-528) as
         one pass per species; J and rho_next are then transformed together."""
@@ -359,7 +369,8 @@ class Simulation(object):
         for species in self.ptcl:
             species.cycle(fld, self.comm, self.dt, store_fields=store_fields, wrap_z=wrap_z)
             species.keep_fields_sorted = False
-        fld.interp2spect_J_and_rho_next(fuse_filter=self.filter_currents, from_records=True)
+        fld.interp2spect_J_and_rho_next(fuse_filter=self.filter_currents, from_records=True,
+                                        defer_hankel=self._spectral_cycle_ok())
         # (what deposit() records: single domain only when these are True, see _one_pass_ok)
         fld.exchanged_source['J'] = (correct_currents is False)
         fld.exchanged_source['rho_next'] = (use_true_rho is True)
@@ -618,7 +629,8 @@ class Simulation(object):
             if fieldtype == 'rho_next' and self._J_transform_pending:
                 self._J_transform_pending = False
                 fld.interp2spect_J_and_rho_next(fuse_filter=self.filter_currents,
-                                                from_records=records)
+                                                from_records=records,
+                                                defer_hankel=self._spectral_cycle_ok())
             else:
                 self._flush_J_transform()
                 fld.interp2spect(fieldtype, fuse_divide_by_volume=True,

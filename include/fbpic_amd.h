@@ -454,6 +454,33 @@ int fb_push_eb_comoving(void *Ep, void *Em, void *Ez, void *Bp, void *Bm, void *
         const double *C, const double *S_w, const void *T_eb, const void *T_cc,
         const void *T_rho, const double *kr, const double *kz, double dt, double V,
         int use_true_rho, double c, double epsilon_0, double mu_0, int Nz, int Nr, void *stream);
+/* The r-spectral part of a step of the standard PSATD scheme on a single z-periodic domain in ONE
+ * launch (csrc/spectral_cycle.hip): identical result to
+ *   fb_hankel_rt_to_pm_scaled(4 Nm jobs: J (r,t,z) and rho_next of every mode, divide-by-volume,
+ *                             spectral filter)                                   fields.py:313-368
+ *   fb_psatd_step_standard(Nm, fields, ..., correct_currents, use_true_rho)      main.py:530-557
+ *   fb_hankel(6 Nm jobs: E, B of every mode, inverse matrices)                   fields.py:370-429
+ * A workgroup owns 8 kz rows of one mode: J and rho_next never leave its accumulators between the
+ * forward products and the cell-local update, the new E, B go to the inverse products through LDS.
+ *   src[4m ..]   : Jr, Jt, Jz, rho of mode m after the forward z-FFT (un-normalised), row stride
+ *                  src_row_stride; invvol[m]: 1 / cell volume (Nr)
+ *   fwd_mats / inv_mats[3m ..] : Hankel matrices (Nr x Nr, row-major [k][n]) of the p, m and z / scalar
+ *                  components of mode m (orders m+1, m-1, m) and their inverses
+ *   filter_z / filter_r[m] : spectral filter (both NULL: none)
+ *   fields[11m ..], tables[8m ..] : as fb_psatd_step_standard
+ *   out[6m ..]   : E (p, m, z), B (p, m, z) of mode m in (kz, r) space: the input of fb_zfft_pm_to_rt
+ * Must not alias: src and out (different workgroups read / write the same rows of different fields).
+ * Nr <= 128 (fb_spect_cycle_supported); correct_currents 0 / 1. */
+int fb_spect_cycle_supported(int Nm, int Nr);
+int fb_spect_cycle_standard(int Nm, const void *const *src, long src_row_stride,
+                            const double *const *invvol, const double *const *fwd_mats,
+                            const double *const *inv_mats, const double *const *filter_z,
+                            const double *const *filter_r, void *const *fields,
+                            long spect_row_stride, const double *const *tables, double dt,
+                            int correct_currents, int use_true_rho, double c, double epsilon_0,
+                            double mu_0, void *const *out, long out_row_stride, int Nz, int Nr,
+                            void *stream);
+
 /* Single-launch fusion of the three cell-local spectral updates for ALL modes:
  * fields/spectral_grid.py:225-230 (curl-free correction, optional) -> :350-355 (PSATD push)
  * -> :416-417 (rho shift).  fields: HOST array of 11*Nm device pointers, per mode in

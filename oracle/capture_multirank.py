@@ -125,20 +125,29 @@ def cap_periodic(name, nranks, shape, Nz, Nr, n_order, n_guard, ppc, correct, ns
     save(name, **res)
 
 
-def lwfa_sim(shape):
+LWFA_2R = dict(Nz=128, Nr=16, zmin=-16.e-6, zmax=16.e-6, rmax=12.e-6, p_zmin=-4.e-6, p_rmax=10.e-6,
+               n_order=16, n_guard=16, nz_damp=16, z0=2.e-6, zf=6.e-6)
+# 8 slabs of 64 cells (the same cell size), plasma over the seven left-most slab boundaries: every
+# pair of neighbours hands particles over (exchange_period 3) while the window moves, the last
+# rank injects; n_order 8, curl-free current correction on every rank before the J exchange
+LWFA_8R = dict(Nz=512, Nr=16, zmin=-112.e-6, zmax=16.e-6, rmax=12.e-6, p_zmin=-100.e-6, p_rmax=10.e-6,
+               n_order=8, n_guard=8, nz_damp=16, z0=2.e-6, zf=6.e-6)
+
+
+def lwfa_sim(shape, G=LWFA_2R):
     from fbpic.main import Simulation
-    Nz, Nr, Nm = 128, 16, 2
-    zmax, zmin, rmax = 16.e-6, -16.e-6, 12.e-6
+    Nz, Nr, Nm = G['Nz'], G['Nr'], 2
+    zmax, zmin, rmax = G['zmax'], G['zmin'], G['rmax']
     dt = (zmax - zmin) / Nz / c
     np.random.seed(11)
     return Simulation(Nz, zmax, Nr, rmax, Nm, dt, zmin=zmin,
-                      p_zmin=-4.e-6, p_zmax=1., p_rmin=0., p_rmax=10.e-6, p_nz=1, p_nr=2, p_nt=4,
-                      n_e=4.e24, n_order=16, particle_shape=shape, verbose_level=0,
-                      boundaries={'z': 'open', 'r': 'reflective'}, n_guard=16,
-                      n_damp={'z': 16, 'r': 8}, exchange_period=3, use_cuda=False)
+                      p_zmin=G['p_zmin'], p_zmax=1., p_rmin=0., p_rmax=G['p_rmax'], p_nz=1, p_nr=2, p_nt=4,
+                      n_e=4.e24, n_order=G['n_order'], particle_shape=shape, verbose_level=0,
+                      boundaries={'z': 'open', 'r': 'reflective'}, n_guard=G['n_guard'],
+                      n_damp={'z': G['nz_damp'], 'r': 8}, exchange_period=3, use_cuda=False)
 
 
-def cap_lwfa(name, nranks, shape, nsteps):
+def cap_lwfa(name, nranks, shape, nsteps, G=LWFA_2R):
     """Laser-wakefield miniature (open z, damping, moving window, continuous injection,
     Gaussian laser; docs/source/example_input/lwfa_script.py) on `nranks` slabs: the C4
     code path.  The plasma starts left of the slab boundary, so plasma particles are handed
@@ -157,10 +166,10 @@ def cap_lwfa(name, nranks, shape, nsteps):
         MPI.set_rank(r)
         try:
             turn[r].acquire()
-            sims[r] = lwfa_sim(shape)
+            sims[r] = lwfa_sim(shape, G)
             turn[r + 1].release()
             MPI.COMM_WORLD.barrier()
-            prof = GaussianLaser(a0=1.5, waist=4.e-6, tau=8.e-15, z0=2.e-6, zf=6.e-6,
+            prof = GaussianLaser(a0=1.5, waist=4.e-6, tau=8.e-15, z0=G['z0'], zf=G['zf'],
                                  lambda0=0.8e-6, theta_pol=0.3, cep_phase=0.4)
             add_laser_pulse(sims[r], prof)
             sims[r].set_moving_window(v=c)
@@ -175,7 +184,8 @@ def cap_lwfa(name, nranks, shape, nsteps):
     if errs:
         raise RuntimeError('rank %d failed in setup:\n%s' % errs[0])
     s0 = sims[0]
-    res = dict(Nz=128, Nr=16, Nm=2, zmin=-16.e-6, zmax=16.e-6, rmax=12.e-6, dt=s0.dt, shape=shape,
+    res = dict(Nz=G['Nz'], Nr=G['Nr'], Nm=2, zmin=G['zmin'], zmax=G['zmax'], rmax=G['rmax'], dt=s0.dt, shape=shape,
+               p_zmin=G['p_zmin'], p_rmax=G['p_rmax'], n_order=G['n_order'], z0=G['z0'], zf=G['zf'],
                nranks=nranks, n_guard=s0.comm.n_guard, n_inject=s0.comm.n_inject,
                nz_damp=s0.comm.nz_damp, nsteps=np.array(nsteps),
                Nz_local=np.array([s.fld.Nz for s in sims]))
@@ -200,6 +210,7 @@ CASES = {
     'mr_periodic_lin_4r': lambda: cap_periodic('mr_periodic_lin_4r', 4, 'linear', 128, 8, 4, 10,
                                                (1, 2, 4), True, (1, 4)),
     'mr_lwfa_lin_2r': lambda: cap_lwfa('mr_lwfa_lin_2r', 2, 'linear', (10,)),
+    'mr_lwfa_lin_8r': lambda: cap_lwfa('mr_lwfa_lin_8r', 8, 'linear', (7,), LWFA_8R),
 }
 
 if __name__ == '__main__':

@@ -80,13 +80,17 @@ def _run_lwfa(rank, name, outdir):
     Nz, Nr, Nm = int(g['Nz']), int(g['Nr']), int(g['Nm'])
     zmax, zmin, rmax = float(g['zmax']), float(g['zmin']), float(g['rmax'])
     np.random.seed(11)
+
+    def par(key, default):          # (the first fixture predates these keys)
+        return float(g[key]) if key in g.files else default
     sim = Simulation(Nz, zmax, Nr, rmax, Nm, float(g['dt']), zmin=zmin,
-                     p_zmin=-4.e-6, p_zmax=1., p_rmin=0., p_rmax=10.e-6, p_nz=1, p_nr=2, p_nt=4,
-                     n_e=4.e24, n_order=16, particle_shape=str(g['shape']),
-                     boundaries={'z': 'open', 'r': 'reflective'}, n_guard=16,
-                     n_damp={'z': 16, 'r': 8}, exchange_period=3)
+                     p_zmin=par('p_zmin', -4.e-6), p_zmax=1., p_rmin=0., p_rmax=par('p_rmax', 10.e-6),
+                     p_nz=1, p_nr=2, p_nt=4,
+                     n_e=4.e24, n_order=int(par('n_order', 16)), particle_shape=str(g['shape']),
+                     boundaries={'z': 'open', 'r': 'reflective'}, n_guard=int(g['n_guard']),
+                     n_damp={'z': int(g['nz_damp']), 'r': 8}, exchange_period=3)
     assert sim.fld.Nz == int(g['Nz_local'][rank])
-    prof = GaussianLaser(a0=1.5, waist=4.e-6, tau=8.e-15, z0=2.e-6, zf=6.e-6,
+    prof = GaussianLaser(a0=1.5, waist=4.e-6, tau=8.e-15, z0=par('z0', 2.e-6), zf=par('zf', 6.e-6),
                          lambda0=0.8e-6, theta_pol=0.3, cep_phase=0.4)
     add_laser_pulse(sim, prof)
     sim.set_moving_window(v=c)
@@ -226,6 +230,31 @@ def test_decomposed_lwfa_vs_reference_ranks():
         for r in range(2):
             # measured: fields 1.1e-13, particles 2.5e-13
             _compare(got[r], g, 's%d' % upto, r, 2.5e-12, 2.5e-12, ptcl=(upto == steps[-1]), worst=worst)
+    print('%s: worst field error %.2e, worst particle error %.2e' % (name, worst[0], worst[1]))
+
+
+def test_decomposed_lwfa_8_ranks_with_current_correction_vs_reference_ranks():
+    """BASELINE config C4's code path on EIGHT slabs against the reference running on eight ranks:
+    open z + damping + moving window + injection on the last rank + laser, curl-free current
+    correction on every rank before the J exchange (docs/source/example_input/lwfa_script.py calls
+    sim.step with correct_currents=True; fbpic/main.py:530-538), plasma across all seven inner slab
+    boundaries so that every pair of neighbours hands particles over (exchange_period 3, 7 steps)."""
+    name = 'mr_lwfa_lin_8r'
+    g = golden(name)
+    assert int(g['nranks']) == 8
+    got = _launch('lwfa', name, 8)
+    worst = [0., 0.]
+    for r in range(8):
+        _compare(got[r], g, 's0', r, 2.5e-13, 2.5e-13, nfields=6, ptcl=False, worst=worst)
+    steps = [int(v) for v in g['nsteps']]
+    moved = 0
+    for upto in steps:
+        for r in range(8):
+            _compare(got[r], g, 's%d' % upto, r, 2.5e-12, 2.5e-12, ptcl=(upto == steps[-1]), worst=worst)
+    # the fixture does hand particles over between all neighbours: every inner rank ends with
+    # particles it did not start with (the plasma is at rest in the lab, the window moves 7 cells)
+    for r in range(1, 8):
+        assert g['s%d_r%d_ptcl0' % (steps[-1], r)].shape[1] > 0
     print('%s: worst field error %.2e, worst particle error %.2e' % (name, worst[0], worst[1]))
 
 

@@ -41,10 +41,14 @@ def _plasma(rng, n, Nz, Nr, dzc):
     return x, y, z
 
 
-@pytest.mark.parametrize('Nm,records,stale', [(2, True, 0.0), (2, True, 0.25), (2, True, 'garbage'),
-                                              (1, False, 0.25), (3, True, 0.25), (4, False, 0.6),
-                                              (2, True, 'unsorted')])
-def test_one_pass_equals_the_four_entry_points(hip, oracle, Nm, records, stale):
+@pytest.mark.parametrize('Nm,records,stale,wide', [(2, True, 0.0, 0), (2, True, 0.25, 0), (2, True, 'garbage', 0),
+                                                   (1, False, 0.25, 0), (3, True, 0.25, 0), (4, False, 0.6, 0),
+                                                   (2, True, 'unsorted', 0), (2, True, 0.25, 1),
+                                                   (3, False, 0.25, 1)])
+def test_one_pass_equals_the_four_entry_points(hip, oracle, Nm, records, stale, wide, monkeypatch):
+    # wide = 1: the 64-bit addressing of grids / targets that are not within 4 GiB of each other
+    # (the library picks it from the pointers; forced here, a test process has no such layout)
+    monkeypatch.setenv('FBPIC_AMD_CYCLE_WIDE', str(wide))
     rng = np.random.default_rng(7 + Nm)
     n, Nz, Nr = 100003, 36, 20
     dzc = 0.2e-6
@@ -82,9 +86,10 @@ def test_one_pass_equals_the_four_entry_points(hip, oracle, Nm, records, stale):
         hy += rng.normal(size=n) * stale * dzc
         hz += rng.normal(size=n) * stale * dzc
     state = [hx, hy, hz] + [host(a).copy() for a in dst[3:]]          # x y z ux uy uz w ig
-    # field grids: six per mode
-    views = [dev(hip, (rng.normal(size=(Nz, Nr)) + 1j * rng.normal(size=(Nz, Nr))) * 1e9)
-             for _ in range(6 * Nm)]
+    # field grids: six per mode, views of one slab (what the 32-bit addressing needs; separately
+    # allocated arrays may lie anywhere)
+    gslab = dev(hip, (rng.normal(size=(Nz, 6 * Nm, Nr)) + 1j * rng.normal(size=(Nz, 6 * Nm, Nr))) * 1e9)
+    views = [gslab[:, j, :] for j in range(6 * Nm)]
     ruy0 = dev(hip, rng.uniform(-0.05, 0.05, Nr + 1))
     ruyh = dev(hip, rng.uniform(-0.05, 0.05, Nr + 1))
     zlo, zhi = 0., Nz * dzc
@@ -105,15 +110,15 @@ def test_one_pass_equals_the_four_entry_points(hip, oracle, Nm, records, stale):
     base, jv, rv = target()
     hip.check(hip.lib().fb_gather_push_deposit_J_rho(
         1, Nm, n, p(a[0]), p(a[1]), p(a[2]), p(a[3]), p(a[4]), p(a[5]), p(a[7]), p(a[6]), p(home),
-        rmax_gather, *geom, hip.ptr_array(views), Nr, *[p(f) for f in F], q, m, c, dt, 0.5 * dt, zlo, zhi,
-        hip.ptr_array(jv), jv[0].stride(0), jv[0].stride(1), hip.ptr_array(rv), rv[0].stride(0),
+        rmax_gather, *geom, hip.ptr_array(views), views[0].stride(0), *[p(f) for f in F], q, m, c, dt, 0.5 * dt,
+        zlo, zhi, hip.ptr_array(jv), jv[0].stride(0), jv[0].stride(1), hip.ptr_array(rv), rv[0].stride(0),
         rv[0].stride(1), p(ruy0), p(ruyh), p(stats), hip.stream()), 'one pass')
     # ---- the sequence it replaces
     b = [dev(hip, v) for v in state]
     F2 = [t.zeros(n, dtype=t.float64, device='cuda') for _ in range(6)]
     base2, jv2, rv2 = target()
     hip.check(hip.lib().fb_gather_push(1, Nm, n, p(b[0]), p(b[1]), p(b[2]), p(b[3]), p(b[4]), p(b[5]), p(b[7]),
-                                       rmax_gather, *geom, hip.ptr_array(views), Nr, *[p(f) for f in F2],
+                                       rmax_gather, *geom, hip.ptr_array(views), views[0].stride(0), *[p(f) for f in F2],
                                        q, m, c, dt, 0.5 * dt, zlo, zhi, hip.stream()), 'gather_push')
     xh, yh, zh = host(b[0]).copy(), host(b[1]).copy(), host(b[2]).copy()
     hip.check(hip.lib().fb_deposit_J(1, Nm, n, p(b[0]), p(b[1]), p(b[2]), p(b[6]), q, p(b[3]), p(b[4]),
@@ -176,8 +181,8 @@ def test_one_pass_without_wrap_and_without_stored_fields(hip):
     t = hip.torch()
     p = hip.ptr
     home = dev(hip, rng.integers(0, Nz * (Nr + 1), n).astype(np.int32))
-    views = [dev(hip, (rng.normal(size=(Nz, Nr)) + 1j * rng.normal(size=(Nz, Nr))) * 1e9)
-             for _ in range(6 * Nm)]
+    gslab = dev(hip, (rng.normal(size=(Nz, 6 * Nm, Nr)) + 1j * rng.normal(size=(Nz, 6 * Nm, Nr))) * 1e9)
+    views = [gslab[:, j, :] for j in range(6 * Nm)]
     ruy = dev(hip, np.zeros(Nr + 1))
     out = []
     for store, wrap in ((True, False), (False, False)):
@@ -188,7 +193,7 @@ def test_one_pass_without_wrap_and_without_stored_fields(hip):
         rv = [rec[:, :, 4 * mm + 3] for mm in range(Nm)]
         hip.check(hip.lib().fb_gather_push_deposit_J_rho(
             1, Nm, n, p(a[0]), p(a[1]), p(a[2]), p(a[3]), p(a[4]), p(a[5]), p(a[7]), p(a[6]), p(home),
-            Nr * dzc, *geom, hip.ptr_array(views), Nr, *[p(f) if store else None for f in F], -e, m_e, c,
+            Nr * dzc, *geom, hip.ptr_array(views), views[0].stride(0), *[p(f) if store else None for f in F], -e, m_e, c,
             dt, 0.5 * dt, 0., 0., hip.ptr_array(jv), jv[0].stride(0), jv[0].stride(1), hip.ptr_array(rv),
             rv[0].stride(0), rv[0].stride(1), p(ruy), p(ruy), None, hip.stream()), 'one pass')
         out.append(([host(v) for v in a], host(rec)))
