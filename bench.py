@@ -71,6 +71,9 @@ WORK = {
     'fb_zfft': ('hbm', lambda a: 32.0 * a[0] * a[1]),
     'fb_shift_periodic': ('hbm', lambda a: 8.0 * a[0]),
     'fb_hankel': ('mfma', lambda a: 4.0 * a[7] * a[8] * a[8] * a[0]),
+    # forward products of J (p, m, z) + rho and inverse products of E, B (p, m, z) of every mode:
+    # 10 Nm transforms in one launch (the cell-local solver step between them is not counted)
+    'fb_spect_cycle_standard': ('mfma', lambda a: 4.0 * a[19] * a[20] * a[20] * 10 * a[0]),
     # (p | m) formed in the operand load: same GEMM work per job
     'fb_hankel_rt_to_pm_scaled': ('mfma', lambda a: 4.0 * a[12] * a[13] * a[13] * a[0]),
     'fb_hankel_scaled': ('mfma', lambda a: 4.0 * a[10] * a[11] * a[11] * a[0]),
@@ -287,6 +290,11 @@ def main():
     # decomposed run: the warm-up also covers the first particle hand-over between the ranks
     # (every `exchange_period` steps; its first execution pays one-time start-up costs, ~3 ms)
     warm = args.warmup if world == 1 else max(args.warmup, sim.comm.exchange_period + 2)
+    # The ceilings of this box (fp64 triad, 4096^3 dgemm) are measured BEFORE the timed region:
+    # ~1 s of full load brings the GPU out of its idle clock state, which a 5-step warm-up (2 ms)
+    # does not - extra.repeat_ms_per_step of round-3-style lines fell 0.48 -> 0.45 -> 0.44 ms over
+    # three back-to-back timed calls of the same kernels.
+    ceil = measured_ceilings(torch) if (rank == 0 or world > 1) and not args.no_kernel_timing else None
     with GpuMemoryManager(sim):
         sim.step(warm)
         barrier()
@@ -340,7 +348,6 @@ def main():
                                         'sorting_two_pass': sum(s.cycle_sorts for s in sim.ptcl),
                                         'sort_period': sim.ptcl[0].cycle_sort_period if sim.ptcl else None}}
     if kern:
-        ceil = measured_ceilings(torch)
         out['roofline'], out['kernels'] = roofline(kern, ceil, {'C2': True, 'C5': 'c5'}.get(config_name(args, ppc, world), False))
         out['measured_ceilings'] = ceil
     if cpu_base:
@@ -486,7 +493,7 @@ def roofline(kern, ceil=None, profiled_workload=True):
                 roof['gather_push'].update(pmc_traffic(n, '' if profiled_workload is True else profiled_workload))
             break
     # the Hankel GEMM (the MFMA-bound kernel of the path) next to it: all launches together
-    hk = [table[n] for n in table if n.startswith('fb_hankel') and 'achieved' in table[n]]
+    hk = [table[n] for n in table if n.startswith(('fb_hankel', 'fb_spect_cycle')) and 'achieved' in table[n]]
     if hk:
         tot_ms = sum(e['total_ms'] for e in hk)
         flops = sum(e['achieved'] * 1e12 * e['total_ms'] * 1e-3 for e in hk)

@@ -53,6 +53,8 @@ _SIGNATURES = {
     'fb_gather_push_deposit_J_rho': (I, [I, I, L, P, P, P, P, P, P, P, P, P, D, D, D, I, D, D, I, _PP, L,
                                          P, P, P, P, P, P, D, D, D, D, D, D, D, _PP, L, L, _PP, L, L,
                                          P, P, P, P]),
+    'fb_gather_push_rank_next_home': (I, [I, I, L, P, P, P, P, P, P, P, P, D, D, D, I, D, D, I, _PP, L,
+                                          P, P, P, P, P, P, D, D, D, D, D, D, D, I, P, Z, I, P]),
     'fb_permute': (I, [L, P, I, _PP, _PP, P]),
     'fb_handover_pack': (I, [L, P, I, _PP, P, L, P]),
     'fb_handover_move': (I, [L, P, P, I, _PP, P]),

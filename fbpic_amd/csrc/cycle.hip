@@ -58,6 +58,9 @@ struct CycleArgs {
     const double *beta0, *betah;               // Ruyten coefficients, mode 0 / modes >= 1
     int chunks_per_wave;
     unsigned long long *stats;                 // optional: [1024] strays of the J deposition
+    // RANK mode (fb_gather_push_rank_next_home): no deposition; x is left at x(n+1/2) and the cell
+    // of x(n+1) and the particle's rank in it go to the counting-sort workspace
+    int *rk_cell, *rk_rank, *rk_count;
 };
 
 // The node values of chunk c+1 are requested right after the stencil sums of chunk c and travel
@@ -122,7 +125,7 @@ struct CycleFront {
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *glb_ptr_t;
 
-template <int NM, bool WIDE>
+template <int NM, bool WIDE, bool RANK>
 __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
 {
     using P = CyclePlan<NM, WIDE>;
@@ -134,15 +137,21 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // per wave: the gather panel (node values of the segments, written by the loads themselves)
     // and, behind it, the panel of the deposition engines
-    double *gpanel = lds + (size_t)wave * P::WAVE_DOUBLES;
+    // (RANK mode has no deposition panel)
+    double *gpanel = lds + (size_t)wave * (RANK ? P::GATHER_DOUBLES : P::WAVE_DOUBLES);
     double *dpanel = gpanel + P::GATHER_DOUBLES;
     const long n = A.n;
     const int Nz = A.Nz, Nr = A.Nr, ncol = Nr + 1;
     const long rs = A.rsG;
     EJ ej;
     ER er;
-    ej.init(dpanel, lane, A.GJ, A.rsJ, 0, Nz, Nr, A.baseJ);
-    er.init(dpanel, lane, A.GR, A.rsR, 0, Nz, Nr, A.baseR);
+    if constexpr (!RANK) {
+        ej.init(dpanel, lane, A.GJ, A.rsJ, 0, Nz, Nr, A.baseJ);
+        er.init(dpanel, lane, A.GR, A.rsR, 0, Nz, Nr, A.baseR);
+    }
+    // RANK: (cell, rank) of the previous chunk, written once the rank atomic has returned
+    long pd_i = -1;
+    int pd_cell = 0, pd_base = 0, pd_run0 = 0;
     const DepGeom geom = {A.invdz, A.zmin, Nz, A.invdr, A.rmin, Nr};
     const bool store_eb = A.Ex != nullptr;
     const unsigned long long le = (2ull << lane) - 1ull, lt = (1ull << lane) - 1ull;
@@ -380,7 +389,48 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
                 KP(double, Bx)[i] = bx; KP(double, By)[i] = by; KP(double, Bz)[i] = bz;
             }
             KP(double, ux)[i] = pux; KP(double, uy)[i] = puy; KP(double, uz)[i] = puz; KP(double, ig)[i] = pig;
-            KP(double, x)[i] = x1; KP(double, y)[i] = y1; KP(double, z)[i] = z1;
+            if constexpr (RANK) {
+                // the second half push belongs to the sort pass that follows (which deposits J
+                // from x(n+1/2) first): the position is left at x(n+1/2)
+                KP(double, x)[i] = xh; KP(double, y)[i] = yh; KP(double, z)[i] = zh;
+            } else {
+                KP(double, x)[i] = x1; KP(double, y)[i] = y1; KP(double, z)[i] = z1;
+            }
+        }
+        if constexpr (RANK) {
+            // cell of x(n+1) as in k_cell_index / k_bin_rank and the rank inside it: one atomic per
+            // run of equal destination cells (gather_finish of particles.hip); the pair is written
+            // one chunk later, when the atomic's value has long arrived
+            {
+                const int b_ = __shfl(pd_base, pd_run0);
+                if (pd_i >= 0) { A.rk_cell[pd_i] = pd_cell; A.rk_rank[pd_i] = b_ + (lane - pd_run0); }
+            }
+            int rk_c = -1;
+            if (act) {
+                const double rq = sqrt(x1 * x1 + y1 * y1);
+                int ir_upper = (int)ceil(A.invdr * (rq - A.rmin) - 0.5);
+                int iz_upper = (int)ceil(A.invdz * (z1 - A.zmin) - 0.5);
+                if (ir_upper > Nr) ir_upper = Nr;
+                if (iz_upper < 0) iz_upper += Nz;
+                else if (iz_upper > Nz - 1) iz_upper -= Nz;
+                rk_c = ir_upper + iz_upper * (Nr + 1);
+            }
+            const int prev = __shfl_up(rk_c, 1);
+            const bool rk_start = act && (lane == 0 || rk_c != prev);
+            const unsigned long long rstarts = __ballot(rk_start);
+            const unsigned long long below = rstarts & le;
+            const int rk_run0 = 63 - __builtin_clzll(below | 1ull);
+            int rk_base = 0;
+            if (rk_start) {
+                const unsigned long long rest = (lane + 1 < 64) ? (rstarts >> (lane + 1)) : 0ull;
+                const int len = rest ? (__builtin_ctzll(rest) + 1) : (cnt - lane);   // (active lanes: a prefix)
+                rk_base = atomicAdd(A.rk_count + rk_c, len);
+            }
+            pd_i = act ? base + lane : -1;
+            pd_cell = rk_c; pd_base = rk_base; pd_run0 = rk_run0;
+            if (!more) break;
+            base = nbase;
+            continue;
         }
         const double wj = act ? A.q * pw : 0.;       // a lane without a particle deposits nothing
 
@@ -418,21 +468,26 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
         if (!more) break;
         base = nbase;
     }
+    if constexpr (RANK) {
+        const int b_ = __shfl(pd_base, pd_run0);
+        if (pd_i >= 0) { A.rk_cell[pd_i] = pd_cell; A.rk_rank[pd_i] = b_ + (lane - pd_run0); }
+        return;
+    }
     ej.flush(false);
     er.flush(false);
     if (A.stats && lane == 0)
         atomicAdd(A.stats + ((blockIdx.x * nwaves + wave) & 1023), (unsigned long long)nstray_J);
 }
 
-template <int NM, bool WIDE>
-__global__ __launch_bounds__(256) void k_cycle_linear(CycleArgs A) { cycle_linear_body<NM, WIDE>(A); }
+template <int NM, bool WIDE, bool RANK>
+__global__ __launch_bounds__(256) void k_cycle_linear(CycleArgs A) { cycle_linear_body<NM, WIDE, RANK>(A); }
 
-template <int NM, bool WIDE>
+template <int NM, bool WIDE, bool RANK = false>
 static int launch_cycle_linear(const CycleArgs &A0, hipStream_t s)
 {
     using P = CyclePlan<NM, WIDE>;
     CycleArgs A = A0;
-    const size_t wave_bytes = 8 * (size_t)P::WAVE_DOUBLES;
+    const size_t wave_bytes = 8 * (size_t)(RANK ? P::GATHER_DOUBLES : P::WAVE_DOUBLES);
     const int nwaves = lds_waves_per_workgroup(wave_bytes);
     const long nchunks = (A.n + 63) / 64;
     const long target_waves = 256L * 64;
@@ -442,14 +497,15 @@ static int launch_cycle_linear(const CycleArgs &A0, hipStream_t s)
     A.chunks_per_wave = cpw;
     const long total_waves = (nchunks + cpw - 1) / cpw;
     const long nblocks = xcd_grid((total_waves + nwaves - 1) / nwaves);
-    hipLaunchKernelGGL((k_cycle_linear<NM, WIDE>), dim3((unsigned)nblocks), dim3(64 * nwaves),
+    hipLaunchKernelGGL((k_cycle_linear<NM, WIDE, RANK>), dim3((unsigned)nblocks), dim3(64 * nwaves),
                        wave_bytes * nwaves, s, A);
-    return check(hipGetLastError(), "fb_gather_push_deposit_J_rho");
+    return check(hipGetLastError(), RANK ? "fb_gather_push_rank_next_home" : "fb_gather_push_deposit_J_rho");
 }
 
 template <int NM>
-static int launch_cycle(const CycleArgs &A, bool wide, hipStream_t s)
+static int launch_cycle(const CycleArgs &A, bool wide, bool rank, hipStream_t s)
 {
+    if (rank) return wide ? launch_cycle_linear<NM, true, true>(A, s) : launch_cycle_linear<NM, false, true>(A, s);
     return wide ? launch_cycle_linear<NM, true>(A, s) : launch_cycle_linear<NM, false>(A, s);
 }
 
@@ -462,7 +518,7 @@ extern "C" int fb_gather_push_deposit_supported(int shape, int Nm)
     return shape == FB_SHAPE_LINEAR && Nm >= 1 && Nm <= 4;
 }
 
-extern "C" int fb_gather_push_deposit_J_rho(int shape, int Nm, long n,
+static int cycle_entry(const char *who, bool rank, int shape, int Nm, long n,
         double *x, double *y, double *z, double *ux, double *uy, double *uz, double *inv_gamma,
         const double *w, const int *home_cell,
         double rmax_gather, double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
@@ -471,9 +527,9 @@ extern "C" int fb_gather_push_deposit_J_rho(int shape, int Nm, long n,
         double q, double m, double c, double dt, double dt_x, double wrap_zmin, double wrap_zmax,
         void *const *J, long J_row_stride, long J_col_stride,
         void *const *rho, long rho_row_stride, long rho_col_stride,
-        const double *ruyten_m0, const double *ruyten_mh, unsigned long long *stats, void *stream)
+        const double *ruyten_m0, const double *ruyten_mh, unsigned long long *stats,
+        int *rk_cell, int *rk_rank, int *rk_count, void *stream)
 {
-    const char *who = "fb_gather_push_deposit_J_rho";
     if (n <= 0) return 0;
     if (!fb_gather_push_deposit_supported(shape, Nm)) {
         set_error(who, "linear shape, Nm = 1..4 (use the separate entry points otherwise)");
@@ -513,21 +569,67 @@ extern "C" int fb_gather_push_deposit_J_rho(int shape, int Nm, long n,
     A.GJ.cs = J_col_stride > 0 ? J_col_stride : 1;
     A.GR.cs = rho_col_stride > 0 ? rho_col_stride : 1;
     for (int i = 0; i < 3 * FB_MAX_MODES; i++) {
-        A.GJ.g[i] = i < 3 * Nm ? (cplx *)J[i] : nullptr;
-        A.GR.g[i] = i < Nm ? (cplx *)rho[i] : nullptr;
+        A.GJ.g[i] = (!rank && i < 3 * Nm) ? (cplx *)J[i] : nullptr;
+        A.GR.g[i] = (!rank && i < Nm) ? (cplx *)rho[i] : nullptr;
     }
     A.rsJ = J_row_stride; A.rsR = rho_row_stride;
-    A.baseJ = dep_grids_base(A.GJ, 3 * Nm, J_row_stride, Nz);
-    A.baseR = dep_grids_base(A.GR, Nm, rho_row_stride, Nz);
-    if (!A.baseJ || !A.baseR) wide = true;     // separately allocated arrays, far apart
+    A.baseJ = A.baseR = nullptr;
+    if (!rank) {
+        A.baseJ = dep_grids_base(A.GJ, 3 * Nm, J_row_stride, Nz);
+        A.baseR = dep_grids_base(A.GR, Nm, rho_row_stride, Nz);
+        if (!A.baseJ || !A.baseR) wide = true;     // separately allocated arrays, far apart
+    }
     A.beta0 = ruyten_m0; A.betah = ruyten_mh;
     A.chunks_per_wave = 1;
     A.stats = stats;
+    A.rk_cell = rk_cell; A.rk_rank = rk_rank; A.rk_count = rk_count;
     hipStream_t s = (hipStream_t)stream;
     switch (Nm) {
-    case 1: return launch_cycle<1>(A, wide, s);
-    case 2: return launch_cycle<2>(A, wide, s);
-    case 3: return launch_cycle<3>(A, wide, s);
-    default: return launch_cycle<4>(A, wide, s);
+    case 1: return launch_cycle<1>(A, wide, rank, s);
+    case 2: return launch_cycle<2>(A, wide, rank, s);
+    case 3: return launch_cycle<3>(A, wide, rank, s);
+    default: return launch_cycle<4>(A, wide, rank, s);
     }
+}
+
+extern "C" int fb_gather_push_deposit_J_rho(int shape, int Nm, long n,
+        double *x, double *y, double *z, double *ux, double *uy, double *uz, double *inv_gamma,
+        const double *w, const int *home_cell,
+        double rmax_gather, double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
+        const void *const *grids, long row_stride,
+        double *Ex, double *Ey, double *Ez, double *Bx, double *By, double *Bz,
+        double q, double m, double c, double dt, double dt_x, double wrap_zmin, double wrap_zmax,
+        void *const *J, long J_row_stride, long J_col_stride,
+        void *const *rho, long rho_row_stride, long rho_col_stride,
+        const double *ruyten_m0, const double *ruyten_mh, unsigned long long *stats, void *stream)
+{
+    return cycle_entry("fb_gather_push_deposit_J_rho", false, shape, Nm, n, x, y, z, ux, uy, uz, inv_gamma, w,
+                       home_cell, rmax_gather, invdz, zmin, Nz, invdr, rmin, Nr, grids, row_stride, Ex, Ey, Ez,
+                       Bx, By, Bz, q, m, c, dt, dt_x, wrap_zmin, wrap_zmax, J, J_row_stride, J_col_stride, rho,
+                       rho_row_stride, rho_col_stride, ruyten_m0, ruyten_mh, stats, nullptr, nullptr, nullptr,
+                       stream);
+}
+
+extern "C" int fb_gather_push_rank_next_home(int shape, int Nm, long n,
+        double *x, double *y, double *z, double *ux, double *uy, double *uz, double *inv_gamma,
+        const int *home_cell,
+        double rmax_gather, double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
+        const void *const *grids, long row_stride,
+        double *Ex, double *Ey, double *Ez, double *Bx, double *By, double *Bz,
+        double q, double m, double c, double dt, double dt_x, double wrap_zmin, double wrap_zmax,
+        int ncell, void *sort_workspace, size_t workspace_bytes, int counts_are_zero, void *stream)
+{
+    const char *who = "fb_gather_push_rank_next_home";
+    hipStream_t s = (hipStream_t)stream;
+    if (ncell != Nz * (Nr + 1)) { set_error(who, "ncell != Nz*(Nr+1)"); return -1; }
+    if (workspace_bytes < fb_bin_sort_workspace_bytes(n, ncell)) { set_error(who, "workspace too small"); return -1; }
+    const BinSortWs W = carve_bin_sort_ws(sort_workspace, workspace_bytes, n, ncell);
+    if (!counts_are_zero) {
+        hipError_t e = hipMemsetAsync(W.count, 0, (size_t)ncell * sizeof(int), s);
+        if (e != hipSuccess) return check(e, who);
+    }
+    return cycle_entry(who, true, shape, Nm, n, x, y, z, ux, uy, uz, inv_gamma, x /* w: not read */, home_cell,
+                       rmax_gather, invdz, zmin, Nz, invdr, rmin, Nr, grids, row_stride, Ex, Ey, Ez, Bx, By, Bz,
+                       q, m, c, dt, dt_x, wrap_zmin, wrap_zmax, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr,
+                       nullptr, W.cell, W.rank, W.count, stream);
 }

@@ -479,6 +479,20 @@ class Particles(object):
             _capi.check(rc, 'fb_gather_push_rank_next_range')
             if part == 'inside':
                 return                      # the book-keeping below belongs to the completed pass
+        elif ranked and self._home_valid and rank_next == (dt_x, 1., 1., 1.) \
+                and self._home_geom == (g0.zmin, g0.invdz, g0.Nz, g0.rmin, g0.invdr, g0.Nr) \
+                and _capi.lib().fb_gather_push_deposit_supported(_SHAPE[self.particle_shape], Nm):
+            # arrays sorted some steps ago (a sorting iteration of the one-pass cycle): segments
+            # from the home cells, which a stale order does not fragment
+            rc = _capi.lib().fb_gather_push_rank_next_home(
+                _SHAPE[self.particle_shape], Nm, self.Ntot, p(self.x), p(self.y), p(self.z),
+                p(self.ux), p(self.uy), p(self.uz), p(self.inv_gamma), p(self.cell_idx),
+                comm.get_rmax(with_damp=False), g0.invdz, g0.zmin, g0.Nz, g0.invdr, g0.rmin, g0.Nr,
+                _capi.ptr_array(views), _capi.row_stride(views[0]), *eb,
+                self.q, self.m, c, self.dt, dt_x, wz[0], wz[1], self.prefix_sum.shape[0],
+                p(self._sort_ws), self._sort_ws.shape[0], int(self._counts_clean), _capi.stream())
+            self._counts_clean = False
+            _capi.check(rc, 'fb_gather_push_rank_next_home')
         elif ranked:
             rc = _capi.lib().fb_gather_push_rank_next(
                 _SHAPE[self.particle_shape], Nm, self.Ntot, p(self.x), p(self.y), p(self.z),

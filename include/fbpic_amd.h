@@ -379,6 +379,23 @@ int fb_gather_push_deposit_J_rho(int shape, int Nm, long n,
                                  const double *ruyten_m0, const double *ruyten_mh,
                                  unsigned long long *stats, void *stream);
 
+/* fb_gather_push_rank_next for arrays that were cell-sorted some steps ago (csrc/cycle.hip): the same
+ * results - momenta, x(n+1/2), and cell + rank of x(n+1) in `sort_workspace`, ranks of a cell in a
+ * different order - with the segments of the gather taken from `home_cell` (runs of equal home cells,
+ * particles that have left theirs staged on their own: see fb_gather_push_deposit_J_rho) instead of
+ * from runs of equal cells, which a stale order fragments (C2, 3 steps after a sort: 184 -> ~125 us).
+ * dt_x, the following push: dt_push = dt_x, x_push = y_push = z_push = 1 (the half steps of
+ * Simulation.step).  Linear shape, Nm <= 4. */
+int fb_gather_push_rank_next_home(int shape, int Nm, long n,
+                                  double *x, double *y, double *z, double *ux, double *uy, double *uz,
+                                  double *inv_gamma, const int *home_cell, double rmax_gather,
+                                  double invdz, double zmin, int Nz, double invdr, double rmin, int Nr,
+                                  const void *const *grids, long row_stride,
+                                  double *Ex, double *Ey, double *Ez, double *Bx, double *By, double *Bz,
+                                  double q, double m, double c, double dt, double dt_x,
+                                  double wrap_zmin, double wrap_zmax, int ncell, void *sort_workspace,
+                                  size_t workspace_bytes, int counts_are_zero, void *stream);
+
 /* fb_deposit_J that also prepares the counting sort which Simulation.step runs after the
  * next push_x (main.py:515-528: deposit J, push_x(dt/2), re-sort for deposit rho_next): for
  * every particle, the cell of the position pushed by (dt_push, x_push, y_push, z_push) and

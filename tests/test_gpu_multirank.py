@@ -91,6 +91,9 @@ def test_two_ranks_reproduce_single_domain(shape, correct, tol, nranks):
     tests/test_gpu_multirank_golden.py, 2e-11.)"""
     import helpers
     outdir = tempfile.mkdtemp()
+    import atexit
+    import shutil
+    atexit.register(shutil.rmtree, outdir, ignore_errors=True)      # (/tmp is RAM on the test boxes)
     ctx = mp.get_context('spawn')
     for world in (1, nranks):
         port = _free_port()
@@ -196,6 +199,9 @@ def test_two_rank_checkpoint_restart():
     grids (guard cells included) and particles, with the curl-free correction on."""
     import helpers
     outdir = tempfile.mkdtemp()
+    import atexit
+    import shutil
+    atexit.register(shutil.rmtree, outdir, ignore_errors=True)      # (/tmp is RAM on the test boxes)
     ctx = mp.get_context('spawn')
     port = _free_port()
     q = ctx.Queue()

@@ -247,3 +247,75 @@ def test_step_one_pass_equals_two_pass_and_oracle(hip, oracle, Nm, period):
     # identify particles by (w, x): unique to rounding in this lattice + thermal state
     pe = max(np.abs(pa[i] - pb[i]).max() / max(np.abs(pb[i]).max(), 1e-300) for i in range(8))
     achieved(None, pe, 5e-11, 'particles vs two-pass s7')
+
+
+@pytest.mark.parametrize('Nm,stale', [(2, 0.3), (3, 'garbage')])
+def test_gather_push_rank_next_home_equals_gather_push_rank_next(hip, oracle, Nm, stale):
+    """fb_gather_push_rank_next_home (segments from the home cells) == fb_gather_push_rank_next:
+    bit-identical particle arrays and stored E, B, the same cell for every particle, and ranks
+    that give the same counting sort (prefix sums and the multiset of every cell)."""
+    rng = np.random.default_rng(77)
+    n, Nz, Nr = 50021, 30, 16
+    dzc = 0.2e-6
+    geom = (1. / dzc, 0., Nz, 1. / dzc, 0., Nr)
+    x, y, z = _plasma(rng, n, Nz, Nr, dzc)
+    ux, uy, uz = (rng.normal(size=n) * 0.3 for _ in range(3))
+    ig = 1. / np.sqrt(1. + ux**2 + uy**2 + uz**2)
+    w = rng.uniform(0.5, 1.5, n)
+    dt = dzc / c
+    t = hip.torch()
+    p = hip.ptr
+    ncell = Nz * (Nr + 1)
+    src = [dev(hip, a) for a in (x, y, z, ux, uy, uz, w, ig)]
+    dst = [t.empty_like(a) for a in src]
+    home = t.empty(n, dtype=t.int32, device='cuda')
+    pre = t.empty(ncell, dtype=t.int32, device='cuda')
+    nb = int(hip.lib().fb_bin_sort_workspace_bytes(n, ncell))
+    ws = t.empty(nb, dtype=t.uint8, device='cuda')
+    hip.check(hip.lib().fb_bin_sort_particles(n, ncell, p(src[0]), p(src[1]), p(src[2]), *geom, 8,
+                                              hip.ptr_array(src), hip.ptr_array(dst), p(home), None, p(pre),
+                                              p(ws), nb, hip.stream()), 'bin_sort')
+    state = [host(a).copy() for a in dst]
+    if stale == 'garbage':
+        home.copy_(t.from_numpy(rng.integers(-2**31, 2**31 - 1, n).astype(np.int32)))
+    else:
+        for k in range(3):
+            state[k] += rng.normal(size=n) * stale * dzc
+    gslab = dev(hip, (rng.normal(size=(Nz, 6 * Nm, Nr)) + 1j * rng.normal(size=(Nz, 6 * Nm, Nr))) * 1e9)
+    views = [gslab[:, j, :] for j in range(6 * Nm)]
+    zlo, zhi = 0., Nz * dzc
+    res = []
+    for homed in (True, False):
+        a = [dev(hip, v) for v in state]
+        F = [t.zeros(n, dtype=t.float64, device='cuda') for _ in range(6)]
+        work = t.empty(nb, dtype=t.uint8, device='cuda')
+        if homed:
+            hip.check(hip.lib().fb_gather_push_rank_next_home(
+                1, Nm, n, p(a[0]), p(a[1]), p(a[2]), p(a[3]), p(a[4]), p(a[5]), p(a[7]), p(home), Nr * dzc, *geom,
+                hip.ptr_array(views), views[0].stride(0), *[p(f) for f in F], -e, m_e, c, dt, 0.5 * dt, zlo, zhi,
+                ncell, p(work), nb, 0, hip.stream()), 'rank_next_home')
+        else:
+            hip.check(hip.lib().fb_gather_push_rank_next(
+                1, Nm, n, p(a[0]), p(a[1]), p(a[2]), p(a[3]), p(a[4]), p(a[5]), p(a[7]), Nr * dzc, *geom,
+                hip.ptr_array(views), views[0].stride(0), *[p(f) for f in F], -e, m_e, c, dt, 0.5 * dt, zlo, zhi,
+                0.5 * dt, 1., 1., 1., ncell, p(work), nb, 0, hip.stream()), 'rank_next')
+        parts = [host(v).copy() for v in a + F]
+        # the counting sort that consumes the ranks
+        out = [t.empty_like(v) for v in a]
+        ci = t.empty(n, dtype=t.int32, device='cuda')
+        si = t.empty(n, dtype=t.int32, device='cuda')
+        pr = t.empty(ncell, dtype=t.int32, device='cuda')
+        hip.check(hip.lib().fb_push_x_bin_sort_particles(
+            n, ncell, p(a[0]), p(a[1]), p(a[2]), p(a[3]), p(a[4]), p(a[5]), p(a[7]), c, 0.5 * dt, 1., 1., 1.,
+            *geom, 8, hip.ptr_array(a), hip.ptr_array(out), p(ci), p(si), p(pr), p(work), nb, 1, hip.stream()),
+            'push_x_bin_sort')
+        res.append((parts, [host(v) for v in out], host(ci), host(si), host(pr)))
+    (pa, oa, cia, sia, pra), (pb, ob, cib, sib, prb) = res
+    for k, (u, v) in enumerate(zip(pa, pb)):
+        assert np.array_equal(u, v), k
+    assert np.array_equal(pra, prb) and np.array_equal(cia, cib)
+    assert np.array_equal(np.sort(sia), np.arange(n, dtype=np.int32))
+    o1 = np.lexsort((oa[2], oa[1], oa[0], cia))
+    o2 = np.lexsort((ob[2], ob[1], ob[0], cib))
+    for u, v in zip(oa, ob):
+        assert np.array_equal(u[o1], v[o2])
