@@ -133,6 +133,7 @@ def bench_c3(args, torch, world, rank):
     warm = max(args.warmup, sim.comm.exchange_period + 2)
     with GpuMemoryManager(sim):
         sim.step(warm)
+        finish_outputs(sim)     # the warm-up is the timed call's twin (first-use FFT plans included)
         torch.cuda.synchronize()
         n0 = sum(s.Ntot for s in sim.ptcl)
         t0 = time.perf_counter()
@@ -294,9 +295,13 @@ def main():
     # ~1 s of full load brings the GPU out of its idle clock state, which a 5-step warm-up (2 ms)
     # does not - extra.repeat_ms_per_step of round-3-style lines fell 0.48 -> 0.45 -> 0.44 ms over
     # three back-to-back timed calls of the same kernels.
-    ceil = measured_ceilings(torch) if (rank == 0 or world > 1) and not args.no_kernel_timing else None
     with GpuMemoryManager(sim):
+        # (inside the block: after the host -> device copies, nothing but the warm-up steps between
+        # this load and the timed region)
+        _sysfs_card()           # (resolves the device's sysfs directory once: a rocm-smi process)
+        ceil = measured_ceilings(torch) if (rank == 0 or world > 1) and not args.no_kernel_timing else None
         sim.step(warm)
+        finish_outputs(sim)     # the warm-up is the timed call's twin
         barrier()
         clocks_before = device_clocks()
         t0 = time.perf_counter()
@@ -304,6 +309,7 @@ def main():
         finish_outputs(sim)
         barrier()
         dt_wall = time.perf_counter() - t0
+        clocks_first = device_clocks()
         # the same timed call twice more, back to back (the headline stays the first): tells a slow
         # box / clock state from a slow build when the line moves between runs of unchanged kernels
         repeats = [1e3 * dt_wall / args.steps]
@@ -343,7 +349,8 @@ def main():
                    'sequence': 'reference' if args.reference_sequence else 'fused'},
     }
     out['extra'] = {'repeat_ms_per_step': repeats, 'device': device_identity(torch),
-                    'clocks_before': clocks_before, 'clocks_after': clocks_after,
+                    'clocks_before': clocks_before, 'clocks_after_headline_call': clocks_first,
+                    'clocks_after': clocks_after,
                     'particle_passes': {'one_pass': sum(s.cycle_passes for s in sim.ptcl),
                                         'sorting_two_pass': sum(s.cycle_sorts for s in sim.ptcl),
                                         'sort_period': sim.ptcl[0].cycle_sort_period if sim.ptcl else None}}
@@ -366,17 +373,42 @@ def _rocm_smi(*flags):
         return {}
 
 
+_SYSFS_CARD = []
+
+
+def _sysfs_card():
+    """/sys/class/drm/cardN/device of the GPU rocm-smi calls card0 (matched by unique id: the host's
+    other GPUs are visible in sysfs too); None when it cannot be resolved."""
+    if not _SYSFS_CARD:
+        import glob
+        uid = str(_rocm_smi('--showuniqueid').get('Unique ID', '')).lower().removeprefix('0x')
+        found = None
+        for d in glob.glob('/sys/class/drm/card*/device'):
+            try:
+                u = open(d + '/unique_id').read().strip().lower().removeprefix('0x')
+            except OSError:
+                continue
+            if uid and u == uid:
+                found = d
+        _SYSFS_CARD.append(found)
+    return _SYSFS_CARD[0]
+
+
 def device_clocks():
-    """sclk / mclk as rocm-smi reports them at this moment (between timed regions: an idle GPU
-    reads its idle state, so both ends of the timed calls are recorded)."""
-    d = _rocm_smi('--showclocks')
+    """Current sclk / mclk (MHz) from the starred line of pp_dpm_sclk / pp_dpm_mclk in sysfs: a file
+    read, so it can sit right behind a timed call without leaving the GPU idle (a rocm-smi process
+    in that place costs the next call its clock state). {} when sysfs is not reachable."""
+    d = _sysfs_card()
     out = {}
-    for k, v in d.items():
-        kl = k.lower()
-        if 'sclk' in kl and 'level' in kl:
-            out['sclk'] = v
-        elif 'mclk' in kl and 'level' in kl:
-            out['mclk'] = v
+    if d is None:
+        return out
+    for name in ('sclk', 'mclk'):
+        try:
+            for line in open('%s/pp_dpm_%s' % (d, name)):
+                if '*' in line:
+                    out[name + '_MHz'] = int(''.join(ch for ch in line.split(':')[1] if ch.isdigit()))
+        except (OSError, ValueError, IndexError):
+            pass
     return out
 
 
