@@ -105,6 +105,14 @@ __device__ __forceinline__ T *karg_ptr(int byte_offset)
 #else
 #define FB_MARK(x)
 #endif
+// s_waitcnt vmcnt(0) as an INSTRUCTION the compiler sees (an asm statement would leave its wait-count
+// bookkeeping believing the loads - also those into LDS - are still pending: it then waits again,
+// with vmcnt(0), in front of the first use, i.e. for whatever stores and atomics were issued since)
+__device__ __forceinline__ void fb_wait_vm()
+{
+    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0), expcnt and lgkmcnt untouched (gfx9 encoding)
+    asm volatile("" ::: "memory");
+}
 #define KP(T, field) karg_ptr<T>((int)__builtin_offsetof(CycleArgs, field))
 
 // Front half of a chunk: what can be done as soon as the positions are there - the keys of the
@@ -267,18 +275,37 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
     const long chunk0 = (xcd_block_id() * nwaves + wave) * A.chunks_per_wave;
     long base = chunk0 * 64;
     if (base >= n) return;
-    // software pipeline: positions and home cell two chunks ahead, node values one chunk ahead
-    double xn, yn, zn;
+    // Software pipeline.  Every wait of this kernel for vector memory is ONE s_waitcnt vmcnt(0) per
+    // chunk, placed where nothing recent is outstanding: behind the staging of J of chunk c.  By then
+    //   * the node values of chunk c+1 (requested after the stencil sums of chunk c),
+    //   * the positions / home cells of chunk c+2 and the momenta of chunk c+1 (requested at the top
+    //     of chunk c)
+    // have been travelling for the gather sums, the front half, the push and the staging, and the
+    // stores and atomics of chunk c are issued only AFTER it (they are waited for a chunk later).
+    // (The counter is shared by loads, stores and atomics and counts in order: a vmcnt(0) in front
+    // of the stencil sums - where it stood first - also waited for the rho atomics issued just
+    // before it and for the momenta requested just before it.)
+    double xn, yn, zn;                 // positions / home cell of the next chunk
     int hn;
-    auto load_pos = [&](long b) {
+    double xq = 0., yq = 0., zq = 0.;  // ... of the one after it
+    int hq = 0;
+    double mux, muy, muz, mig;         // momenta, 1/gamma of the next chunk
+    auto load_pos = [&](long b, double &x_, double &y_, double &z_, int &h_) {
         const long i = min(b + lane, n - 1);
-        xn = KP(const double, x)[i]; yn = KP(const double, y)[i]; zn = KP(const double, z)[i];
-        hn = KP(const int, home)[i];
+        x_ = KP(const double, x)[i]; y_ = KP(const double, y)[i]; z_ = KP(const double, z)[i];
+        h_ = KP(const int, home)[i];
     };
-    load_pos(base);
+    auto load_mom = [&](long b) {
+        const long i = min(b + lane, n - 1);
+        mux = KP(const double, ux)[i]; muy = KP(const double, uy)[i]; muz = KP(const double, uz)[i];
+        mig = KP(const double, ig)[i];
+    };
+    load_pos(base, xn, yn, zn, hn);
+    load_mom(base);
     CycleFront fr;
     front(fr, base, xn, yn, zn, hn);
-    if (A.chunks_per_wave > 1) load_pos(base + 64);
+    if (A.chunks_per_wave > 1) load_pos(base + 64, xn, yn, zn, hn);
+    fb_wait_vm();
     unsigned int nstray_J = 0;
     for (int ch = 0; ch < A.chunks_per_wave; ch++) {
         const long i = min(base + lane, n - 1);
@@ -289,10 +316,17 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
         const unsigned long long runstarts = fr.runstarts;
         const bool inside = (fr.insidem >> lane) & 1ull;
         FB_MARK("M_TOP");
-        // momenta and weight of this chunk: in flight during the stencil phase
-        double pux = KP(const double, ux)[i], puy = KP(const double, uy)[i], puz = KP(const double, uz)[i];
-        double pig = KP(const double, ig)[i];
-        const double pw = KP(const double, w)[i];
+        const long nbase = base + 64;
+        const bool more = (ch + 1 < A.chunks_per_wave) && nbase < n;
+        // momenta of this chunk (requested a chunk ago); its weights (first read behind the wait), the
+        // momenta of the next chunk and the positions of the one after it leave now
+        double pux = mux, puy = muy, puz = muz, pig = mig;
+        double pw = 0.;
+        if constexpr (!RANK) pw = KP(const double, w)[i];
+        if (more) {
+            load_mom(nbase);
+            if (ch + 2 < A.chunks_per_wave) load_pos(nbase + 64, xq, yq, zq, hq);
+        }
         // ---- gather: shape factors (threading_methods.py:108-117), cos, sin
         double cs, sn, Sz[S], Sr[S];
         bool axis;
@@ -324,9 +358,11 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
         for (int s0 = 0; s0 < nseg; s0 += NSEG) {
             const int ns = min(NSEG, nseg - s0);
             // more segments than one round holds (a badly out-of-date order): requested here
-            if (s0 > 0) request(fr, ns);
-            // the node values requested one iteration ago (or just now) have landed
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (the first round was requested a chunk ago and has landed: see the pipeline above)
+            if (s0 > 0) {
+                request(fr, ns);
+                fb_wait_vm();
+            }
             wave_lds_release();
             if (inside && myseg >= s0 && myseg < s0 + ns) {
                 const double *Pp = (const double *)__builtin_assume_aligned(gpanel + (size_t)(myseg - s0) * PSTR, 16);
@@ -363,11 +399,8 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
         }
         FB_MARK("M_FRONT");
         // ---- front half of the next chunk: its node loads travel during the rest of this one
-        const long nbase = base + 64;
-        const bool more = (ch + 1 < A.chunks_per_wave) && nbase < n;
         if (more) {
             front(fr, nbase, xn, yn, zn, hn);
-            if (ch + 2 < A.chunks_per_wave) load_pos(nbase + 64);
         }
 
         FB_MARK("M_VAY");
@@ -383,21 +416,27 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
         const double x1 = xh + A.chdt * pig * 1. * pux;
         const double y1 = yh + A.chdt * pig * 1. * puy;
         const double z1 = zh + A.chdt * pig * 1. * puz;
-        if (act) {
-            if (store_eb) {
-                KP(double, Ex)[i] = ex; KP(double, Ey)[i] = ey; KP(double, Ez)[i] = ez;
-                KP(double, Bx)[i] = bx; KP(double, By)[i] = by; KP(double, Bz)[i] = bz;
+        // the chunk's one wait for vector memory (see the pipeline above), then its stores
+        auto wait_and_store = [&]() {
+            fb_wait_vm();
+            xn = xq; yn = yq; zn = zq; hn = hq;
+            if (act) {
+                if (store_eb) {
+                    KP(double, Ex)[i] = ex; KP(double, Ey)[i] = ey; KP(double, Ez)[i] = ez;
+                    KP(double, Bx)[i] = bx; KP(double, By)[i] = by; KP(double, Bz)[i] = bz;
+                }
+                KP(double, ux)[i] = pux; KP(double, uy)[i] = puy; KP(double, uz)[i] = puz; KP(double, ig)[i] = pig;
+                if constexpr (RANK) {
+                    // the second half push belongs to the sort pass that follows (which deposits J
+                    // from x(n+1/2) first): the position is left at x(n+1/2)
+                    KP(double, x)[i] = xh; KP(double, y)[i] = yh; KP(double, z)[i] = zh;
+                } else {
+                    KP(double, x)[i] = x1; KP(double, y)[i] = y1; KP(double, z)[i] = z1;
+                }
             }
-            KP(double, ux)[i] = pux; KP(double, uy)[i] = puy; KP(double, uz)[i] = puz; KP(double, ig)[i] = pig;
-            if constexpr (RANK) {
-                // the second half push belongs to the sort pass that follows (which deposits J
-                // from x(n+1/2) first): the position is left at x(n+1/2)
-                KP(double, x)[i] = xh; KP(double, y)[i] = yh; KP(double, z)[i] = zh;
-            } else {
-                KP(double, x)[i] = x1; KP(double, y)[i] = y1; KP(double, z)[i] = z1;
-            }
-        }
+        };
         if constexpr (RANK) {
+            wait_and_store();
             // cell of x(n+1) as in k_cell_index / k_bin_rank and the rank inside it: one atomic per
             // run of equal destination cells (gather_finish of particles.hip); the pair is written
             // one chunk later, when the atomic's value has long arrived
@@ -437,8 +476,13 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
         FB_MARK("M_JSTAGE");
         // ---- J from x(n+1/2)
         int dkz, dkr, dnb;
-        ej.stage(true, xh, yh, zh, wj, pux, puy, puz, pig, A.c_light, geom, KP(const double, beta0),
-                 KP(const double, betah), dkz, dkr, dnb);
+        // (Ruyten coefficients of both depositions: requested here, so that no staging waits for a
+        // load - i.e. for the atomics issued before it)
+        const int irJ = ej.ruyten_index(xh, yh, geom), irR = er.ruyten_index(x1, y1, geom);
+        const double bJ0 = KP(const double, beta0)[irJ], bJh = KP(const double, betah)[irJ];
+        const double bR0 = KP(const double, beta0)[irR], bRh = KP(const double, betah)[irR];
+        wait_and_store();
+        ej.stage_with(true, xh, yh, zh, wj, pux, puy, puz, pig, A.c_light, geom, bJ0, bJh, dkz, dkr, dnb);
         {
             const bool home = act && dkz == hkz && dkr == hkr && dnb == hnb;
             const unsigned long long hm = __ballot(home), sm = __ballot(act && !home);
@@ -452,8 +496,7 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
         }
         FB_MARK("M_RSTAGE");
         // ---- rho from x(n+1)
-        er.stage(true, x1, y1, z1, wj, 0., 0., 0., 0., 0., geom, KP(const double, beta0), KP(const double, betah),
-                 dkz, dkr, dnb);
+        er.stage_with(true, x1, y1, z1, wj, 0., 0., 0., 0., 0., geom, bR0, bRh, dkz, dkr, dnb);
         {
             const bool home = act && dkz == hkz && dkr == hkr && dnb == hnb;
             const unsigned long long hm = __ballot(home), sm = __ballot(act && !home);
@@ -494,6 +537,7 @@ static int launch_cycle_linear(const CycleArgs &A0, hipStream_t s)
     int cpw = (int)((nchunks + target_waves - 1) / target_waves);
     if (cpw < 1) cpw = 1;
     if (cpw > 64) cpw = 64;
+    if (const char *e = getenv("FBPIC_AMD_CYCLE_CPW")) cpw = atoi(e) > 0 ? atoi(e) : cpw;
     A.chunks_per_wave = cpw;
     const long total_waves = (nchunks + cpw - 1) / cpw;
     const long nblocks = xcd_grid((total_waves + nwaves - 1) / nwaves);

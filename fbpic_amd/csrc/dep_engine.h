@@ -439,6 +439,26 @@ struct DepEngine {
             const double *__restrict__ beta0, const double *__restrict__ betah,
             int &my_kz, int &my_kr, int &my_nb)
     {
+        double b0 = 0., bh = 0.;
+        if (act) {
+            const int ir_ruy = ruyten_index(xj, yj, g);
+            if constexpr (NEED_W0) b0 = beta0[ir_ruy];
+            if constexpr (NEED_WH) bh = betah[ir_ruy];
+        }
+        stage_with(act, xj, yj, zj, wj, ux, uy, uz, ig, c_light, g, b0, bh, my_kz, my_kr, my_nb);
+    }
+    // index of the particle's Ruyten coefficient (the one stage() reads): a kernel may fetch the
+    // coefficients early and pass them to stage_with, so that the staging itself waits for no load
+    __device__ __forceinline__ int ruyten_index(double xj, double yj, const DepGeom &g) const
+    {
+        const double rj = sqrt(xj * xj + yj * yj);
+        const double r_cell = g.invdr * (rj - g.rmin) - 0.5;
+        return min((int)ceil(r_cell), Nr);
+    }
+    __device__ __forceinline__ void stage_with(bool act, double xj, double yj, double zj, double wj,
+            double ux, double uy, double uz, double ig, double c_light, const DepGeom &g,
+            double beta0_v, double betah_v, int &my_kz, int &my_kr, int &my_nb)
+    {
         my_kz = DEP_NOKEY; my_kr = DEP_NOKEY; my_nb = 0;
         if (act) {
             const double rj = sqrt(xj * xj + yj * yj);
@@ -485,11 +505,10 @@ struct DepEngine {
             // lowest node of the stencil (unfolded)
             if constexpr (SHAPE == FB_SHAPE_LINEAR) { my_kr = min(icr - 1, Nr); my_kz = icz - 1; }
             else { my_kr = min(icr, Nr) - 2; my_kz = icz - 2; }
-            const int ir_ruy = min(icr, Nr);
             double Sz[S], Sr0[S], Srh[S];
             shape_z<SHAPE>(z_cell, Sz);
-            if constexpr (NEED_W0) shape_r<SHAPE>(r_cell, beta0[ir_ruy], Sr0);
-            if constexpr (NEED_WH) shape_r<SHAPE>(r_cell, betah[ir_ruy], Srh);
+            if constexpr (NEED_W0) shape_r<SHAPE>(r_cell, beta0_v, Sr0);
+            if constexpr (NEED_WH) shape_r<SHAPE>(r_cell, betah_v, Srh);
 #pragma unroll
             for (int j = 0; j < S; j++) {
                 Wl[j * DEP_PAD + lane] = Sz[j];

@@ -46,5 +46,22 @@ def pmc(db, out):
             w.writerow([short(n), cn, c, '%.3f' % v, '%.2f' % (d / 1e3)])
 
 
+def pmcseq(db, out, pattern='k_cycle_linear'):
+    """Counter values per dispatch, in dispatch order, of the kernels whose name holds `pattern`."""
+    cur = sqlite3.connect(db).cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info('counters_collection')").fetchall()]
+    key = next((c for c in ('dispatch_id', 'start', 'id') if c in cols), 'rowid')
+    rows = cur.execute('select %s, kernel_name, counter_name, value from counters_collection '
+                       'where kernel_name like ? order by %s' % (key, key), ('%' + pattern + '%',)).fetchall()
+    with open(out, 'w', newline='') as f:
+        w = csv.writer(f)
+        w.writerow(['dispatch', 'kernel', 'counter', 'value'])
+        for k, n, cn, v in rows:
+            w.writerow([k, short(n)[:60], cn, '%.0f' % v])
+
+
 if __name__ == '__main__':
+    if sys.argv[1] == 'pmcseq':
+        pmcseq(*sys.argv[2:])
+        sys.exit(0)
     {'stats': stats, 'pmc': pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])

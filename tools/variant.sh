@@ -1,11 +1,15 @@
-# usage: bash tools/variant.sh <name> <file.hip> "<extra -D flags>"  -> fbpic_amd/csrc/libfbpic_amd_<name>.so
+# usage: bash tools/variant.sh <name> <file.hip> "<extra flags>"  -> fbpic_amd/csrc/variants/libfbpic_amd_<name>.so
 # (developer A/B builds: one object recompiled with extra flags, linked with the current others)
 set -e
-cd fbpic_amd/csrc
+cd /root/repo/fbpic_amd/csrc
+mkdir -p variants
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Wno-unused-result -Wno-pass-failed -I../../include"
-/opt/rocm/bin/hipcc $F $3 -c $2 -o /tmp/var_$1.o 2>/dev/null
+EXTRA=""
+[ "$2" = "cycle.hip" ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1"
+/opt/rocm/bin/hipcc $F $EXTRA $3 -c $2 -o /tmp/var_$1.o
 OBJS=""
-for o in runtime comm particles sort handover deposit fields fft zfft hankel; do
-  if [ "$o.hip" = "$2" ]; then OBJS="$OBJS /tmp/var_$1.o"; else OBJS="$OBJS $o.o"; fi
+for s in $(grep '^SRCS' Makefile | cut -d= -f2); do
+  o=${s%.hip}
+  if [ "$s" = "$2" ]; then OBJS="$OBJS /tmp/var_$1.o"; else OBJS="$OBJS $o.o"; fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libfbpic_amd_$1.so $OBJS -L/opt/rocm/lib -lrocfft -Wl,-rpath,/opt/rocm/lib
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/libfbpic_amd_$1.so $OBJS -L/opt/rocm/lib -lrocfft -ldl -Wl,-rpath,/opt/rocm/lib
