@@ -22,6 +22,7 @@
 // Rows i of a tile = (kz_local, re | im): i = kz_local + 8 ri, so that a lane's four D registers
 // are re / im of the SAME two cells (kz_local = l >> 4 and + 4): complete complex numbers in one
 // lane, no shuffle before the cell-local update.
+#include <cstdlib>
 #include "fb_common.h"
 #ifndef SC_KNOCK
 #define SC_KNOCK 0                 // timing experiments (tools/sc_time.py): 1 .. 4 drop one part each
@@ -70,31 +71,36 @@ struct SpectCycleArgs {
 // the load it has just issued - measured: 130 us instead of 70 for the whole kernel): rows beyond
 // Nr are clamped to the last row, where the A panel holds zeros (0 x finite = 0); columns beyond Nr
 // are clamped too, their sums are never stored.
-struct ScStream {
-    double b0[SC_PF], b1[SC_PF];
+// NT: 16-column tiles per wave (a workgroup has 8 / NT waves)
+template <int NT> struct ScStream {
+    double b[NT][SC_PF];
 };
 
-__device__ __forceinline__ void sc_prime(ScStream &B, const double *__restrict__ mat, int Nr, int n0, int li, int lk)
+template <int NT>
+__device__ __forceinline__ void sc_prime(ScStream<NT> &B, const double *__restrict__ mat, int Nr, int n0, int li, int lk)
 {
-    const double *m0 = mat + min(n0 + li, Nr - 1), *m1 = mat + min(n0 + 16 + li, Nr - 1);
 #pragma unroll
     for (int p = 0; p < SC_PF; p++) {
         const long ro = (long)min(4 * p + lk, Nr - 1) * Nr;
-        B.b0[p] = m0[ro];
-        B.b1[p] = m1[ro];
+#pragma unroll
+        for (int t = 0; t < NT; t++) B.b[t][p] = mat[ro + min(n0 + 16 * t + li, Nr - 1)];
     }
 }
 
 // acc = A (16 rows x K, LDS panel) . M[:, this wave's 32 columns]; `next`: the matrix of the product
 // that follows (its first SC_PF steps are requested here), or null
+template <int NT>
 __device__ __forceinline__ void sc_product(const double *__restrict__ panel, const double *__restrict__ mat,
-                                           const double *__restrict__ next, ScStream &B,
-                                           int Nr, int K4, int n0, int li, int lk, double4_t (&acc)[2])
+                                           const double *__restrict__ next, ScStream<NT> &B,
+                                           int Nr, int K4, int n0, int li, int lk, double4_t (&acc)[NT])
 {
-    acc[0] = (double4_t){0., 0., 0., 0.};
-    acc[1] = (double4_t){0., 0., 0., 0.};
+    int cc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        acc[t] = (double4_t){0., 0., 0., 0.};
+        cc[t] = min(n0 + 16 * t + li, Nr - 1);
+    }
     const double *Arow = panel + li * SC_RS + lk;
-    const int c0 = min(n0 + li, Nr - 1), c1 = min(n0 + 16 + li, Nr - 1);
     if (next == nullptr) next = mat;                  // (redundant loads at the very end)
     // (K4 is a multiple of SC_PF - the panel is zero beyond Nr - so that the body is straight-line
     // code: a conditional step makes every refill a copy behind an s_waitcnt vmcnt(0))
@@ -106,20 +112,25 @@ __device__ __forceinline__ void sc_product(const double *__restrict__ panel, con
 #pragma unroll
         for (int p = 0; p < SC_PF; p++) {
             const double a = Arow[4 * (s0 + p)];
-            const double x0 = B.b0[p], x1 = B.b1[p];
+            double x[NT];
             const long ro = (long)min(4 * (sb + p) + lk, Nr - 1) * Nr;
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                x[t] = B.b[t][p];
 #if SC_KNOCK != 1            // (1: timing experiment without the matrix stream)
-            B.b0[p] = src[ro + c0];
-            B.b1[p] = src[ro + c1];
+                B.b[t][p] = src[ro + cc[t]];
 #endif
-            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, x0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, x1, acc[1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, x[t], acc[t], 0, 0, 0);
         }
     }
 }
 
-__global__ __launch_bounds__(256) void k_spect_cycle(SpectCycleArgs A)
+template <int NT>
+__global__ __launch_bounds__(512 / NT) void k_spect_cycle(SpectCycleArgs A)
 {
+    constexpr int NTHREADS = 512 / NT;
     extern __shared__ double sc_lds[];
     const int m = blockIdx.y;
     const int zb = blockIdx.x * SC_TZ;
@@ -128,9 +139,9 @@ __global__ __launch_bounds__(256) void k_spect_cycle(SpectCycleArgs A)
     const int li = lane & 15, lk = lane >> 4;
     const int Nz = A.Nz, Nr = A.Nr;
     const int K4 = (Nr + 4 * SC_PF - 1) / (4 * SC_PF) * SC_PF;     // MFMA steps over K (multiple of SC_PF)
-    const int n0 = 32 * wave;
+    const int n0 = 16 * NT * wave;
 
-    ScStream B;
+    ScStream<NT> B;
     sc_prime(B, A.fwd[3 * m + 0], Nr, n0, li, lk);     // (in flight while the panels are filled)
 
     // ---- E, B, rho_prev and the coefficient tables of this lane's 4 cells (kz = zb + lk + 4 h,
@@ -140,10 +151,10 @@ __global__ __launch_bounds__(256) void k_spect_cycle(SpectCycleArgs A)
     cplx *const *f = A.f + 11 * m;
     const double *const *tb = A.t + 8 * m;
     const double *fz = A.fz[m], *fr = A.fr[m];
-    cplx c_f[4][7];                    // Ep Em Ez Bp Bm Bz rho_prev
-    double c_t[4][8], c_cz[4];
+    cplx c_f[2 * NT][7];               // Ep Em Ez Bp Bm Bz rho_prev
+    double c_t[2 * NT][8], c_cz[2 * NT];
 #pragma unroll
-    for (int t = 0; t < 2; t++)
+    for (int t = 0; t < NT; t++)
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const int q = 2 * t + h;
@@ -165,7 +176,7 @@ __global__ __launch_bounds__(256) void k_spect_cycle(SpectCycleArgs A)
     {
         const cplx *sr = A.src[4 * m], *st = A.src[4 * m + 1], *sz = A.src[4 * m + 2], *sq = A.src[4 * m + 3];
         const double *iv = A.invvol[m];
-        for (int e = tid; e < SC_TZ * SC_KMAX; e += 256) {
+        for (int e = tid; e < SC_TZ * SC_KMAX; e += NTHREADS) {
             const int row = e >> 7, k = e & (SC_KMAX - 1);
             const int zz = zb + row;
             cplx p = {0., 0.}, mm = {0., 0.}, z = {0., 0.}, q = {0., 0.};
@@ -188,7 +199,7 @@ __global__ __launch_bounds__(256) void k_spect_cycle(SpectCycleArgs A)
     __syncthreads();
 
     // ---- forward products: Jp, Jm (matrices of p, m), Jz, rho (matrix of order m)
-    double4_t aJ[4][2];
+    double4_t aJ[4][NT];
     sc_product(sc_lds + 0 * SC_PANEL, A.fwd[3 * m + 0], A.fwd[3 * m + 1], B, Nr, K4, n0, li, lk, aJ[0]);
     sc_product(sc_lds + 1 * SC_PANEL, A.fwd[3 * m + 1], A.fwd[3 * m + 2], B, Nr, K4, n0, li, lk, aJ[1]);
     sc_product(sc_lds + 2 * SC_PANEL, A.fwd[3 * m + 2], A.fwd[3 * m + 2], B, Nr, K4, n0, li, lk, aJ[2]);
@@ -196,9 +207,9 @@ __global__ __launch_bounds__(256) void k_spect_cycle(SpectCycleArgs A)
     sc_product(sc_lds + 3 * SC_PANEL, A.fwd[3 * m + 2], A.inv[3 * m + 0], B, Nr, K4, n0, li, lk, aJ[3]);
     __syncthreads();                 // the source panels are dead: the E, B panels take their place
 
-    // ---- cell-local update of this lane's 4 cells
+    // ---- cell-local update of this lane's 2 NT cells
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
+    for (int t = 0; t < NT; t++) {
         const int n = n0 + 16 * t + li;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -282,12 +293,12 @@ __global__ __launch_bounds__(256) void k_spect_cycle(SpectCycleArgs A)
     // ---- inverse products, written to the (kz, r) slab the backward z-FFT reads
 #pragma unroll 1
     for (int j = 0; j < 6; j++) {
-        double4_t acc[2];
+        double4_t acc[NT];
         sc_product(sc_lds + j * SC_PANEL, A.inv[3 * m + (j % 3)], j < 5 ? A.inv[3 * m + ((j + 1) % 3)] : nullptr,
                    B, Nr, K4, n0, li, lk, acc);
         cplx *o_ = A.out[6 * m + j];
 #pragma unroll
-        for (int t = 0; t < 2; t++) {
+        for (int t = 0; t < NT; t++) {
             const int n = n0 + 16 * t + li;
 #pragma unroll
             for (int h = 0; h < 2; h++) {
@@ -338,12 +349,18 @@ extern "C" int fb_spect_cycle_standard(int Nm, const void *const *src, long src_
     const size_t lds_bytes = (size_t)6 * SC_PANEL * 8;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_spect_cycle, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void *)k_spect_cycle<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds_bytes);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)k_spect_cycle<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds_bytes);
         if (e != hipSuccess) return check(e, who);
         attr_done = true;
     }
     dim3 grid((Nz + SC_TZ - 1) / SC_TZ, Nm);
-    hipLaunchKernelGGL(k_spect_cycle, grid, dim3(256), lds_bytes, (hipStream_t)stream, A);
+    // 8 waves of one 16-column tile each, or 4 waves of two (FBPIC_AMD_SC_WAVES=4)
+    static const int nw = [] { const char *e = getenv("FBPIC_AMD_SC_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
+    if (nw == 8) hipLaunchKernelGGL(k_spect_cycle<1>, grid, dim3(512), lds_bytes, (hipStream_t)stream, A);
+    else hipLaunchKernelGGL(k_spect_cycle<2>, grid, dim3(256), lds_bytes, (hipStream_t)stream, A);
     return check(hipGetLastError(), who);
 }
