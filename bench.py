@@ -381,14 +381,19 @@ def _sysfs_card():
     other GPUs are visible in sysfs too); None when it cannot be resolved."""
     if not _SYSFS_CARD:
         import glob
-        uid = str(_rocm_smi('--showuniqueid').get('Unique ID', '')).lower().removeprefix('0x')
+        def as_int(text):
+            try:
+                return int(str(text).strip(), 16)
+            except ValueError:
+                return None
+        uid = as_int(_rocm_smi('--showuniqueid').get('Unique ID', ''))
         found = None
         for d in glob.glob('/sys/class/drm/card*/device'):
             try:
-                u = open(d + '/unique_id').read().strip().lower().removeprefix('0x')
+                u = as_int(open(d + '/unique_id').read())
             except OSError:
                 continue
-            if uid and u == uid:
+            if uid is not None and u == uid:      # (as numbers: one of the two drops leading zeros)
                 found = d
         _SYSFS_CARD.append(found)
     return _SYSFS_CARD[0]

@@ -79,6 +79,8 @@ def main():
     print('%s: Nz_local %d, %d particles, exchange_period %d: %.4f ms/step, %.3e updates/s per rank'
           % ('single domain' if a.single else 'decomposed (loopback)', sim.fld.Nz, n,
              sim.comm.exchange_period, 1e3 * dt / a.steps, n * a.steps / dt))
+    print('   particle passes: one-pass %d, sorting two-pass %d' % (sum(s.cycle_passes for s in sim.ptcl),
+                                                                      sum(s.cycle_sorts for s in sim.ptcl)))
 
 
 if __name__ == '__main__':
