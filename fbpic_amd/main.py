@@ -52,6 +52,38 @@ class GpuMemoryManager(object):
                 s.receive_particles_from_gpu()
 
 
+_VERSION_COUNTER_OK = []
+
+
+def _version_counter_works():
+    """The carried state relies on `Tensor._version` (a private torch attribute) to notice that
+    the user wrote into a state tensor between two step() calls.  Checked once per process: the
+    attribute exists and an in-place write, a slice assignment and a copy_ each advance it; if
+    a torch build ever behaves differently, nothing is carried (every call starts like the
+    reference's)."""
+    if not _VERSION_COUNTER_OK:
+        import warnings
+        ok = False
+        try:
+            import torch
+            t = torch.zeros(4, dtype=torch.float64)
+            v0 = t._version
+            t += 1.
+            v1 = t._version
+            t[1:3] = 2.
+            v2 = t._version
+            t.copy_(torch.ones(4, dtype=torch.float64))
+            v3 = t._version
+            ok = v0 < v1 < v2 < v3
+        except Exception:
+            ok = False
+        if not ok:
+            warnings.warn('torch.Tensor._version does not track in-place writes in this torch build: '
+                          'fbpic_amd does not carry device state between step() calls')
+        _VERSION_COUNTER_OK.append(ok)
+    return _VERSION_COUNTER_OK[0]
+
+
 class Simulation(object):
     def __init__(self, Nz, zmax, Nr, rmax, Nm, dt,
                  p_zmin=-np.inf, p_zmax=np.inf, p_rmin=0, p_rmax=np.inf,
@@ -222,6 +254,8 @@ class Simulation(object):
                 or self.reference_sequence or fld.current_correction == 'cross-deposition':
             return None
         if not (fld.data_is_on_gpu and all(s.data_is_on_gpu for s in self.ptcl)):
+            return None
+        if not _version_counter_works():
             return None
         sig = [self.iteration, fld._epoch, getattr(fld, '_ext_gen', 0), fld.d_interp.data_ptr(),
                fld.d_interp._version,

@@ -72,3 +72,16 @@ def test_no_carry_signature_without_resident_data_or_for_excluded_schemes():
     sim.carry_state_between_calls = False
     assert sim._carry_signature() is None
     assert sim._can_defer_particle_fields() is False
+
+
+def test_version_counter_self_test(monkeypatch):
+    """The carried state depends on torch's private Tensor._version: checked once per process,
+    and nothing is carried where the check fails."""
+    from fbpic_amd import main
+    assert main._version_counter_works() is True        # this torch build
+    monkeypatch.setattr(main, '_VERSION_COUNTER_OK', [False])
+    sim = _small_sim()
+    sim.fld.data_is_on_gpu = True
+    for s in sim.ptcl:
+        s.data_is_on_gpu = True
+    assert sim._carry_signature() is None
