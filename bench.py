@@ -353,7 +353,9 @@ def main():
                     'clocks_after': clocks_after,
                     'particle_passes': {'one_pass': sum(s.cycle_passes for s in sim.ptcl),
                                         'sorting_two_pass': sum(s.cycle_sorts for s in sim.ptcl),
-                                        'sort_period': sim.ptcl[0].cycle_sort_period if sim.ptcl else None}}
+                                        'sort_period': sim.ptcl[0].cycle_sort_period if sim.ptcl else None,
+                                        'last_stray_fraction': max((s.cycle_last_stray_fraction or 0.) for s in sim.ptcl)
+                                        if sim.ptcl else None}}
     if kern:
         out['roofline'], out['kernels'] = roofline(kern, ceil, {'C2': True, 'C5': 'c5'}.get(config_name(args, ppc, world), False))
         out['measured_ceilings'] = ceil

@@ -143,6 +143,7 @@ class Particles(object):
         self.cycle_sorts = 0              # diagnostics: sorts and passes of the one-pass cycle
         self.cycle_passes = 0
         self.cycle_stray_fraction = None  # latest measured share of strays (J deposition)
+        self.cycle_last_stray_fraction = None     # ... not reset by a sort (for reports)
 
     # ---------------------------------------------------------------- host <-> device
     def _alloc_device_helpers(self):
@@ -530,6 +531,7 @@ class Particles(object):
         if st is not None and st[2] is not None and st[2][0].query():
             total = int(st[1].sum())
             self.cycle_stray_fraction = float(total - st[3]) / max(st[2][1], 1)
+            self.cycle_last_stray_fraction = self.cycle_stray_fraction
             st[3] = total
             st[2] = None
 
@@ -599,9 +601,9 @@ class Particles(object):
         ruy0 = grid[0].d_ruyten_linear_coef
         ruyh = grid[1 if Nm > 1 else 0].d_ruyten_linear_coef
         stats = self._cycle_stats
-        # (the counters are cumulative - the pass adds to them - and read back every fourth pass:
-        # one small copy, no memset launch)
-        measure = stats[2] is None and self._cycle_since_sort % 4 == 3
+        # (the counters are cumulative - the pass adds to them - and are read back whenever no
+        # earlier read-back is still travelling: one small copy, no memset launch)
+        measure = stats[2] is None
         rc = lib.fb_gather_push_deposit_J_rho(
             _SHAPE[self.particle_shape], Nm, self.Ntot, p(self.x), p(self.y), p(self.z),
             p(self.ux), p(self.uy), p(self.uz), p(self.inv_gamma), p(self.w), p(self.cell_idx),
