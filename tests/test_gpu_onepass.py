@@ -203,10 +203,11 @@ def test_one_pass_without_wrap_and_without_stored_fields(hip):
     assert np.isfinite(out[0][1]).all() and np.abs(out[0][1]).max() > 0
 
 
-@pytest.mark.parametrize('Nm,period', [(2, 3), (3, 1), (1, 50)])
-def test_step_one_pass_equals_two_pass_and_oracle(hip, oracle, Nm, period):
-    """Simulation.step through Particles.cycle (re-sort every `period` steps) against the
-    two-pass sequence and the oracle: fields 5e-13 after 7 steps, same particle set."""
+@pytest.mark.parametrize('Nm,period,limit', [(2, 3, None), (3, 1, None), (1, 50, None), (2, 50, 0.05)])
+def test_step_one_pass_equals_two_pass_and_oracle(hip, oracle, Nm, period, limit):
+    """Simulation.step through Particles.cycle (re-sort every `period` steps, or - `limit` - when
+    the measured share of strays exceeds it) against the two-pass sequence and the oracle: fields
+    5e-13 after 7 steps, same particle set."""
     import helpers
     res = []
     for one in (True, False):
@@ -214,6 +215,7 @@ def test_step_one_pass_equals_two_pass_and_oracle(hip, oracle, Nm, period):
         sim.one_pass_cycle = one
         for s in sim.ptcl:
             s.cycle_sort_period = period
+            s.cycle_stray_limit = 2.0 if limit is None else limit
         if one:
             ref = helpers.oracle_from_sim(oracle, sim)
         sim.step(4)
@@ -223,7 +225,12 @@ def test_step_one_pass_equals_two_pass_and_oracle(hip, oracle, Nm, period):
         if one:
             # every call starts with a sorting (two-pass) iteration: the arrays come from the host;
             # `period` one-pass iterations follow each of them
-            assert (s.cycle_sorts, s.cycle_passes) == {3: (2, 5), 1: (4, 3), 50: (2, 5)}[period]
+            if limit is None:
+                assert (s.cycle_sorts, s.cycle_passes) == {3: (2, 5), 1: (4, 3), 50: (2, 5)}[period]
+            else:
+                # u_th = 0.1: more than 5 % of the particles leave their cell within a step or two
+                assert s.cycle_sorts > 2 and s.cycle_sorts + s.cycle_passes == 7
+                assert s.cycle_last_stray_fraction is not None
         res.append(sim)
     ref.step(7)
     a, b = res
