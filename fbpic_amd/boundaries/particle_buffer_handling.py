@@ -273,15 +273,15 @@ def exchange_particles_between_ranks(comm, species, fld, time):
         setattr(species, k, b)
     species.Ntot = n_new
     for k in _FIELDS:
-        # E, B on the particles: re-sized only.  Nothing reads them before the next gather
-        # writes them (inside step() every read follows a gather that stores; the reference
-        # zeroes them here, :289-417) - except for a neutral species, which never gathers
+        # E, B on the particles: inside step() re-sized only - every read follows a gather that
+        # stores them.  The reference zeroes them here (:289-417): so does a direct call of
+        # comm.exchange_particles, and a neutral species (which never gathers) always
         f = getattr(species, k, None)
         if hasattr(f, 'untyped_storage') and f.device == dev:
             f = _resized(t, f, 0, n_new)
         else:
             f = t.zeros(n_new, dtype=t.float64, device=dev)
-        if getattr(species, 'q', 1) == 0 or dev.type != 'cuda':
+        if getattr(species, 'q', 1) == 0 or dev.type != 'cuda' or not getattr(species, '_in_step', False):
             f.zero_()
         setattr(species, k, f)
     # The arrays stay cell-sorted except for the few particles that were moved / appended: the

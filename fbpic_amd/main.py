@@ -421,7 +421,9 @@ class Simulation(object):
                                           and not cross) else None
         pend = self._eb_pending
         if pend is not None and pend[1] is not None and hint is not None and wrap_z is None \
-                and all(sp.can_split_gather(fld.Nm) for sp in ptcl):
+                and all(sp.can_split_gather(fld.Nm) for sp in ptcl if sp.q != 0):
+            # (a neutral species has nothing to gather: gather_push pushes it once, with the
+            # 'outside' part)
             # the rows [lo, hi) of the interpolation grid are final; a particle of cell
             # row iz_upper reads rows iz_upper - 2 ... iz_upper + 1 at most (cubic shape)
             rows = (pend[1] + 2, pend[2] - 2)

@@ -42,6 +42,25 @@ except (OSError, ValueError):
     _MEASURED = {}
 
 
+_CLAMP_APPLIES = []
+
+
+def _clamp_applies():
+    """The measured figures are those of MI355X (gfx950) with the HIP 7.0 runtime of this image:
+    on another GPU, ROCm or rocFFT build the clamp is not applied (the stated tolerance is)."""
+    if not _CLAMP_APPLIES:
+        ok = False
+        try:
+            import torch
+            if torch.cuda.is_available():
+                arch = getattr(torch.cuda.get_device_properties(0), 'gcnArchName', '')
+                ok = arch.startswith('gfx950') and str(getattr(torch.version, 'hip', '')).startswith('7.0')
+        except Exception:
+            ok = False
+        _CLAMP_APPLIES.append(ok)
+    return _CLAMP_APPLIES[0]
+
+
 def achieved(name, err, tol, what=''):
     """Assert err < tol and keep the achieved figure: the list is printed at the end of the run
     (pytest_terminal_summary) and written to gpurun_out/achieved_errors.json, so a bound that is
@@ -53,7 +72,7 @@ def achieved(name, err, tol, what=''):
         if what:
             name += ' ' + what
     ref = _MEASURED.get(name)
-    if ref is not None:
+    if ref is not None and _clamp_applies():
         tol = min(float(tol), max(10. * ref, 5e-15))
     _ACHIEVED.append((name, float(err), float(tol)))
     assert err < tol, (name, err, tol)
