@@ -533,11 +533,13 @@ static int launch_cycle_linear(const CycleArgs &A0, hipStream_t s)
     const size_t wave_bytes = 8 * (size_t)(RANK ? P::GATHER_DOUBLES : P::WAVE_DOUBLES);
     const int nwaves = lds_waves_per_workgroup(wave_bytes);
     const long nchunks = (A.n + 63) / 64;
+    // (chunks per wave: 2 .. 6 measure the same, longer per-wave ranges LOSE - 8: +4 %, 11: +22 %, 22:
+    // x 2.3 - because the waves in flight then span the whole grid instead of a moving front of it
+    // and its node lines leave the XCD's L2)
     const long target_waves = 256L * 64;
     int cpw = (int)((nchunks + target_waves - 1) / target_waves);
     if (cpw < 1) cpw = 1;
     if (cpw > 64) cpw = 64;
-    if (const char *e = getenv("FBPIC_AMD_CYCLE_CPW")) cpw = atoi(e) > 0 ? atoi(e) : cpw;
     A.chunks_per_wave = cpw;
     const long total_waves = (nchunks + cpw - 1) / cpw;
     const long nblocks = xcd_grid((total_waves + nwaves - 1) / nwaves);

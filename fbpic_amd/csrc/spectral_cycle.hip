@@ -10,19 +10,18 @@
 // overlap no MFMA work, and the spectral slab makes a full round trip between them.
 //
 // Here a workgroup owns 8 kz rows of ONE azimuthal mode (the solver does not couple modes) and
-// all Nr columns; its 4 waves split the OUTPUT columns (32 each).  The PSATD update is local in
+// all Nr columns; its 8 waves split the OUTPUT columns (16 each).  The PSATD update is local in
 // (kz, kr), so after the forward products every lane holds J and rho_next of its own cells in its
 // accumulators, updates them with E, B, rho_prev read once from the spectral slab, writes the
 // slab, and passes the new E, B to the inverse products through LDS (the K dimension of the
 // inverse transform runs over kr: all four waves need all of it).  1024 x 128, Nm = 2: 256
-// workgroups = one per CU, one wave per SIMD, 640 v_mfma_f64_16x16x4 per wave back to back.
+// workgroups = one per CU, two waves per SIMD, 320 v_mfma_f64_16x16x4 per wave back to back.
 //
 // MFMA fragments (cdna_hip_programming.md section 3): A lane l -> A[i = l & 15][k = l >> 4],
 // B lane l -> B[k = l >> 4][j = l & 15], D reg r of lane l -> D[i = (l >> 4) + 4 r][j = l & 15].
 // Rows i of a tile = (kz_local, re | im): i = kz_local + 8 ri, so that a lane's four D registers
 // are re / im of the SAME two cells (kz_local = l >> 4 and + 4): complete complex numbers in one
 // lane, no shuffle before the cell-local update.
-#include <cstdlib>
 #include "fb_common.h"
 #ifndef SC_KNOCK
 #define SC_KNOCK 0                 // timing experiments (tools/sc_time.py): 1 .. 4 drop one part each
@@ -351,16 +350,11 @@ extern "C" int fb_spect_cycle_standard(int Nm, const void *const *src, long src_
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void *)k_spect_cycle<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds_bytes);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void *)k_spect_cycle<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds_bytes);
         if (e != hipSuccess) return check(e, who);
         attr_done = true;
     }
     dim3 grid((Nz + SC_TZ - 1) / SC_TZ, Nm);
-    // 8 waves of one 16-column tile each, or 4 waves of two (FBPIC_AMD_SC_WAVES=4)
-    static const int nw = [] { const char *e = getenv("FBPIC_AMD_SC_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
-    if (nw == 8) hipLaunchKernelGGL(k_spect_cycle<1>, grid, dim3(512), lds_bytes, (hipStream_t)stream, A);
-    else hipLaunchKernelGGL(k_spect_cycle<2>, grid, dim3(256), lds_bytes, (hipStream_t)stream, A);
+    // 8 waves of one 16-column tile each (NT = 2, 4 waves of two tiles: 58 against 52 us at C2)
+    hipLaunchKernelGGL(k_spect_cycle<1>, grid, dim3(512), lds_bytes, (hipStream_t)stream, A);
     return check(hipGetLastError(), who);
 }

@@ -35,22 +35,25 @@ def _plasma(rng, n, Nz, Nr, dzc):
     z = rng.uniform(0., Nz * dzc, n)
     z[50:80] = rng.uniform(0., 0.6 * dzc, 30)         # periodic wrap of the stencil
     z[80:110] = Nz * dzc - rng.uniform(0., 0.6 * dzc, 30)
-    x[110:114] = (np.arange(4) + 0.5) * dzc           # exactly on nodes
-    y[110:114] = 0.
-    z[110:114] = (np.arange(4) + 2.5) * dzc
+    if n >= 114:
+        x[110:114] = (np.arange(4) + 0.5) * dzc       # exactly on nodes
+        y[110:114] = 0.
+        z[110:114] = (np.arange(4) + 2.5) * dzc
     return x, y, z
 
 
-@pytest.mark.parametrize('Nm,records,stale,wide', [(2, True, 0.0, 0), (2, True, 0.25, 0), (2, True, 'garbage', 0),
-                                                   (1, False, 0.25, 0), (3, True, 0.25, 0), (4, False, 0.6, 0),
-                                                   (2, True, 'unsorted', 0), (2, True, 0.25, 1),
-                                                   (3, False, 0.25, 1)])
-def test_one_pass_equals_the_four_entry_points(hip, oracle, Nm, records, stale, wide, monkeypatch):
+@pytest.mark.parametrize('Nm,records,stale,wide,n', [
+    (2, True, 0.0, 0, 100003), (2, True, 0.25, 0, 100003), (2, True, 'garbage', 0, 100003),
+    (1, False, 0.25, 0, 100003), (3, True, 0.25, 0, 100003), (4, False, 0.6, 0, 100003),
+    (2, True, 'unsorted', 0, 100003), (2, True, 0.25, 1, 100003), (3, False, 0.25, 1, 100003),
+    # fewer particles than a wavefront, one more than a wavefront, a single one
+    (2, True, 0.25, 0, 63), (2, True, 0.25, 0, 65), (1, True, 0.0, 0, 1)])
+def test_one_pass_equals_the_four_entry_points(hip, oracle, Nm, records, stale, wide, n, monkeypatch):
     # wide = 1: the 64-bit addressing of grids / targets that are not within 4 GiB of each other
     # (the library picks it from the pointers; forced here, a test process has no such layout)
     monkeypatch.setenv('FBPIC_AMD_CYCLE_WIDE', str(wide))
     rng = np.random.default_rng(7 + Nm)
-    n, Nz, Nr = 100003, 36, 20
+    Nz, Nr = 36, 20
     dzc = 0.2e-6
     geom = (1. / dzc, 0., Nz, 1. / dzc, 0., Nr)
     rmax_gather = Nr * dzc
@@ -157,7 +160,10 @@ def test_one_pass_equals_the_four_entry_points(hip, oracle, Nm, records, stale, 
     achieved(None, worst, 1e-13, 'J, rho vs oracle')
     # the pass counted the particles it deposited on their own
     nstray = int(host(stats).sum())
-    if stale == 0.0:
+    assert 0 <= nstray <= n
+    if n < 1000:
+        pass                              # (a handful of particles: any count is possible)
+    elif stale == 0.0:
         assert nstray < 0.5 * n           # those that leave their cell within the half push (u ~ 0.4)
     elif stale == 'garbage':
         assert nstray > 0.99 * n
