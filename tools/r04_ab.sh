@@ -1,7 +1,7 @@
 # A/B of the default library against fbpic_amd/csrc/variants/*.so: tests of the touched kernels, the
 # frozen-state one-pass timing, the two bench sequences
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_onepass.py tests/test_gpu_kernels.py -x -q 2>&1 | tail -2
+timeout 900 python -m pytest tests/test_gpu_onepass.py tests/test_gpu_kernels.py -x -q 2>&1 | grep "passed\|failed" | tail -2
 python tools/cycle_knock.py 2>&1 | grep -v amdgpu.ids
 for lib in "" $PWD/fbpic_amd/csrc/variants/libfbpic_amd_prev.so; do
   for seq in "1 1" "0 0"; do set -- $seq
