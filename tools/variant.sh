@@ -5,7 +5,7 @@ cd /root/repo/fbpic_amd/csrc
 mkdir -p variants
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Wno-unused-result -Wno-pass-failed -I../../include"
 EXTRA=""
-[ "$2" = "cycle.hip" ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1"
+[ "$2" = "cycle.hip" ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1 -mllvm -amdgpu-sched-strategy=max-memory-clause"
 /opt/rocm/bin/hipcc $F $EXTRA $3 -c $2 -o /tmp/var_$1.o
 OBJS=""
 for s in $(grep '^SRCS' Makefile | cut -d= -f2); do
