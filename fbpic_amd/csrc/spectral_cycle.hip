@@ -44,9 +44,10 @@ constexpr int SC_KMAX = 128;        // Nr <= 128
 constexpr int SC_RS = SC_KMAX + 2;  // panel row stride in doubles: the 32 (row, k) pairs of half a
                                     // wave's ds_read_b64 fall on 32 different bank pairs
 constexpr int SC_PANEL = 16 * SC_RS;
-// (with two waves per SIMD a short look-ahead is enough: 4 / 8 / 16 / 32 steps measure 50.8 / 51.4 /
-// 52.8 / 61.3 us at C2)
-constexpr int SC_PF = 4;            // matrix row groups requested ahead of the MFMA that uses them
+// (4 / 8 / 16 / 32 steps: 50.8 / 51.4 / 52.8 / 61.3 us when the launch is repeated back to back,
+// tools/sc_time.py - but INSIDE a step, where the particle kernels have flushed the matrices out
+// of L2: 64.8 / 57.9 / 56.7 / 65.7 us.  The depth is chosen in the bench, not in the loop.)
+constexpr int SC_PF = 16;            // matrix row groups requested ahead of the MFMA that uses them
 
 struct SpectCycleArgs {
     // per mode m: src[4m..] = Jr, Jt, Jz, rho after the forward z-FFT (un-normalised)
