@@ -531,7 +531,10 @@ static int launch_cycle_linear(const CycleArgs &A0, hipStream_t s)
     using P = CyclePlan<NM, WIDE>;
     CycleArgs A = A0;
     const size_t wave_bytes = 8 * (size_t)(RANK ? P::GATHER_DOUBLES : P::WAVE_DOUBLES);
-    const int nwaves = lds_waves_per_workgroup(wave_bytes);
+    // one wave per workgroup (nothing is shared between the waves of this kernel): 0.260 against
+    // 0.269 ms per launch for the 4-wave workgroups lds_waves_per_workgroup() picks (2 waves: 0.263,
+    // 3: 0.266) - finer dispatch granularity at the same 11-12 waves per CU
+    const int nwaves = 1;
     const long nchunks = (A.n + 63) / 64;
     // (chunks per wave: 2 .. 6 measure the same, longer per-wave ranges LOSE - 8: +4 %, 11: +22 %, 22:
     // x 2.3 - because the waves in flight then span the whole grid instead of a moving front of it
