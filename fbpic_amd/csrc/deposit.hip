@@ -486,7 +486,10 @@ static int launch_perm_J_rho(long n, double q, double c, const DepGeom &gJ, cons
                              const double *b0, const double *bh, const PermArgs &PM, hipStream_t s)
 {
     const size_t wave_bytes = 8 * (size_t)FusedPlan<SHAPE, NM>::WAVE_DOUBLES;
-    const int nwaves = dep_waves_per_workgroup(wave_bytes);
+    // one wave per workgroup, as for the one-pass kernel (cycle.hip): 0.208 against 0.218 ms per
+    // launch at C2 for the 4-wave workgroups dep_waves_per_workgroup() picks, 5.69 against 5.74 ms
+    // for the cubic pass of C5 (the stand-alone depositions measure the other way: 80 against 77 us)
+    const int nwaves = 1;
     const long nchunks = (n + 63) / 64;
     const long target_waves = 256L * 64;
     int cpw = (int)((nchunks + target_waves - 1) / target_waves);
