@@ -381,6 +381,8 @@ _SYSFS_CARD = []
 def _sysfs_card():
     """/sys/class/drm/cardN/device of the GPU rocm-smi calls card0 (matched by unique id: the host's
     other GPUs are visible in sysfs too); None when it cannot be resolved."""
+    if not _SYSFS_CARD and int(os.environ.get('WORLD_SIZE', '1')) > 1:
+        _SYSFS_CARD.append(None)        # (rocm-smi's card0 is not this rank's GPU: no clocks reported)
     if not _SYSFS_CARD:
         import glob
         def as_int(text):
