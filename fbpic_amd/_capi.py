@@ -52,9 +52,9 @@ _SIGNATURES = {
     'fb_gather_push_deposit_supported': (I, [I, I]),
     'fb_gather_push_deposit_J_rho': (I, [I, I, L, P, P, P, P, P, P, P, P, P, D, D, D, I, D, D, I, _PP, L,
                                          P, P, P, P, P, P, D, D, D, D, D, D, D, _PP, L, L, _PP, L, L,
-                                         P, P, P, P]),
+                                         P, P, P, I, P]),
     'fb_gather_push_rank_next_home': (I, [I, I, L, P, P, P, P, P, P, P, P, D, D, D, I, D, D, I, _PP, L,
-                                          P, P, P, P, P, P, D, D, D, D, D, D, D, I, P, Z, I, P]),
+                                          P, P, P, P, P, P, D, D, D, D, D, D, D, I, P, Z, I, I, P]),
     'fb_permute': (I, [L, P, I, _PP, _PP, P]),
     'fb_handover_pack': (I, [L, P, I, _PP, P, L, P]),
     'fb_handover_move': (I, [L, P, P, I, _PP, P]),
@@ -108,6 +108,8 @@ _SIGNATURES = {
 }
 
 EXPORTS = tuple(_SIGNATURES)
+# FB_ABI_VERSION of include/fbpic_amd.h the signatures above were written against
+ABI_VERSION = 5
 
 
 class BackendError(RuntimeError):
@@ -128,6 +130,18 @@ def lib():
         # the DT_NEEDED entries of libfbpic_amd.so then resolve to the copies torch loaded.
         torch()
         _l = ctypes.CDLL(LIB_PATH)
+        # the argument lists below belong to ONE revision of include/fbpic_amd.h: a library built
+        # from another one must not be bound (a stale .so would otherwise fail far from here, with
+        # an AttributeError or - worse - shifted arguments)
+        try:
+            _l.fb_abi_version.restype = I
+            have = _l.fb_abi_version()
+        except AttributeError:
+            have = None
+        if have != ABI_VERSION:
+            raise BackendError('%s was built for ABI revision %s of include/fbpic_amd.h, this package '
+                               'binds revision %d: rebuild it (`make -C fbpic_amd/csrc`).'
+                               % (LIB_PATH, have, ABI_VERSION))
         for name, (res, args) in _SIGNATURES.items():
             f = getattr(_l, name)
             f.restype = res

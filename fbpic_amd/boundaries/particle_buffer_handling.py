@@ -288,7 +288,8 @@ def exchange_particles_between_ranks(comm, species, fld, time):
     # deposition and the gather work on runs of equal cells and do not need more (any order is
     # correct), and the next fused pass re-sorts everything anyway.  Only the per-cell prefix
     # sum is no longer exact.
-    nearly_sorted = bool(getattr(species, 'sorted', False) and (n_leave + n_in) * 16 < max(n_new, 1))
+    few_movers = (n_leave + n_in) * 16 < max(n_new, 1)
+    nearly_sorted = bool(getattr(species, 'sorted', False) and few_movers)
     moved = getattr(species, '_moved_since_sort', 0.)
     home = getattr(species, '_home_valid', False) and species.cell_idx is not None
     home_ptr = species.cell_idx.data_ptr() if home else None
@@ -297,9 +298,13 @@ def exchange_particles_between_ranks(comm, species, fld, time):
     if nearly_sorted:
         species.sorted = True
         species._moved_since_sort = moved
+    if few_movers:
         # The home cells of the one-pass cycle (Particles.cycle) stay usable as well: a particle
         # that was moved into a hole or appended meets some other particle's (or no) home cell
         # and is simply treated as one that has left it - any content gives the same result.
+        # (Decided by the share of movers, not by `sorted`: a one-pass iteration clears that flag
+        # - the arrays are in home order, not in cell order - and every hand-over that followed one
+        # used to force a sorting iteration.)
         species._home_valid = bool(home and species.cell_idx is not None
                                    and species.cell_idx.data_ptr() == home_ptr)
     # capacities for the next hand-over (same rule, same numbers on both ends of a link)

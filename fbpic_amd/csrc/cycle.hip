@@ -29,6 +29,7 @@
 #include "fb_common.h"
 #include "push_common.h"
 #include "dep_engine.h"
+#include "cycle_dep.h"
 
 namespace fb {
 
@@ -37,6 +38,7 @@ struct CycleArgs {
     double *x, *y, *z, *ux, *uy, *uz, *ig;
     const double *w;
     const int *home;                           // cell ir_upper + iz_upper (Nr+1) at the last sort
+    int home_shift;                            // ... minus this: (cells the grid has moved since) x (Nr+1)
     double *Ex, *Ey, *Ez, *Bx, *By, *Bz;       // optional: gathered fields stored
     double invdz, zmin;
     int Nz;
@@ -78,10 +80,14 @@ template <int NM, bool WIDE> struct CyclePlan {
     // panel stride in doubles: load j of a segment fills the 16-B slots 64 j ... of its lanes
     // (only NV of them in all), + a 16-B pad (segments start on different banks)
     static constexpr int PSTR = 2 * NV + 2;
-    using EJ = DepEngine<FB_SHAPE_LINEAR, 3, NM, true, !WIDE>;
-    using ER = DepEngine<FB_SHAPE_LINEAR, 1, NM, true, !WIDE>;
-    static constexpr int DEP_DOUBLES = EJ::L::WAVE_DOUBLES > ER::L::WAVE_DOUBLES ? EJ::L::WAVE_DOUBLES
-                                                                                 : ER::L::WAVE_DOUBLES;
+    // WIDE: the two DepEngines one after the other on one panel (64-bit pointers per lane); else the
+    // merged engine of cycle_dep.h (J and rho staged together, one traversal of the runs)
+    using EJ = DepEngine<FB_SHAPE_LINEAR, 3, NM, true, false>;
+    using ER = DepEngine<FB_SHAPE_LINEAR, 1, NM, true, false>;
+    using ED = CycleDep<NM>;
+    static constexpr int DEP2_DOUBLES = EJ::L::WAVE_DOUBLES > ER::L::WAVE_DOUBLES ? EJ::L::WAVE_DOUBLES
+                                                                                  : ER::L::WAVE_DOUBLES;
+    static constexpr int DEP_DOUBLES = WIDE ? DEP2_DOUBLES : ED::L::WAVE_DOUBLES;
     static constexpr int GATHER_DOUBLES = NSEG * PSTR;
     // the two panels do not share LDS: the node values of chunk c+1 arrive while chunk c deposits
     static constexpr int WAVE_DOUBLES = GATHER_DOUBLES + DEP_DOUBLES;
@@ -139,6 +145,7 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
     using P = CyclePlan<NM, WIDE>;
     using EJ = typename P::EJ;
     using ER = typename P::ER;
+    using ED = typename P::ED;
     constexpr int S = 2, NV = P::NV, NVL = P::NVL, NSEG = P::NSEG, PSTR = P::PSTR;
     extern __shared__ double lds[];
     const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
@@ -153,9 +160,14 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
     const long rs = A.rsG;
     EJ ej;
     ER er;
+    ED ed;
     if constexpr (!RANK) {
-        ej.init(dpanel, lane, A.GJ, A.rsJ, 0, Nz, Nr, A.baseJ);
-        er.init(dpanel, lane, A.GR, A.rsR, 0, Nz, Nr, A.baseR);
+        if constexpr (WIDE) {
+            ej.init(dpanel, lane, A.GJ, A.rsJ, 0, Nz, Nr);
+            er.init(dpanel, lane, A.GR, A.rsR, 0, Nz, Nr);
+        } else {
+            ed.init(dpanel, lane, A.GJ, A.rsJ, A.GR, A.rsR, Nz, Nr, A.baseJ);
+        }
     }
     // RANK: (cell, rank) of the previous chunk, written once the rank atomic has returned
     long pd_i = -1;
@@ -240,7 +252,7 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
         // stencil = (iz_upper - 1, ir_upper - 1), the same for gather and deposition).
         // hc / ncol: (hc + 0.5) / ncol is at least 0.5 / ncol away from an integer, so the floor
         // of the rounded product is the quotient for any int hc.
-        const int hc = hn;
+        const int hc = hn - A.home_shift;
         const int hzu = (int)floor(((double)hc + 0.5) * A.inv_ncol);
         const int hru = hc - hzu * ncol;
         f.hkz = hzu - 1; f.hkr = hru - 1; f.hnb = 1 - hru;
@@ -474,37 +486,59 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
         const double wj = act ? A.q * pw : 0.;       // a lane without a particle deposits nothing
 
         FB_MARK("M_JSTAGE");
-        // ---- J from x(n+1/2)
+        // ---- J from x(n+1/2), rho from x(n+1)
         int dkz, dkr, dnb;
         // (Ruyten coefficients of both depositions: requested here, so that no staging waits for a
         // load - i.e. for the atomics issued before it)
-        const int irJ = ej.ruyten_index(xh, yh, geom), irR = er.ruyten_index(x1, y1, geom);
+        auto ruyten_index = [&](double xa, double ya) {       // DepEngine::ruyten_index
+            const double ra = sqrt(xa * xa + ya * ya);
+            return min((int)ceil(A.invdr * (ra - A.rmin) - 0.5), Nr);
+        };
+        const int irJ = ruyten_index(xh, yh), irR = ruyten_index(x1, y1);
         const double bJ0 = KP(const double, beta0)[irJ], bJh = KP(const double, betah)[irJ];
         const double bR0 = KP(const double, beta0)[irR], bRh = KP(const double, betah)[irR];
         wait_and_store();
-        ej.stage_with(true, xh, yh, zh, wj, pux, puy, puz, pig, A.c_light, geom, bJ0, bJh, dkz, dkr, dnb);
-        {
-            const bool home = act && dkz == hkz && dkr == hkr && dnb == hnb;
-            const unsigned long long hm = __ballot(home), sm = __ballot(act && !home);
-            nstray_J += __popcll(sm);
-            wave_lds_release();
-        FB_MARK("M_JREDUCE");
-            ej.reduce_home(cnt, runstarts, hm, hkz, hkr, hnb);
-        FB_MARK("M_JSCATTER");
-            ej.scatter_strays(sm, dkz, dkr, dnb);
-            wave_lds_acquire();
-        }
+        if constexpr (WIDE) {
+            ej.stage_with(true, xh, yh, zh, wj, pux, puy, puz, pig, A.c_light, geom, bJ0, bJh, dkz, dkr, dnb);
+            {
+                const bool home = act && dkz == hkz && dkr == hkr && dnb == hnb;
+                const unsigned long long hm = __ballot(home), sm = __ballot(act && !home);
+                nstray_J += __popcll(sm);
+                wave_lds_release();
+                ej.reduce_home(cnt, runstarts, hm, hkz, hkr, hnb);
+                ej.scatter_strays(sm, dkz, dkr, dnb);
+                wave_lds_acquire();
+            }
+            er.stage_with(true, x1, y1, z1, wj, 0., 0., 0., 0., 0., geom, bR0, bRh, dkz, dkr, dnb);
+            {
+                const bool home = act && dkz == hkz && dkr == hkr && dnb == hnb;
+                const unsigned long long hm = __ballot(home), sm = __ballot(act && !home);
+                wave_lds_release();
+                er.reduce_home(cnt, runstarts, hm, hkz, hkr, hnb);
+                er.scatter_strays(sm, dkz, dkr, dnb);
+                wave_lds_acquire();
+            }
+        } else {
+            int rkz, rkr, rnb;
+            ed.template stage<0>(xh, yh, zh, wj, pux, puy, puz, pig, A.c_light, geom, bJ0, bJh, dkz, dkr, dnb);
         FB_MARK("M_RSTAGE");
-        // ---- rho from x(n+1)
-        er.stage_with(true, x1, y1, z1, wj, 0., 0., 0., 0., 0., geom, bR0, bRh, dkz, dkr, dnb);
-        {
-            const bool home = act && dkz == hkz && dkr == hkr && dnb == hnb;
-            const unsigned long long hm = __ballot(home), sm = __ballot(act && !home);
+            ed.template stage<1>(x1, y1, z1, wj, 0., 0., 0., 0., 0., geom, bR0, bRh, rkz, rkr, rnb);
+            const bool homeJ = act && dkz == hkz && dkr == hkr && dnb == hnb;
+            const bool homeR = act && rkz == hkz && rkr == hkr && rnb == hnb;
+            const unsigned long long hmJ = __ballot(homeJ), smJ = __ballot(act && !homeJ);
+            const unsigned long long hmR = __ballot(homeR), smR = __ballot(act && !homeR);
+            nstray_J += __popcll(smJ);
             wave_lds_release();
-        FB_MARK("M_RREDUCE");
-            er.reduce_home(cnt, runstarts, hm, hkz, hkr, hnb);
-        FB_MARK("M_RSCATTER");
-            er.scatter_strays(sm, dkz, dkr, dnb);
+        FB_MARK("M_SCATTER");
+            if (smJ | smR) {
+                // strays first (they read their staged amplitudes), then their amplitudes are zeroed:
+                // the products below need no per-particle mask
+                ed.scatter_strays(smJ, smR, dkz, dkr, dnb, rkz, rkr, rnb);
+                ed.zero_amplitudes(!homeJ, !homeR);
+                wave_lds_release();
+            }
+        FB_MARK("M_REDUCE");
+            ed.reduce(cnt, runstarts, hmJ | hmR, hkz, hkr, hnb);
             wave_lds_acquire();
         }
         FB_MARK("M_END");
@@ -516,8 +550,12 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
         if (pd_i >= 0) { A.rk_cell[pd_i] = pd_cell; A.rk_rank[pd_i] = b_ + (lane - pd_run0); }
         return;
     }
-    ej.flush(false);
-    er.flush(false);
+    if constexpr (WIDE) {
+        ej.flush(false);
+        er.flush(false);
+    } else {
+        ed.flush(false);
+    }
     if (A.stats && lane == 0)
         atomicAdd(A.stats + ((blockIdx.x * nwaves + wave) & 1023), (unsigned long long)nstray_J);
 }
@@ -577,7 +615,7 @@ static int cycle_entry(const char *who, bool rank, int shape, int Nm, long n,
         void *const *J, long J_row_stride, long J_col_stride,
         void *const *rho, long rho_row_stride, long rho_col_stride,
         const double *ruyten_m0, const double *ruyten_mh, unsigned long long *stats,
-        int *rk_cell, int *rk_rank, int *rk_count, void *stream)
+        int *rk_cell, int *rk_rank, int *rk_count, int home_cell_shift, void *stream)
 {
     if (n <= 0) return 0;
     if (!fb_gather_push_deposit_supported(shape, Nm)) {
@@ -590,6 +628,7 @@ static int cycle_entry(const char *who, bool rank, int shape, int Nm, long n,
     A.n = n;
     A.x = x; A.y = y; A.z = z; A.ux = ux; A.uy = uy; A.uz = uz; A.ig = inv_gamma; A.w = w;
     A.home = home_cell;
+    A.home_shift = home_cell_shift;
     A.Ex = Ex; A.Ey = Ey; A.Ez = Ez; A.Bx = Bx; A.By = By; A.Bz = Bz;
     A.invdz = invdz; A.zmin = zmin; A.Nz = Nz; A.invdr = invdr; A.rmin = rmin; A.Nr = Nr;
     A.inv_ncol = 1. / (double)(Nr + 1);
@@ -624,9 +663,22 @@ static int cycle_entry(const char *who, bool rank, int shape, int Nm, long n,
     A.rsJ = J_row_stride; A.rsR = rho_row_stride;
     A.baseJ = A.baseR = nullptr;
     if (!rank) {
-        A.baseJ = dep_grids_base(A.GJ, 3 * Nm, J_row_stride, Nz);
-        A.baseR = dep_grids_base(A.GR, Nm, rho_row_stride, Nz);
-        if (!A.baseJ || !A.baseR) wide = true;     // separately allocated arrays, far apart
+        // the merged engine (cycle_dep.h) addresses J and rho from ONE base with the same strides
+        // (the views of one record array, or arrays of one slab); anything else: 64-bit pointers
+        DepGrids U;
+        U.cs = A.GJ.cs;
+        for (int i = 0; i < 3 * Nm; i++) U.g[i] = A.GJ.g[i];
+        DepGrids V = A.GR;
+        cplx *bj = dep_grids_base(U, 3 * Nm, J_row_stride, Nz), *br = dep_grids_base(V, Nm, rho_row_stride, Nz);
+        if (bj && br && J_row_stride == rho_row_stride && A.GJ.cs == A.GR.cs) {
+            const uintptr_t lo = (uintptr_t)bj < (uintptr_t)br ? (uintptr_t)bj : (uintptr_t)br;
+            uintptr_t hi = 0;
+            for (int i = 0; i < 3 * Nm; i++) if ((uintptr_t)A.GJ.g[i] > hi) hi = (uintptr_t)A.GJ.g[i];
+            for (int i = 0; i < Nm; i++) if ((uintptr_t)A.GR.g[i] > hi) hi = (uintptr_t)A.GR.g[i];
+            if ((double)(hi - lo) + 16. * (double)J_row_stride * (double)(Nz + 1) < 4294967296.)
+                A.baseJ = A.baseR = (cplx *)lo;
+        }
+        if (!A.baseJ) wide = true;
     }
     A.beta0 = ruyten_m0; A.betah = ruyten_mh;
     A.chunks_per_wave = 1;
@@ -650,13 +702,14 @@ extern "C" int fb_gather_push_deposit_J_rho(int shape, int Nm, long n,
         double q, double m, double c, double dt, double dt_x, double wrap_zmin, double wrap_zmax,
         void *const *J, long J_row_stride, long J_col_stride,
         void *const *rho, long rho_row_stride, long rho_col_stride,
-        const double *ruyten_m0, const double *ruyten_mh, unsigned long long *stats, void *stream)
+        const double *ruyten_m0, const double *ruyten_mh, unsigned long long *stats,
+        int home_cell_shift, void *stream)
 {
     return cycle_entry("fb_gather_push_deposit_J_rho", false, shape, Nm, n, x, y, z, ux, uy, uz, inv_gamma, w,
                        home_cell, rmax_gather, invdz, zmin, Nz, invdr, rmin, Nr, grids, row_stride, Ex, Ey, Ez,
                        Bx, By, Bz, q, m, c, dt, dt_x, wrap_zmin, wrap_zmax, J, J_row_stride, J_col_stride, rho,
                        rho_row_stride, rho_col_stride, ruyten_m0, ruyten_mh, stats, nullptr, nullptr, nullptr,
-                       stream);
+                       home_cell_shift, stream);
 }
 
 extern "C" int fb_gather_push_rank_next_home(int shape, int Nm, long n,
@@ -666,7 +719,8 @@ extern "C" int fb_gather_push_rank_next_home(int shape, int Nm, long n,
         const void *const *grids, long row_stride,
         double *Ex, double *Ey, double *Ez, double *Bx, double *By, double *Bz,
         double q, double m, double c, double dt, double dt_x, double wrap_zmin, double wrap_zmax,
-        int ncell, void *sort_workspace, size_t workspace_bytes, int counts_are_zero, void *stream)
+        int ncell, void *sort_workspace, size_t workspace_bytes, int counts_are_zero,
+        int home_cell_shift, void *stream)
 {
     const char *who = "fb_gather_push_rank_next_home";
     hipStream_t s = (hipStream_t)stream;
@@ -680,5 +734,5 @@ extern "C" int fb_gather_push_rank_next_home(int shape, int Nm, long n,
     return cycle_entry(who, true, shape, Nm, n, x, y, z, ux, uy, uz, inv_gamma, x /* w: not read */, home_cell,
                        rmax_gather, invdz, zmin, Nz, invdr, rmin, Nr, grids, row_stride, Ex, Ey, Ez, Bx, By, Bz,
                        q, m, c, dt, dt_x, wrap_zmin, wrap_zmax, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr,
-                       nullptr, W.cell, W.rank, W.count, stream);
+                       nullptr, W.cell, W.rank, W.count, home_cell_shift, stream);
 }

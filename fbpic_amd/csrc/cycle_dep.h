@@ -1,0 +1,388 @@
+// Deposition engine of the one-pass particle cycle (cycle.hip), round 5: J (from x(n+1/2)) and rho
+// (from x(n+1)) of a chunk are staged TOGETHER and reduced in ONE traversal of the home runs.
+//
+// Why a second engine next to DepEngine (dep_engine.h, still used by deposit.hip and by the
+// 64-bit-pointer form of the cycle kernel): SQ counters of round 4 put 547 of the 1381 VALU and 414
+// of the 596 SALU instructions per 64 particles into the two run reductions - each run was walked
+// twice (once per engine: the same readlanes, key compares and flush decisions), and every flush
+// added the 4 MFMA blocks of every tile with DPP rotations (8 VALU per tile) before one lane group
+// could write it.  Here
+//   * the 4 blocks of v_mfma_f64_4x4x4_4b are the 4 WEIGHT VARIANTS of a node - block v: 0 = J with
+//     the mode-0 Ruyten weights, 1 = J with the weights of the modes >= 1, 2 = rho / mode 0,
+//     3 = rho / modes >= 1 - so one instruction multiplies W_v[4 nodes][4 particles] by the
+//     amplitudes of variant v of the same 4 particles for all four variants at once, and every
+//     lane ends with ONE FINISHED sum per tile: (node l >> 4, amplitude 4 tile + (l & 3), variant
+//     (l >> 2) & 3).  No cross-block sum, no second traversal, one flush decision per run, and the
+//     J and rho values of a node (one 128-B record of the in-step target) leave in the same atomic
+//     instruction.
+//   * the panel holds per particle and engine the FIRST shape factor of each direction only
+//     (linear shape: the second one is 1 - first, formed by an fma on read): s = Sz[0], t0 / th =
+//     Sr[0] with the Ruyten coefficient of mode 0 / of the modes >= 1, then the amplitudes.
+//     Nm = 2: 18 rows x 66 doubles = 9.3 KB per wave (DepEngine: 7.8 KB for J alone).
+//   * two cells that follow each other along r share a node column: its sums MOVE to the lanes of
+//     the lower column (v_permlane16_swap: node = lane >> 4, the two columns are 16 lanes apart)
+//     instead of the lanes changing role - no per-lane state depends on the run.
+//   * a stray (a particle that has left the stencil of its home cell, per engine) is written out
+//     directly as before (lane = node x amplitude x variant); its amplitudes are then zeroed in the
+//     panel, so the products need no per-particle mask - only the last step of a run masks the
+//     particles of the next one.
+// Lane layout of v_mfma_f64_4x4x4_4b (tools/mfma4_probe.hip): A operand lane l = A[i = l & 3][k = l >> 4]
+// of block (l >> 2) & 3, B operand lane l = B[k = l >> 4][j = l & 3] of the same block, D lane l =
+// D[i = l >> 4][j = l & 3] of the same block.
+//
+// Per-particle arithmetic (cos, sin, mode recurrence, shape factors, Ruyten term, cell keys) is that of
+// DepEngine::stage_with, i.e. fbpic/particles/deposition/threading_methods.py:27-305 and
+// particle_shapes.py:17-41; guard folding and axis signs are those of DepEngine::flush_values
+// (fbpic/fields/numba_methods.py:409-461).  Only the summation order differs.
+#pragma once
+#include "dep_engine.h"
+
+namespace fb {
+
+template <int NM> struct CycleDepLayout {
+    static constexpr int NAJ0 = 3, NAJH = 6 * (NM - 1), NAR0 = 1, NARH = 2 * (NM - 1);
+    static constexpr int NTR = (NM > 1) ? 2 : 1;           // radial factor rows per engine: t0 [, th]
+    static constexpr int ROW_SJ = 0, ROW_TJ = 1, ROW_AJ = 1 + NTR;
+    static constexpr int ROW_SR = ROW_AJ + NAJ0 + NAJH, ROW_TR = ROW_SR + 1, ROW_AR = ROW_SR + 1 + NTR;
+    static constexpr int NROWS = ROW_AR + NAR0 + NARH;
+    // row stride in doubles: the (row, particle) pairs of a fragment read - up to 16 rows x 4
+    // consecutive particles - fall two by two on the 32 bank pairs (the rate of a 64-lane b64 read)
+    static constexpr int PAD = 66;
+    // tiles of 4 amplitudes: the largest variant decides (J, modes >= 1)
+    static constexpr int NTL = (NAJH > 4) ? (NAJH + 3) / 4 : 1;
+    static constexpr int WAVE_DOUBLES = NROWS * PAD + 4;
+    __host__ __device__ static constexpr int namp(int v) { return v == 0 ? NAJ0 : v == 1 ? NAJH : v == 2 ? NAR0 : NARH; }
+    __host__ __device__ static constexpr int amp_row0(int v)
+    {
+        return v == 0 ? ROW_AJ : v == 1 ? ROW_AJ + NAJ0 : v == 2 ? ROW_AR : ROW_AR + NAR0;
+    }
+};
+
+template <int NM>
+struct CycleDep {
+    using L = CycleDepLayout<NM>;
+    static constexpr int NTL = L::NTL, PAD = L::PAD;
+
+    char *P;                       // the wave's panel (LDS)
+    char *gbase;                   // lowest address of the J and rho targets (all within 4 GiB of it)
+    int lane;
+    int rsB, csB, Nz, Nr;
+    // A / B operand roles: byte offsets of this lane's rows, particle (l >> 4) of a step included
+    int aS, aT, aB[NTL];
+    int k8, kA;                    // 8 (l >> 4); l >> 4
+    double cz0, cz1, cr0, cr1;     // A role, node l & 3: Sz[jz] = cz0 + cz1 s, Sr[jr] = cr0 + cr1 t
+    // D role: target of tile t as a byte offset from gbase (node row jzD included), validity and
+    // below-axis sign as bit masks, node (jzD, jrD), engine
+    unsigned f_off[NTL];
+    unsigned valid, neg;
+    int jzD, jrD, jrDB;
+    bool engR, evenrow;
+    double acc[NTL];
+    int cur_z, cur_r, cur_nb;
+
+    // aS, aT, aB are absolute LDS byte addresses (the panel base folded in once): a fragment read is
+    // one v_add (+ 8 q) per row and immediate offsets for the steps of a group
+    typedef __attribute__((address_space(3))) const double lds_cdouble;
+    __device__ __forceinline__ double ld(int addr) const { return *(lds_cdouble *)(unsigned long)(unsigned)addr; }
+
+    __device__ __forceinline__ void init(double *panel, int lane_, const DepGrids &GJ, long rsJ, const DepGrids &GR,
+                                         long rsR, int Nz_, int Nr_, cplx *gbase_)
+    {
+        P = (char *)panel;
+        gbase = (char *)gbase_;
+        lane = lane_;
+        // (both targets are views of one record array: same strides - checked by the host)
+        rsB = (int)(16 * rsJ); csB = (int)(16 * GJ.cs);
+        Nz = Nz_; Nr = Nr_;
+        const int v = (lane >> 2) & 3, e = v >> 1, vh = v & 1, j = lane & 3;
+        kA = lane >> 4; k8 = 8 * kA;
+        const int pl = (int)(unsigned long)(__attribute__((address_space(3))) char *)P + k8;
+        aS = (e ? L::ROW_SR : L::ROW_SJ) * PAD * 8 + pl;
+        aT = ((e ? L::ROW_TR : L::ROW_TJ) + ((L::NTR > 1) ? vh : 0)) * PAD * 8 + pl;
+        const int na = L::namp(v), r0 = L::amp_row0(v);
+        valid = 0u; neg = 0u;
+        const int iD = lane >> 4;
+        jzD = iD >> 1; jrD = iD & 1; jrDB = jrD * csB;
+        engR = e != 0;
+        evenrow = jrD == 0;
+#pragma unroll
+        for (int t = 0; t < NTL; t++) {
+            const int a = 4 * t + j;
+            const bool ok = a < na;
+            aB[t] = (na > 0 ? r0 + (ok ? a : na - 1) : 0) * PAD * 8 + pl;
+            // amplitude a of variant v -> component, mode, re / im (rows as DepLayout::row)
+            int comp = 0, m = 0, ri = 0;
+            if (ok) {
+                if (v == 0) { comp = a; }
+                else if (v == 1) { ri = a & 1; comp = (a >> 1) % 3; m = 1 + (a >> 1) / 3; }
+                else if (v == 3) { ri = a & 1; m = 1 + (a >> 1); }
+            }
+            double *fp = e ? (double *)GR.g[m] : (double *)GJ.g[comp + 3 * m];
+            fp += ri;
+            f_off[t] = (unsigned)((char *)fp - gbase) + (unsigned)(jzD * rsB);
+            valid |= ok ? (1u << t) : 0u;
+            // rho, Jz: (-1)^m ; Jr, Jt: -(-1)^m (threading_methods.py:143-146, 289-302)
+            const double flip = m1pow(m);
+            neg |= (((e || comp == 2) ? flip : -flip) < 0.) ? (1u << t) : 0u;
+            acc[t] = 0.;
+        }
+        // (opaque to the optimiser: it would otherwise split the constant row offsets off again and
+        // re-add them, and the panel base, in front of every read)
+        asm volatile("" : "+v"(aS), "+v"(aT));
+#pragma unroll
+        for (int t = 0; t < NTL; t++) asm volatile("" : "+v"(aB[t]));
+        const int iA = lane & 3, jzA = iA >> 1, jrA = iA & 1;
+        cz0 = jzA ? 1. : 0.; cz1 = jzA ? -1. : 1.;
+        cr0 = jrA ? 1. : 0.; cr1 = jrA ? -1. : 1.;
+        cur_z = DEP_NOKEY; cur_r = DEP_NOKEY; cur_nb = 0;
+        // The last step of a run reads up to 3 particles beyond it (masked weights, but the values
+        // must be finite): columns 64, 65 of every row and the 4 doubles behind the last row are
+        // never staged - zero them once.
+        if (lane < L::NROWS) {
+            *(double *)(P + (lane * PAD + 64) * 8) = 0.;
+            *(double *)(P + (lane * PAD + 65) * 8) = 0.;
+        }
+        if (lane < 4) *(double *)(P + (L::NROWS * PAD + lane) * 8) = 0.;
+    }
+
+    // ---- phase 1, lane = particle: amplitudes, first shape factors, stencil key of engine E
+    // (0: J, 1: rho) - the arithmetic of DepEngine::stage_with.  u, ig, c_light only for J.
+    template <int E>
+    __device__ __forceinline__ void stage(double xj, double yj, double zj, double wj,
+            double ux, double uy, double uz, double ig, double c_light, const DepGeom &g,
+            double beta0_v, double betah_v, int &my_kz, int &my_kr, int &my_nb)
+    {
+        constexpr int NC = (E == 0) ? 3 : 1;
+        constexpr int R0 = (E == 0) ? L::ROW_AJ : L::ROW_AR;           // mode 0 (real parts only)
+        constexpr int RH = R0 + NC;                                    // modes >= 1
+        double *Pd = (double *)P;
+        const double rj = sqrt(xj * xj + yj * yj);
+        double cs_, sn;
+        if (rj != 0.) {
+            double r0 = __builtin_amdgcn_rcp(rj);
+            r0 = __builtin_fma(r0, __builtin_fma(-rj, r0, 1.), r0);
+            const double invr = __builtin_fma(r0, __builtin_fma(-rj, r0, 1.), r0);
+            cs_ = xj * invr; sn = yj * invr;
+        } else { cs_ = 1.; sn = 0.; }
+        double are[NC], aim[NC];
+        if constexpr (NC == 1) {
+            are[0] = wj; aim[0] = 0.;
+        } else {
+            are[0] = wj * c_light * ig * (cs_ * ux + sn * uy); aim[0] = 0.;
+            are[1] = wj * c_light * ig * (cs_ * uy - sn * ux); aim[1] = 0.;
+            are[2] = wj * c_light * ig * uz; aim[2] = 0.;
+        }
+#pragma unroll
+        for (int mm = 0; mm < NM; mm++) {
+#pragma unroll
+            for (int k = 0; k < NC; k++) {
+                if (mm == 0) Pd[(R0 + k) * PAD + lane] = are[k];
+                else {
+                    Pd[(RH + ((mm - 1) * NC + k) * 2) * PAD + lane] = are[k];
+                    Pd[(RH + ((mm - 1) * NC + k) * 2 + 1) * PAD + lane] = aim[k];
+                }
+                const double re = cs_ * are[k] - sn * aim[k], im = cs_ * aim[k] + sn * are[k];
+                are[k] = re; aim[k] = im;
+            }
+        }
+        const double r_cell = g.invdr * (rj - g.rmin) - 0.5;
+        const double z_cell = g.invdz * (zj - g.zmin) - 0.5;
+        const int icr = (int)ceil(r_cell), icz = (int)ceil(z_cell);
+        my_kr = min(icr - 1, Nr); my_kz = icz - 1;
+        my_nb = 1 - icr;
+        double Sz[2], Sr0[2], Srh[2];
+        shape_z<FB_SHAPE_LINEAR>(z_cell, Sz);
+        shape_r<FB_SHAPE_LINEAR>(r_cell, beta0_v, Sr0);
+        constexpr int RS = (E == 0) ? L::ROW_SJ : L::ROW_SR, RT = (E == 0) ? L::ROW_TJ : L::ROW_TR;
+        Pd[RS * PAD + lane] = Sz[0];
+        Pd[RT * PAD + lane] = Sr0[0];
+        if constexpr (NM > 1) {
+            shape_r<FB_SHAPE_LINEAR>(r_cell, betah_v, Srh);
+            Pd[(RT + 1) * PAD + lane] = Srh[0];
+        }
+    }
+
+    // zero the amplitudes of the lanes (= particles) that take no part in the runs of an engine
+    __device__ __forceinline__ void zero_amplitudes(bool notJ, bool notR)
+    {
+        double *Pd = (double *)P;
+        if (notJ) {
+#pragma unroll
+            for (int a = 0; a < L::NAJ0 + L::NAJH; a++) Pd[(L::ROW_AJ + a) * PAD + lane] = 0.;
+        }
+        if (notR) {
+#pragma unroll
+            for (int a = 0; a < L::NAR0 + L::NARH; a++) Pd[(L::ROW_AR + a) * PAD + lane] = 0.;
+        }
+    }
+
+    // ---- flush of the current cell: one atomic instruction per tile.  keep_upper: only its lower
+    // node column (the upper one carries on as the lower column of the next cell)
+    __device__ __forceinline__ void flush(bool keep_upper)
+    {
+        if (cur_z == DEP_NOKEY) return;
+        const int cz = cur_z, cr = cur_r;
+        const bool interior = cz >= 0 && cz + 2 <= Nz && cr >= 0 && cr + 2 <= Nr;
+        const int cell_baseB = cz * rsB + cr * csB;       // wave-uniform: scalar arithmetic
+#pragma unroll
+        for (int t = 0; t < NTL; t++) {
+            double v = acc[t];
+            if (!((valid >> t) & 1u) || v == 0. || (keep_upper && !evenrow)) continue;
+            unsigned voff;
+            if (interior) {
+                voff = f_off[t] + (unsigned)(cell_baseB + jrDB);
+            } else {
+                int gz = cz + jzD, gr = cr + jrD;
+                fold_node(gz, gr, Nz, Nr);
+                if (jrD < cur_nb && ((neg >> t) & 1u)) v = -v;      // node below the axis: signed fold
+                voff = f_off[t] + (unsigned)((gz - jzD) * rsB + gr * csB);
+            }
+            atomicAdd((double *)(gbase + voff), v);
+        }
+    }
+
+    // value of the lane 16 further on (node column jr = 1 of the same node row) for the lanes of
+    // column 0; v_permlane16_swap: vdst keeps its even rows of 16 and receives the even rows of src in
+    // its odd rows, src the reverse (particles.hip, other_xor16)
+    __device__ __forceinline__ double upper_column(double v) const
+    {
+        const int lo = __double2loint(v), hi = __double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        return __hiloint2double(b[1], a[1]);
+    }
+
+    // ---- one group of NST steps of 4 particles, first particle q (byte offset q8 = 8 q), rem = e - q
+    // particles of the run left.  MASK: the last step holds particles of the next run.
+    template <int NST, bool MASK>
+    __device__ __forceinline__ void group(int q8, int rem)
+    {
+        double s[NST], t[NST], b[NST][NTL];
+        const int oS = aS + q8, oT = aT + q8;
+        int oB[NTL];
+#pragma unroll
+        for (int tl = 0; tl < NTL; tl++) oB[tl] = aB[tl] + q8;
+#pragma unroll
+        for (int u = 0; u < NST; u++) {
+            s[u] = ld(oS + 32 * u);
+            t[u] = ld(oT + 32 * u);
+#pragma unroll
+            for (int tl = 0; tl < NTL; tl++) b[u][tl] = ld(oB[tl] + 32 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < NST; u++) {
+            double w = __builtin_fma(s[u], cz1, cz0) * __builtin_fma(t[u], cr1, cr0);
+            if (MASK && u == NST - 1) w = (kA < rem - 4 * u) ? w : 0.;
+#pragma unroll
+            for (int tl = 0; tl < NTL; tl++) acc[tl] = __builtin_amdgcn_mfma_f64_4x4x4f64(w, b[u][tl], acc[tl], 0, 0, 0);
+        }
+    }
+    // acc += W . amplitudes over the staged particles [p, e) (one run)
+    __device__ __forceinline__ void product(int p, int e)
+    {
+#ifndef FB_CD_GROUP
+#define FB_CD_GROUP 4
+#endif
+        for (int q = p; q < e; q += 4 * FB_CD_GROUP) {
+            const int rem = e - q;
+            if (rem >= 4 * FB_CD_GROUP) group<FB_CD_GROUP, false>(8 * q, rem);
+#if FB_CD_GROUP >= 4
+            else if (rem > 12) group<4, true>(8 * q, rem);
+#endif
+#if FB_CD_GROUP >= 3
+            else if (rem > 8) group<3, true>(8 * q, rem);
+#endif
+#if FB_CD_GROUP >= 2
+            else if (rem > 4) group<2, true>(8 * q, rem);
+#endif
+            else group<1, true>(8 * q, rem);
+        }
+    }
+
+    // ---- phase 2: ONE traversal of the home runs for both engines.  runstarts: lanes where the home
+    // cell changes; homem: particles that take part in a run of either engine (the amplitudes of the
+    // others are zero in the panel); hkz, hkr, hnb: stencil key of the lane's home cell.
+    __device__ __forceinline__ void reduce(int cnt, unsigned long long runstarts, unsigned long long homem,
+                                           int hkz, int hkr, int hnb)
+    {
+        int p = 0;
+        while (p < cnt) {
+            const unsigned long long rest = (p + 1 < 64) ? (runstarts >> (p + 1)) : 0ull;
+            int e = rest ? p + 1 + __builtin_ctzll(rest) : cnt;
+            if (e > cnt) e = cnt;
+            const unsigned long long span = ((e - p) >= 64 ? ~0ull : ((1ull << (e - p)) - 1ull)) << p;
+            if (homem & span) {
+                const int nz_ = __builtin_amdgcn_readlane(hkz, p);
+                const int nr_ = __builtin_amdgcn_readlane(hkr, p);
+                if (nz_ == cur_z && nr_ == cur_r) {
+                    // the run of the previous chunk goes on
+                } else if (nz_ == cur_z && nr_ == cur_r + 1) {
+                    flush(true);                     // column cur_r is complete
+#pragma unroll
+                    for (int t = 0; t < NTL; t++) {
+                        const double up = upper_column(acc[t]);
+                        acc[t] = evenrow ? up : 0.;
+                    }
+                    cur_r = nr_;
+                    cur_nb = __builtin_amdgcn_readlane(hnb, p);
+                } else {
+                    flush(false);
+#pragma unroll
+                    for (int t = 0; t < NTL; t++) acc[t] = 0.;
+                    cur_z = nz_;
+                    cur_r = nr_;
+                    cur_nb = __builtin_amdgcn_readlane(hnb, p);
+                }
+                product(p, e);
+            }
+            p = e;
+        }
+    }
+
+    // ---- strays: staged particle l (wave-uniform) written out directly - lane = (node l >> 4,
+    // amplitude, variant), value = (Sz Sr) amplitude from the staged rows, one atomic instruction per
+    // tile for BOTH engines where the particle is a stray of both (keys per engine).
+    __device__ __forceinline__ void scatter_strays(unsigned long long smJ, unsigned long long smR,
+            int jkz, int jkr, int jnb, int rkz, int rkr, int rnb)
+    {
+        unsigned long long um = smJ | smR;
+        while (um) {
+            const int l = __builtin_ctzll(um);
+            um &= um - 1ull;
+            const bool inJ = (smJ >> l) & 1ull, inR = (smR >> l) & 1ull;
+            const int zJ = __builtin_amdgcn_readlane(jkz, l), rJ = __builtin_amdgcn_readlane(jkr, l);
+            const int nJ = __builtin_amdgcn_readlane(jnb, l);
+            const int zR = __builtin_amdgcn_readlane(rkz, l), rR = __builtin_amdgcn_readlane(rkr, l);
+            const int nR = __builtin_amdgcn_readlane(rnb, l);
+            const bool mine = engR ? inR : inJ;
+            const int so = 8 * l - k8;
+            // (D role, node l >> 4: the second factor of a direction is 1 - first)
+            const double s_ = ld(aS + so), t_ = ld(aT + so);
+            const double wz = jzD ? 1. - s_ : s_;
+            const double wr = jrD ? 1. - t_ : t_;
+            const double w = wz * wr;
+            const bool intJ = zJ >= 0 && zJ + 2 <= Nz && rJ >= 0 && rJ + 2 <= Nr;
+            const bool intR = zR >= 0 && zR + 2 <= Nz && rR >= 0 && rR + 2 <= Nr;
+            const bool interior = (intJ || !inJ) && (intR || !inR);
+            const int baseJ = zJ * rsB + rJ * csB, baseR = zR * rsB + rR * csB;
+#pragma unroll
+            for (int t = 0; t < NTL; t++) {
+                double v = w * ld(aB[t] + so);
+                if (!mine || !((valid >> t) & 1u) || v == 0.) continue;
+                unsigned voff;
+                if (interior) {
+                    voff = f_off[t] + (unsigned)((engR ? baseR : baseJ) + jrDB);
+                } else {
+                    const int kz = engR ? zR : zJ, kr = engR ? rR : rJ, nb = engR ? nR : nJ;
+                    int gz = kz + jzD, gr = kr + jrD;
+                    fold_node(gz, gr, Nz, Nr);
+                    if (jrD < nb && ((neg >> t) & 1u)) v = -v;
+                    voff = f_off[t] + (unsigned)((gz - jzD) * rsB + gr * csB);
+                }
+                atomicAdd((double *)(gbase + voff), v);
+            }
+        }
+    }
+};
+
+}  // namespace fb

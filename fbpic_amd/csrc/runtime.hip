@@ -21,7 +21,7 @@ int check(hipError_t e, const char *where)
 
 }  // namespace fb
 
-extern "C" int fb_abi_version(void) { return 1; }
+extern "C" int fb_abi_version(void) { return FB_ABI_VERSION; }
 extern "C" const char *fb_last_error(void) { return fb::g_err; }
 extern "C" int fb_set_device(int device) { return fb::check(hipSetDevice(device), "fb_set_device"); }
 extern "C" int fb_sync(void *stream)

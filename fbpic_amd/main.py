@@ -368,13 +368,14 @@ class Simulation(object):
 
     def _one_pass_ok(self, correct_currents, use_true_rho, cross):
         """Whether the particle work of this iteration can be the single pass of
-        Particles.cycle: grids that do not move between the gather and the depositions, the
-        in-step (record) deposition target, nothing on a second stream waiting for a split
-        gather, every species supported by the kernel."""
+        Particles.cycle: grids that do not move between the gather and the depositions (a Galilean
+        grid does; a moving window advances at the END of an iteration, main.py:559-563 - between
+        iterations the home cells are re-keyed, Particles._home_shift), the in-step (record)
+        deposition target, nothing on a second stream waiting for a split gather, every species
+        supported by the kernel."""
         fld, comm = self.fld, self.comm
         if not (self.one_pass_cycle and not self.reference_sequence and not cross
-                and not self.use_galilean and comm.moving_win is None
-                and self.particle_shape == 'linear'):
+                and not self.use_galilean and self.particle_shape == 'linear'):
             return False
         if comm.size > 1 and ((correct_currents is False) or (use_true_rho is True)):
             return False             # those deposits exchange their guard cells on the interpolation grid

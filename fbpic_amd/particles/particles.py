@@ -481,7 +481,7 @@ class Particles(object):
             if part == 'inside':
                 return                      # the book-keeping below belongs to the completed pass
         elif ranked and self._home_valid and rank_next == (dt_x, 1., 1., 1.) \
-                and self._home_geom == (g0.zmin, g0.invdz, g0.Nz, g0.rmin, g0.invdr, g0.Nr) \
+                and self._home_shift(g0) is not None \
                 and _capi.lib().fb_gather_push_deposit_supported(_SHAPE[self.particle_shape], Nm):
             # arrays sorted some steps ago (a sorting iteration of the one-pass cycle): segments
             # from the home cells, which a stale order does not fragment
@@ -491,7 +491,8 @@ class Particles(object):
                 comm.get_rmax(with_damp=False), g0.invdz, g0.zmin, g0.Nz, g0.invdr, g0.rmin, g0.Nr,
                 _capi.ptr_array(views), _capi.row_stride(views[0]), *eb,
                 self.q, self.m, c, self.dt, dt_x, wz[0], wz[1], self.prefix_sum.shape[0],
-                p(self._sort_ws), self._sort_ws.shape[0], int(self._counts_clean), _capi.stream())
+                p(self._sort_ws), self._sort_ws.shape[0], int(self._counts_clean),
+                self._home_shift(g0), _capi.stream())
             self._counts_clean = False
             _capi.check(rc, 'fb_gather_push_rank_next_home')
         elif ranked:
@@ -525,6 +526,21 @@ class Particles(object):
                     and (self.q == 0 or _capi.lib().fb_gather_push_deposit_supported(
                         _SHAPE[self.particle_shape], Nm)))
 
+    def _home_shift(self, g0):
+        """(Cells the grid has advanced since the home cells were recorded) x (Nr + 1) - the moving
+        window translates the grid by whole cells (boundaries/moving_window.py:60-239), so the
+        recorded cell of a particle that stays where it is moves that many rows down and the kernels
+        subtract the product from every home cell.  None: the recorded cells belong to another grid
+        (re-sort)."""
+        hg = getattr(self, '_home_geom', None)
+        if hg is None or tuple(hg[1:]) != (g0.invdz, g0.Nz, g0.rmin, g0.invdr, g0.Nr):
+            return None
+        d = (g0.zmin - hg[0]) * g0.invdz
+        n_move = int(round(d))
+        if abs(d - n_move) > 1.e-6 or abs(n_move) >= g0.Nz:
+            return None
+        return n_move * (g0.Nr + 1)
+
     def _cycle_poll(self):
         """Pick up the stray count of an earlier pass if its copy has landed."""
         st = self._cycle_stats
@@ -551,8 +567,8 @@ class Particles(object):
     def _cycle_needs_sort(self, g0):
         if not self._home_valid or self._cycle_since_sort >= self.cycle_sort_period:
             return True
-        if self._home_geom != (g0.zmin, g0.invdz, g0.Nz, g0.rmin, g0.invdr, g0.Nr):
-            return True                      # the grid moved: the recorded cells are not cells any more
+        if self._home_shift(g0) is None:
+            return True                      # another grid: the recorded cells are not cells any more
         self._cycle_poll()
         return (self.cycle_stray_fraction is not None
                 and self.cycle_stray_fraction > self.cycle_stray_limit)
@@ -612,7 +628,7 @@ class Particles(object):
             self.q, self.m, c, self.dt, 0.5 * dt, wz[0], wz[1],
             _capi.ptr_array(jv), jv[0].stride(0), jv[0].stride(1),
             _capi.ptr_array(rv), rv[0].stride(0), rv[0].stride(1), p(ruy0), p(ruyh),
-            p(stats[0]) if measure else None, st)
+            p(stats[0]) if measure else None, self._home_shift(g0), st)
         _capi.check(rc, 'fb_gather_push_deposit_J_rho')
         if measure:
             stats[1].copy_(stats[0], non_blocking=True)

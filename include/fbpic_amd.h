@@ -34,6 +34,9 @@ extern "C" {
 #define FB_HANDOVER_HEADER 8
 
 /* ---- runtime ---------------------------------------------------------------- */
+/* revision of this header; fb_abi_version() returns the one the library was built from (the
+ * Python binding refuses a library of another revision) */
+#define FB_ABI_VERSION 5
 int fb_abi_version(void);
 const char *fb_last_error(void);
 /* utils/cuda.py:261-299 (GPU selection) -> explicit device binding per process */
@@ -363,6 +366,9 @@ int fb_push_x_sort_deposit_J_rho(long n, int ncell, const double *x, const doubl
  * cell are gathered / deposited on their own.  Any `home_cell` content gives the same result; how
  * many particles take the slow path is what changes, and `stats` (optional, 1024 counters that
  * the call ADDS to) receives their number for the caller's re-sort policy.
+ * `home_cell_shift` is subtracted from every home cell before use: n_move (Nr + 1) when the grid
+ * has advanced by n_move cells since the sort (moving window, boundaries/moving_window.py:60-239 -
+ * the cell of a particle that stays where it is moves n_move rows down), 0 otherwise.
  * Linear shape, Nm <= 4 (fb_gather_push_deposit_supported). */
 int fb_gather_push_deposit_supported(int shape, int Nm);
 int fb_gather_push_deposit_J_rho(int shape, int Nm, long n,
@@ -377,7 +383,7 @@ int fb_gather_push_deposit_J_rho(int shape, int Nm, long n,
                                  void *const *J, long J_row_stride, long J_col_stride,
                                  void *const *rho, long rho_row_stride, long rho_col_stride,
                                  const double *ruyten_m0, const double *ruyten_mh,
-                                 unsigned long long *stats, void *stream);
+                                 unsigned long long *stats, int home_cell_shift, void *stream);
 
 /* fb_gather_push_rank_next for arrays that were cell-sorted some steps ago (csrc/cycle.hip): the same
  * results - momenta, x(n+1/2), and cell + rank of x(n+1) in `sort_workspace`, ranks of a cell in a
@@ -394,7 +400,8 @@ int fb_gather_push_rank_next_home(int shape, int Nm, long n,
                                   double *Ex, double *Ey, double *Ez, double *Bx, double *By, double *Bz,
                                   double q, double m, double c, double dt, double dt_x,
                                   double wrap_zmin, double wrap_zmax, int ncell, void *sort_workspace,
-                                  size_t workspace_bytes, int counts_are_zero, void *stream);
+                                  size_t workspace_bytes, int counts_are_zero, int home_cell_shift,
+                                  void *stream);
 
 /* fb_deposit_J that also prepares the counting sort which Simulation.step runs after the
  * next push_x (main.py:515-528: deposit J, push_x(dt/2), re-sort for deposit rho_next): for

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in decl:
         assert hasattr(lib, name), name
     assert sorted(_capi.EXPORTS) == decl
-    assert lib.fb_abi_version() == 1
+    assert lib.fb_abi_version() == _capi.ABI_VERSION
 
 
 def test_no_cpu_fallback():

@@ -111,11 +111,15 @@ def test_one_pass_equals_the_four_entry_points(hip, oracle, Nm, records, stale, 
     F = [t.zeros(n, dtype=t.float64, device='cuda') for _ in range(6)]
     stats = t.zeros(1024, dtype=t.int64, device='cuda')
     base, jv, rv = target()
+    # home cells recorded n_move rows further up, as after n_move steps of a moving window: the
+    # kernel subtracts `shift` again (same runs, same stray count as with shift 0)
+    shift = (Nm + 1) * (Nr + 1)
+    home = home + shift
     hip.check(hip.lib().fb_gather_push_deposit_J_rho(
         1, Nm, n, p(a[0]), p(a[1]), p(a[2]), p(a[3]), p(a[4]), p(a[5]), p(a[7]), p(a[6]), p(home),
         rmax_gather, *geom, hip.ptr_array(views), views[0].stride(0), *[p(f) for f in F], q, m, c, dt, 0.5 * dt,
         zlo, zhi, hip.ptr_array(jv), jv[0].stride(0), jv[0].stride(1), hip.ptr_array(rv), rv[0].stride(0),
-        rv[0].stride(1), p(ruy0), p(ruyh), p(stats), hip.stream()), 'one pass')
+        rv[0].stride(1), p(ruy0), p(ruyh), p(stats), shift, hip.stream()), 'one pass')
     # ---- the sequence it replaces
     b = [dev(hip, v) for v in state]
     F2 = [t.zeros(n, dtype=t.float64, device='cuda') for _ in range(6)]
@@ -201,7 +205,7 @@ def test_one_pass_without_wrap_and_without_stored_fields(hip):
             1, Nm, n, p(a[0]), p(a[1]), p(a[2]), p(a[3]), p(a[4]), p(a[5]), p(a[7]), p(a[6]), p(home),
             Nr * dzc, *geom, hip.ptr_array(views), views[0].stride(0), *[p(f) if store else None for f in F], -e, m_e, c,
             dt, 0.5 * dt, 0., 0., hip.ptr_array(jv), jv[0].stride(0), jv[0].stride(1), hip.ptr_array(rv),
-            rv[0].stride(0), rv[0].stride(1), p(ruy), p(ruy), None, hip.stream()), 'one pass')
+            rv[0].stride(0), rv[0].stride(1), p(ruy), p(ruy), None, 0, hip.stream()), 'one pass')
         out.append(([host(v) for v in a], host(rec)))
     for u, v in zip(out[0][0], out[1][0]):
         assert np.array_equal(u, v)
@@ -306,7 +310,7 @@ def test_gather_push_rank_next_home_equals_gather_push_rank_next(hip, oracle, Nm
             hip.check(hip.lib().fb_gather_push_rank_next_home(
                 1, Nm, n, p(a[0]), p(a[1]), p(a[2]), p(a[3]), p(a[4]), p(a[5]), p(a[7]), p(home), Nr * dzc, *geom,
                 hip.ptr_array(views), views[0].stride(0), *[p(f) for f in F], -e, m_e, c, dt, 0.5 * dt, zlo, zhi,
-                ncell, p(work), nb, 0, hip.stream()), 'rank_next_home')
+                ncell, p(work), nb, 0, 0, hip.stream()), 'rank_next_home')
         else:
             hip.check(hip.lib().fb_gather_push_rank_next(
                 1, Nm, n, p(a[0]), p(a[1]), p(a[2]), p(a[3]), p(a[4]), p(a[5]), p(a[7]), Nr * dzc, *geom,

@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-section static instruction census of k_cycle_linear<Nm> (sections = the FB_MARK points of cycle.hip)
 NM=${1:-2}
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -mllvm -amdgpu-mfma-vgpr-form=1 -DFB_ISA_MARKS \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -mllvm -amdgpu-mfma-vgpr-form=1 -mllvm -amdgpu-sched-strategy=max-memory-clause -DFB_ISA_MARKS \
   -I/root/repo/include -I/root/repo/fbpic_amd/csrc -S --cuda-device-only -o /tmp/isa_cycle_marks.s /root/repo/fbpic_amd/csrc/cycle.hip 2>/dev/null
 python3 - $NM <<'PY'
 import re, sys, collections
