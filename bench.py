@@ -256,50 +256,63 @@ def main():
     n_order = -1 if world == 1 else 32
     if args.config == 'C3':
         return bench_c3(args, torch, world, rank)
-    # weak scaling: every rank owns args.Nz cells; strong: the args.Nz cells are divided.
-    # The Simulation is given the global box either way.
-    Nz_global = args.Nz * world if args.scaling == 'weak' else args.Nz
-    sim = helpers.uniform_plasma_sim(Nz_global, args.Nr, args.Nm, ppc, args.shape, seed=0,
-                                     n_order=n_order, n_guard=(None if world == 1 else 64))
-    if args.reference_sequence:
-        sim.redeposit_rho_prev_every_step = True
-        sim.fuse_gather_push = False
-        sim.prerank_in_deposit = False
-        sim.reference_sequence = True
-        for sp in sim.ptcl:
-            sp.fuse_sort_deposit_rho = False
-    if args.resort_fragmentation is not None:
-        for sp in sim.ptcl:
-            sp.resort_fragmentation = args.resort_fragmentation
-    n_local = sum(s.Ntot for s in sim.ptcl)
-    n_total = n_local
-    if world > 1:
-        tcount = torch.tensor([n_local], dtype=torch.int64,
-                              device=('cuda' if dist.get_backend() == 'nccl' else 'cpu'))
-        dist.all_reduce(tcount)
-        n_total = int(tcount.item())
-    cpu_base = None
-    if rank == 0 and not args.no_cpu_baseline and world == 1:
-        cpu_base = cpu_baseline(sim, args)
-
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def build(scaling):
+        # weak scaling: every rank owns args.Nz cells; strong: the args.Nz cells are divided.
+        # The Simulation is given the global box either way.
+        Nz_g = args.Nz * world if scaling == 'weak' else args.Nz
+        sm = helpers.uniform_plasma_sim(Nz_g, args.Nr, args.Nm, ppc, args.shape, seed=0,
+                                        n_order=n_order, n_guard=(None if world == 1 else 64))
+        if args.reference_sequence:
+            sm.redeposit_rho_prev_every_step = True
+            sm.fuse_gather_push = False
+            sm.prerank_in_deposit = False
+            sm.reference_sequence = True
+            for sp in sm.ptcl:
+                sp.fuse_sort_deposit_rho = False
+        if args.resort_fragmentation is not None:
+            for sp in sm.ptcl:
+                sp.resort_fragmentation = args.resort_fragmentation
+        n_loc = sum(s_.Ntot for s_ in sm.ptcl)
+        n_tot = n_loc
+        if world > 1:
+            tcount = torch.tensor([n_loc], dtype=torch.int64,
+                                  device=('cuda' if dist.get_backend() == 'nccl' else 'cpu'))
+            dist.all_reduce(tcount)
+            n_tot = int(tcount.item())
+        return sm, Nz_g, n_tot
+
+    def max_over_ranks(seconds):
+        if world > 1:
+            tt = torch.tensor([seconds], dtype=torch.float64,
+                              device=('cuda' if dist.get_backend() == 'nccl' else 'cpu'))
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
+        return seconds
+
+    sim, Nz_global, n_total = build(args.scaling)
+    cpu_base = None
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        cpu_base = cpu_baseline(sim, args)
+
     # decomposed run: the warm-up also covers the first particle hand-over between the ranks
     # (every `exchange_period` steps; its first execution pays one-time start-up costs, ~3 ms)
     warm = args.warmup if world == 1 else max(args.warmup, sim.comm.exchange_period + 2)
-    # The ceilings of this box (fp64 triad, 4096^3 dgemm) are measured BEFORE the timed region:
-    # ~1 s of full load brings the GPU out of its idle clock state, which a 5-step warm-up (2 ms)
-    # does not - extra.repeat_ms_per_step of round-3-style lines fell 0.48 -> 0.45 -> 0.44 ms over
-    # three back-to-back timed calls of the same kernels.
+    # The ceilings of this box (fp64 triad, 4096^3 dgemm) are measured BEFORE the timed region, on
+    # every run whatever --no-kernel-timing says (extra.preheat): ~1 s of full load brings the GPU out
+    # of its idle clock state, which a 5-step warm-up (2 ms) does not - extra.repeat_ms_per_step of
+    # round-3-style lines fell 0.48 -> 0.45 -> 0.44 ms over three back-to-back timed calls of the
+    # same kernels.
     with GpuMemoryManager(sim):
         # (inside the block: after the host -> device copies, nothing but the warm-up steps between
         # this load and the timed region)
         _sysfs_card()           # (resolves the device's sysfs directory once: a rocm-smi process)
-        ceil = measured_ceilings(torch) if (rank == 0 or world > 1) and not args.no_kernel_timing else None
+        ceil = measured_ceilings(torch)
         sim.step(warm)
         finish_outputs(sim)     # the warm-up is the timed call's twin
         barrier()
@@ -326,11 +339,35 @@ def main():
             _capi.enable_timing()
             sim.step(10)     # enough launches for a stable mean (durations vary ~15% per step)
             kern = _capi.collect_timing()
-    if world > 1:
-        tt = torch.tensor([dt_wall], dtype=torch.float64,
-                          device=('cuda' if dist.get_backend() == 'nccl' else 'cpu'))
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt_wall = float(tt.item())
+    dt_wall = max_over_ranks(dt_wall)
+    passes = {'one_pass': sum(s_.cycle_passes for s_ in sim.ptcl),
+              'sorting_two_pass': sum(s_.cycle_sorts for s_ in sim.ptcl),
+              'sort_period': sim.ptcl[0].cycle_sort_period if sim.ptcl else None,
+              'last_stray_fraction': max((s_.cycle_last_stray_fraction or 0.) for s_ in sim.ptcl)
+              if sim.ptcl else None}
+    # N > 1: BASELINE.json's metric names the FIXED 1024 x 128 box on 1 -> 8 GPUs (strong scaling),
+    # the driver's contract asks for per-GPU work that stays fixed (weak): the line carries both -
+    # `value` / `scaling` are the run --scaling selects (default weak), `other_scaling` the other
+    # one, same steps, same barriers, max over ranks.
+    other = None
+    if world > 1 and not args.reference_sequence:
+        oscal = 'strong' if args.scaling == 'weak' else 'weak'
+        sim = None
+        sim2, Nz2, n2 = build(oscal)
+        warm2 = max(args.warmup, sim2.comm.exchange_period + 2)
+        with GpuMemoryManager(sim2):
+            sim2.step(warm2)
+            finish_outputs(sim2)
+            barrier()
+            t2 = time.perf_counter()
+            sim2.step(args.steps)
+            finish_outputs(sim2)
+            barrier()
+            dt2 = max_over_ranks(time.perf_counter() - t2)
+        other = {'scaling': oscal, 'value': n2 * args.steps / dt2, 'unit': 'particle-updates/s',
+                 'ms_per_step': 1e3 * dt2 / args.steps, 'steps': args.steps, 'warmup': warm2,
+                 'particles': n2, 'global_grid': [Nz2, args.Nr],
+                 'rows_per_rank': Nz2 // world, 'guard_rows_per_side': 64}
     if rank != 0:
         return
     value = n_total * args.steps / dt_wall
@@ -348,17 +385,17 @@ def main():
                    'particles': n_total, 'parallelism': 'z-slab x%d' % world,
                    'sequence': 'reference' if args.reference_sequence else 'fused'},
     }
+    if other:
+        out['other_scaling'] = other
     out['extra'] = {'repeat_ms_per_step': repeats, 'device': device_identity(torch),
+                    'preheat': 'fp64 triad + 4096^3 dgemm (measured_ceilings, ~1 s) before the warm-up, '
+                               'whatever --no-kernel-timing says',
                     'clocks_before': clocks_before, 'clocks_after_headline_call': clocks_first,
                     'clocks_after': clocks_after,
-                    'particle_passes': {'one_pass': sum(s.cycle_passes for s in sim.ptcl),
-                                        'sorting_two_pass': sum(s.cycle_sorts for s in sim.ptcl),
-                                        'sort_period': sim.ptcl[0].cycle_sort_period if sim.ptcl else None,
-                                        'last_stray_fraction': max((s.cycle_last_stray_fraction or 0.) for s in sim.ptcl)
-                                        if sim.ptcl else None}}
+                    'particle_passes': passes}
     if kern:
         out['roofline'], out['kernels'] = roofline(kern, ceil, {'C2': True, 'C5': 'c5'}.get(config_name(args, ppc, world), False))
-        out['measured_ceilings'] = ceil
+    out['measured_ceilings'] = ceil
     if cpu_base:
         out['cpu_baseline'] = cpu_base
     print(json.dumps(out))

@@ -81,13 +81,19 @@ template <int NM, bool WIDE> struct CyclePlan {
     // (only NV of them in all), + a 16-B pad (segments start on different banks)
     static constexpr int PSTR = 2 * NV + 2;
     // WIDE: the two DepEngines one after the other on one panel (64-bit pointers per lane); else the
-    // merged engine of cycle_dep.h (J and rho staged together, one traversal of the runs)
-    using EJ = DepEngine<FB_SHAPE_LINEAR, 3, NM, true, false>;
-    using ER = DepEngine<FB_SHAPE_LINEAR, 1, NM, true, false>;
+    // merged engine of cycle_dep.h (J and rho staged together, one traversal of the runs).
+    // (-DFB_CYCLE_TWO_ENGINES: round 4's form of the 32-bit path as well, for A/B builds)
+#ifdef FB_CYCLE_TWO_ENGINES
+    static constexpr bool MERGED = false;
+#else
+    static constexpr bool MERGED = !WIDE;
+#endif
+    using EJ = DepEngine<FB_SHAPE_LINEAR, 3, NM, true, !WIDE && !MERGED>;
+    using ER = DepEngine<FB_SHAPE_LINEAR, 1, NM, true, !WIDE && !MERGED>;
     using ED = CycleDep<NM>;
     static constexpr int DEP2_DOUBLES = EJ::L::WAVE_DOUBLES > ER::L::WAVE_DOUBLES ? EJ::L::WAVE_DOUBLES
                                                                                   : ER::L::WAVE_DOUBLES;
-    static constexpr int DEP_DOUBLES = WIDE ? DEP2_DOUBLES : ED::L::WAVE_DOUBLES;
+    static constexpr int DEP_DOUBLES = MERGED ? ED::L::WAVE_DOUBLES : DEP2_DOUBLES;
     static constexpr int GATHER_DOUBLES = NSEG * PSTR;
     // the two panels do not share LDS: the node values of chunk c+1 arrive while chunk c deposits
     static constexpr int WAVE_DOUBLES = GATHER_DOUBLES + DEP_DOUBLES;
@@ -162,9 +168,9 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
     ER er;
     ED ed;
     if constexpr (!RANK) {
-        if constexpr (WIDE) {
-            ej.init(dpanel, lane, A.GJ, A.rsJ, 0, Nz, Nr);
-            er.init(dpanel, lane, A.GR, A.rsR, 0, Nz, Nr);
+        if constexpr (!P::MERGED) {
+            ej.init(dpanel, lane, A.GJ, A.rsJ, 0, Nz, Nr, A.baseJ);
+            er.init(dpanel, lane, A.GR, A.rsR, 0, Nz, Nr, A.baseR);
         } else {
             ed.init(dpanel, lane, A.GJ, A.rsJ, A.GR, A.rsR, Nz, Nr, A.baseJ);
         }
@@ -498,7 +504,7 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
         const double bJ0 = KP(const double, beta0)[irJ], bJh = KP(const double, betah)[irJ];
         const double bR0 = KP(const double, beta0)[irR], bRh = KP(const double, betah)[irR];
         wait_and_store();
-        if constexpr (WIDE) {
+        if constexpr (!P::MERGED) {
             ej.stage_with(true, xh, yh, zh, wj, pux, puy, puz, pig, A.c_light, geom, bJ0, bJh, dkz, dkr, dnb);
             {
                 const bool home = act && dkz == hkz && dkr == hkr && dnb == hnb;
@@ -550,7 +556,7 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
         if (pd_i >= 0) { A.rk_cell[pd_i] = pd_cell; A.rk_rank[pd_i] = b_ + (lane - pd_run0); }
         return;
     }
-    if constexpr (WIDE) {
+    if constexpr (!P::MERGED) {
         ej.flush(false);
         er.flush(false);
     } else {

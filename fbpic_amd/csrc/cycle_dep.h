@@ -40,11 +40,22 @@
 namespace fb {
 
 template <int NM> struct CycleDepLayout {
+    // amplitudes of a variant: J m0 (Jr, Jt, Jz: real), J modes >= 1 (3 components x re / im per mode),
+    // rho m0, rho modes >= 1
     static constexpr int NAJ0 = 3, NAJH = 6 * (NM - 1), NAR0 = 1, NARH = 2 * (NM - 1);
     static constexpr int NTR = (NM > 1) ? 2 : 1;           // radial factor rows per engine: t0 [, th]
-    static constexpr int ROW_SJ = 0, ROW_TJ = 1, ROW_AJ = 1 + NTR;
-    static constexpr int ROW_SR = ROW_AJ + NAJ0 + NAJH, ROW_TR = ROW_SR + 1, ROW_AR = ROW_SR + 1 + NTR;
-    static constexpr int NROWS = ROW_AR + NAR0 + NARH;
+    // Rows of an engine: s | t0 [th] | mode-0 amplitudes a0 (3 / 1) | cos m theta, sin m theta of the
+    // modes m >= 1.  The amplitude of mode m is a0 (cos m theta + i sin m theta) (threading_methods.py:
+    // 119-121, 264-267: the recurrence starts from a real a0), formed when the matrix operand is read
+    // as X . Y = (a0 row) . (cos | sin row, or the row of ones for mode 0): 15 rows at Nm = 2 where the
+    // products themselves take 19 - the 12.8 KB per wave (with the gather panel) that let 12 waves
+    // share a CU; with 14.2 KB only 10 did (SQ_WAVE_CYCLES / SQ_BUSY_CYCLES, profiles/README.md) and
+    // the kernel was slower than round 4's in spite of 250 fewer VALU instructions per 64 particles.
+    static constexpr int NCS = 2 * (NM - 1);
+    static constexpr int ROW_ONE = 0;
+    static constexpr int ROW_SJ = 1, ROW_TJ = 2, ROW_AJ = 2 + NTR, ROW_CJ = ROW_AJ + 3;
+    static constexpr int ROW_SR = ROW_CJ + NCS, ROW_TR = ROW_SR + 1, ROW_AR = ROW_SR + 1 + NTR, ROW_CR = ROW_AR + 1;
+    static constexpr int NROWS = ROW_CR + NCS;
     // row stride in doubles: the (row, particle) pairs of a fragment read - up to 16 rows x 4
     // consecutive particles - fall two by two on the 32 bank pairs (the rate of a 64-lane b64 read)
     static constexpr int PAD = 66;
@@ -52,9 +63,16 @@ template <int NM> struct CycleDepLayout {
     static constexpr int NTL = (NAJH > 4) ? (NAJH + 3) / 4 : 1;
     static constexpr int WAVE_DOUBLES = NROWS * PAD + 4;
     __host__ __device__ static constexpr int namp(int v) { return v == 0 ? NAJ0 : v == 1 ? NAJH : v == 2 ? NAR0 : NARH; }
-    __host__ __device__ static constexpr int amp_row0(int v)
+    // rows X (mode-0 amplitude) and Y (cos / sin of the mode, or ones) behind amplitude a of variant v
+    __host__ __device__ static constexpr int row_x(int v, int a)
     {
-        return v == 0 ? ROW_AJ : v == 1 ? ROW_AJ + NAJ0 : v == 2 ? ROW_AR : ROW_AR + NAR0;
+        return v == 0 ? ROW_AJ + a : v == 1 ? ROW_AJ + (a >> 1) % 3 : ROW_AR;
+    }
+    __host__ __device__ static constexpr int row_y(int v, int a)
+    {
+        // modes >= 1: amplitude a -> mode 1 + (a >> 1) / ncomp, re (cos) / im (sin)
+        return v == 0 || v == 2 ? ROW_ONE
+             : v == 1 ? ROW_CJ + 2 * ((a >> 1) / 3) + (a & 1) : ROW_CR + 2 * (a >> 1) + (a & 1);
     }
 };
 
@@ -68,7 +86,7 @@ struct CycleDep {
     int lane;
     int rsB, csB, Nz, Nr;
     // A / B operand roles: byte offsets of this lane's rows, particle (l >> 4) of a step included
-    int aS, aT, aB[NTL];
+    int aS, aT, aX[NTL], aY[NTL];
     int k8, kA;                    // 8 (l >> 4); l >> 4
     double cz0, cz1, cr0, cr1;     // A role, node l & 3: Sz[jz] = cz0 + cz1 s, Sr[jr] = cr0 + cr1 t
     // D role: target of tile t as a byte offset from gbase (node row jzD included), validity and
@@ -99,7 +117,7 @@ struct CycleDep {
         const int pl = (int)(unsigned long)(__attribute__((address_space(3))) char *)P + k8;
         aS = (e ? L::ROW_SR : L::ROW_SJ) * PAD * 8 + pl;
         aT = ((e ? L::ROW_TR : L::ROW_TJ) + ((L::NTR > 1) ? vh : 0)) * PAD * 8 + pl;
-        const int na = L::namp(v), r0 = L::amp_row0(v);
+        const int na = L::namp(v);
         valid = 0u; neg = 0u;
         const int iD = lane >> 4;
         jzD = iD >> 1; jrD = iD & 1; jrDB = jrD * csB;
@@ -109,7 +127,9 @@ struct CycleDep {
         for (int t = 0; t < NTL; t++) {
             const int a = 4 * t + j;
             const bool ok = a < na;
-            aB[t] = (na > 0 ? r0 + (ok ? a : na - 1) : 0) * PAD * 8 + pl;
+            const int ac = na > 0 ? (ok ? a : na - 1) : 0;       // (columns beyond the variant: any finite rows)
+            aX[t] = (na > 0 ? L::row_x(v, ac) : L::ROW_ONE) * PAD * 8 + pl;
+            aY[t] = (na > 0 ? L::row_y(v, ac) : L::ROW_ONE) * PAD * 8 + pl;
             // amplitude a of variant v -> component, mode, re / im (rows as DepLayout::row)
             int comp = 0, m = 0, ri = 0;
             if (ok) {
@@ -130,7 +150,7 @@ struct CycleDep {
         // re-add them, and the panel base, in front of every read)
         asm volatile("" : "+v"(aS), "+v"(aT));
 #pragma unroll
-        for (int t = 0; t < NTL; t++) asm volatile("" : "+v"(aB[t]));
+        for (int t = 0; t < NTL; t++) asm volatile("" : "+v"(aX[t]), "+v"(aY[t]));
         const int iA = lane & 3, jzA = iA >> 1, jrA = iA & 1;
         cz0 = jzA ? 1. : 0.; cz1 = jzA ? -1. : 1.;
         cr0 = jrA ? 1. : 0.; cr1 = jrA ? -1. : 1.;
@@ -143,6 +163,9 @@ struct CycleDep {
             *(double *)(P + (lane * PAD + 65) * 8) = 0.;
         }
         if (lane < 4) *(double *)(P + (L::NROWS * PAD + lane) * 8) = 0.;
+        // the row of ones (Y of the mode-0 amplitudes): written once
+        *(double *)(P + (L::ROW_ONE * PAD + lane) * 8) = 1.;
+        if (lane < 2) *(double *)(P + (L::ROW_ONE * PAD + 64 + lane) * 8) = 1.;
     }
 
     // ---- phase 1, lane = particle: amplitudes, first shape factors, stencil key of engine E
@@ -153,8 +176,8 @@ struct CycleDep {
             double beta0_v, double betah_v, int &my_kz, int &my_kr, int &my_nb)
     {
         constexpr int NC = (E == 0) ? 3 : 1;
-        constexpr int R0 = (E == 0) ? L::ROW_AJ : L::ROW_AR;           // mode 0 (real parts only)
-        constexpr int RH = R0 + NC;                                    // modes >= 1
+        constexpr int R0 = (E == 0) ? L::ROW_AJ : L::ROW_AR;           // mode-0 amplitudes (real)
+        constexpr int RC = (E == 0) ? L::ROW_CJ : L::ROW_CR;           // cos m theta, sin m theta, m >= 1
         double *Pd = (double *)P;
         const double rj = sqrt(xj * xj + yj * yj);
         double cs_, sn;
@@ -164,25 +187,21 @@ struct CycleDep {
             const double invr = __builtin_fma(r0, __builtin_fma(-rj, r0, 1.), r0);
             cs_ = xj * invr; sn = yj * invr;
         } else { cs_ = 1.; sn = 0.; }
-        double are[NC], aim[NC];
         if constexpr (NC == 1) {
-            are[0] = wj; aim[0] = 0.;
+            Pd[R0 * PAD + lane] = wj;
         } else {
-            are[0] = wj * c_light * ig * (cs_ * ux + sn * uy); aim[0] = 0.;
-            are[1] = wj * c_light * ig * (cs_ * uy - sn * ux); aim[1] = 0.;
-            are[2] = wj * c_light * ig * uz; aim[2] = 0.;
+            Pd[(R0 + 0) * PAD + lane] = wj * c_light * ig * (cs_ * ux + sn * uy);
+            Pd[(R0 + 1) * PAD + lane] = wj * c_light * ig * (cs_ * uy - sn * ux);
+            Pd[(R0 + 2) * PAD + lane] = wj * c_light * ig * uz;
         }
+        {
+            double er = cs_, ei = sn;                      // (cos + i sin)^m by the reference's recurrence
 #pragma unroll
-        for (int mm = 0; mm < NM; mm++) {
-#pragma unroll
-            for (int k = 0; k < NC; k++) {
-                if (mm == 0) Pd[(R0 + k) * PAD + lane] = are[k];
-                else {
-                    Pd[(RH + ((mm - 1) * NC + k) * 2) * PAD + lane] = are[k];
-                    Pd[(RH + ((mm - 1) * NC + k) * 2 + 1) * PAD + lane] = aim[k];
-                }
-                const double re = cs_ * are[k] - sn * aim[k], im = cs_ * aim[k] + sn * are[k];
-                are[k] = re; aim[k] = im;
+            for (int mm = 1; mm < NM; mm++) {
+                Pd[(RC + 2 * (mm - 1)) * PAD + lane] = er;
+                Pd[(RC + 2 * (mm - 1) + 1) * PAD + lane] = ei;
+                const double re = cs_ * er - sn * ei, im = cs_ * ei + sn * er;
+                er = re; ei = im;
             }
         }
         const double r_cell = g.invdr * (rj - g.rmin) - 0.5;
@@ -208,12 +227,9 @@ struct CycleDep {
         double *Pd = (double *)P;
         if (notJ) {
 #pragma unroll
-            for (int a = 0; a < L::NAJ0 + L::NAJH; a++) Pd[(L::ROW_AJ + a) * PAD + lane] = 0.;
+            for (int a = 0; a < 3; a++) Pd[(L::ROW_AJ + a) * PAD + lane] = 0.;
         }
-        if (notR) {
-#pragma unroll
-            for (int a = 0; a < L::NAR0 + L::NARH; a++) Pd[(L::ROW_AR + a) * PAD + lane] = 0.;
-        }
+        if (notR) Pd[L::ROW_AR * PAD + lane] = 0.;
     }
 
     // ---- flush of the current cell: one atomic instruction per tile.  keep_upper: only its lower
@@ -259,15 +275,15 @@ struct CycleDep {
     {
         double s[NST], t[NST], b[NST][NTL];
         const int oS = aS + q8, oT = aT + q8;
-        int oB[NTL];
+        int oX[NTL], oY[NTL];
 #pragma unroll
-        for (int tl = 0; tl < NTL; tl++) oB[tl] = aB[tl] + q8;
+        for (int tl = 0; tl < NTL; tl++) { oX[tl] = aX[tl] + q8; oY[tl] = aY[tl] + q8; }
 #pragma unroll
         for (int u = 0; u < NST; u++) {
             s[u] = ld(oS + 32 * u);
             t[u] = ld(oT + 32 * u);
 #pragma unroll
-            for (int tl = 0; tl < NTL; tl++) b[u][tl] = ld(oB[tl] + 32 * u);
+            for (int tl = 0; tl < NTL; tl++) b[u][tl] = ld(oX[tl] + 32 * u) * ld(oY[tl] + 32 * u);
         }
 #pragma unroll
         for (int u = 0; u < NST; u++) {
@@ -367,7 +383,7 @@ struct CycleDep {
             const int baseJ = zJ * rsB + rJ * csB, baseR = zR * rsB + rR * csB;
 #pragma unroll
             for (int t = 0; t < NTL; t++) {
-                double v = w * ld(aB[t] + so);
+                double v = w * (ld(aX[t] + so) * ld(aY[t] + so));
                 if (!mine || !((valid >> t) & 1u) || v == 0.) continue;
                 unsigned voff;
                 if (interior) {

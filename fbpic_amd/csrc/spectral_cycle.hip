@@ -64,44 +64,41 @@ struct SpectCycleArgs {
     int correct, use_true_rho, Nz, Nr;
 };
 
-// The matrix operand of a wave: column n0 + 16 t + li (t = 0, 1) of rows 4 s + lk, s = 0 .. K4 - 1,
-// one 128-B row segment per quarter wave, straight from L2 (each wave reads a different column
-// slice: nothing to share through LDS).  The stream of all products of the kernel is requested
-// SC_PF steps ahead - across the products too: while product j runs its last steps, the first rows
-// of product j + 1's matrix are already on their way (b0 / b1 carry over from call to call).
+// The matrix operand of a wave: column n0 + li of rows 4 s + lk, s = 0 .. K4 - 1, one 128-B row
+// segment per quarter wave, straight from L2 (each wave reads a different column slice: nothing to
+// share through LDS).  The stream of all products of the kernel is requested SC_PF steps ahead -
+// across the products too: while product j runs its last steps, the first rows of product j + 1's
+// matrix are already on their way (b carries over from call to call).
 // Every load is unconditional (a select between the loaded value and 0 makes the compiler wait for
 // the load it has just issued - measured: 130 us instead of 70 for the whole kernel): rows beyond
 // Nr are clamped to the last row, where the A panel holds zeros (0 x finite = 0); columns beyond Nr
 // are clamped too, their sums are never stored.
-// NT: 16-column tiles per wave (a workgroup has 8 / NT waves)
-template <int NT> struct ScStream {
-    double b[NT][SC_PF];
+struct ScStream {
+    double b[SC_PF];
 };
 
-template <int NT>
-__device__ __forceinline__ void sc_prime(ScStream<NT> &B, const double *__restrict__ mat, int Nr, int n0, int li, int lk)
+__device__ __forceinline__ void sc_prime(ScStream &B, const double *__restrict__ mat, int Nr, int n0, int li, int lk)
 {
+    const int cc = min(n0 + li, Nr - 1);
 #pragma unroll
-    for (int p = 0; p < SC_PF; p++) {
-        const long ro = (long)min(4 * p + lk, Nr - 1) * Nr;
-#pragma unroll
-        for (int t = 0; t < NT; t++) B.b[t][p] = mat[ro + min(n0 + 16 * t + li, Nr - 1)];
-    }
+    for (int p = 0; p < SC_PF; p++) B.b[p] = mat[(long)min(4 * p + lk, Nr - 1) * Nr + cc];
 }
 
-// acc = A (16 rows x K, LDS panel) . M[:, this wave's 32 columns]; `next`: the matrix of the product
-// that follows (its first SC_PF steps are requested here), or null
-template <int NT>
-__device__ __forceinline__ void sc_product(const double *__restrict__ panel, const double *__restrict__ mat,
-                                           const double *__restrict__ next, ScStream<NT> &B,
-                                           int Nr, int K4, int n0, int li, int lk, double4_t (&acc)[NT])
+// acc[a] = A_a (16 rows x K, LDS panel `panel + a * pstride`) . M[:, this wave's 16 columns], a < NA:
+// the NA fields that share a Hankel matrix (spectral_transformer.py:67-69: Jz | rho forward, E and B
+// of the same (p | m | z) component backward) are multiplied against ONE stream of its fragments -
+// round 4 streamed 10 matrices per workgroup for 6 different ones, each 512-B fragment feeding a
+// single MFMA.  `next`: the matrix of the product that follows (its first SC_PF steps are
+// requested here), or null.
+template <int NA>
+__device__ __forceinline__ void sc_product(const double *__restrict__ panel, int pstride,
+                                           const double *__restrict__ mat, const double *__restrict__ next,
+                                           ScStream &B, int Nr, int K4, int n0, int li, int lk,
+                                           double4_t (&acc)[NA])
 {
-    int cc[NT];
 #pragma unroll
-    for (int t = 0; t < NT; t++) {
-        acc[t] = (double4_t){0., 0., 0., 0.};
-        cc[t] = min(n0 + 16 * t + li, Nr - 1);
-    }
+    for (int a = 0; a < NA; a++) acc[a] = (double4_t){0., 0., 0., 0.};
+    const int cc = min(n0 + li, Nr - 1);
     const double *Arow = panel + li * SC_RS + lk;
     if (next == nullptr) next = mat;                  // (redundant loads at the very end)
     // (K4 is a multiple of SC_PF - the panel is zero beyond Nr - so that the body is straight-line
@@ -113,26 +110,41 @@ __device__ __forceinline__ void sc_product(const double *__restrict__ panel, con
         const int sb = wrap ? 0 : s0 + SC_PF;
 #pragma unroll
         for (int p = 0; p < SC_PF; p++) {
-            const double a = Arow[4 * (s0 + p)];
-            double x[NT];
-            const long ro = (long)min(4 * (sb + p) + lk, Nr - 1) * Nr;
+            double a[NA];
 #pragma unroll
-            for (int t = 0; t < NT; t++) {
-                x[t] = B.b[t][p];
+            for (int q = 0; q < NA; q++) a[q] = Arow[q * pstride + 4 * (s0 + p)];
+            const double x = B.b[p];
 #if SC_KNOCK != 1            // (1: timing experiment without the matrix stream)
-                B.b[t][p] = src[ro + cc[t]];
+            B.b[p] = src[(long)min(4 * (sb + p) + lk, Nr - 1) * Nr + cc];
 #endif
-            }
 #pragma unroll
-            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, x[t], acc[t], 0, 0, 0);
+            for (int q = 0; q < NA; q++) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], x, acc[q], 0, 0, 0);
+#ifdef SC_SGB
+            // keep the step's shape in the schedule: operand reads, ONE matrix request, the MFMAs
+            // (left alone the scheduler gathers the 16 requests of a round behind its MFMAs)
+            __builtin_amdgcn_sched_group_barrier(0x100, NA, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NA, 0);
+#endif
         }
     }
 }
 
-template <int NT>
-__global__ __launch_bounds__(512 / NT) void k_spect_cycle(SpectCycleArgs A)
+// Order of the kernel's memory operations (round 5).  Loads, stores and atomics of a wave retire
+// IN ORDER through one counter (vmcnt): a matrix fragment requested after a batch of other
+// accesses cannot be used before that batch has completed.  Round 4 requested the 30 values of the
+// cell-local update (E, B, rho_prev and the tables of the lane's two cells: 46 MB over the launch)
+// in front of the sources, so the forward products started only when 63 MB had arrived, and issued
+// all 22 stores of the update in front of the inverse products, whose 17th step then waited for
+// 46 MB to be written: the four phases ran one after the other (~14 + 8 + 12 + 11 us of the 58).
+// Now the sources - the only thing the forward products need - go first; the update's operands
+// are requested in three batches at the start of the three forward products (their first SC_PF
+// matrix fragments are already in registers, so the batch gets that many MFMA steps to land and
+// the transfer overlaps the products); J and rho are stored by the update itself, the new E, B
+// in two batches at the start of the second and third inverse product.
+__global__ __launch_bounds__(512) void k_spect_cycle(SpectCycleArgs A)
 {
-    constexpr int NTHREADS = 512 / NT;
+    constexpr int NTHREADS = 512;
     extern __shared__ double sc_lds[];
     const int m = blockIdx.y;
     const int zb = blockIdx.x * SC_TZ;
@@ -141,36 +153,7 @@ __global__ __launch_bounds__(512 / NT) void k_spect_cycle(SpectCycleArgs A)
     const int li = lane & 15, lk = lane >> 4;
     const int Nz = A.Nz, Nr = A.Nr;
     const int K4 = (Nr + 4 * SC_PF - 1) / (4 * SC_PF) * SC_PF;     // MFMA steps over K (multiple of SC_PF)
-    const int n0 = 16 * NT * wave;
-
-    ScStream<NT> B;
-    sc_prime(B, A.fwd[3 * m + 0], Nr, n0, li, lk);     // (in flight while the panels are filled)
-
-    // ---- E, B, rho_prev and the coefficient tables of this lane's 4 cells (kz = zb + lk + 4 h,
-    // kr = n0 + 16 t + li): requested NOW, used after the forward products (with one wave per SIMD
-    // nothing else would hide their latency: 58 -> 33 us without the update, measured).  Cells
-    // outside the grid read a clamped address; their results are never stored.
-    cplx *const *f = A.f + 11 * m;
-    const double *const *tb = A.t + 8 * m;
-    const double *fz = A.fz[m], *fr = A.fr[m];
-    cplx c_f[2 * NT][7];               // Ep Em Ez Bp Bm Bz rho_prev
-    double c_t[2 * NT][8], c_cz[2 * NT];
-#pragma unroll
-    for (int t = 0; t < NT; t++)
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int q = 2 * t + h;
-            const int zc = min(zb + lk + 4 * h, Nz - 1), nc = min(n0 + 16 * t + li, Nr - 1);
-            const long o = (long)zc * A.srs + nc, idx = (long)zc * Nr + nc;
-#pragma unroll
-            for (int j = 0; j < 6; j++) c_f[q][j] = sc_ld(f[j] + o);
-            c_f[q][6] = sc_ld(f[9] + o);
-#pragma unroll
-            for (int j = 0; j < 8; j++) c_t[q][j] = tb[j][idx];
-            // filter factor of the sources (fz[iz] * fr[ir] * F as in numba_filter_*, k_hankel epilogue)
-            c_cz[q] = 1.0;
-            if (fr) { const double cn = 1.0 * fr[nc]; c_cz[q] = fz[zc] * cn; }
-        }
+    const int n0 = 16 * wave;
 
     // ---- sources -> LDS panels [field][i = kz_local + 8 ri][k = r]: p, m, z, rho
     // (p = (r - i t) / 2, m = (r + i t) / 2, each times 1 / volume: spectral_transformer.py:208-210
@@ -178,135 +161,184 @@ __global__ __launch_bounds__(512 / NT) void k_spect_cycle(SpectCycleArgs A)
     {
         const cplx *sr = A.src[4 * m], *st = A.src[4 * m + 1], *sz = A.src[4 * m + 2], *sq = A.src[4 * m + 3];
         const double *iv = A.invvol[m];
-        for (int e = tid; e < SC_TZ * SC_KMAX; e += NTHREADS) {
+        constexpr int NE = SC_TZ * SC_KMAX / NTHREADS;
+        cplx r_[NE], t_[NE], z_[NE], q_[NE];
+        double s_[NE];
+#pragma unroll
+        for (int u = 0; u < NE; u++) {
+            const int e = tid + u * NTHREADS;
             const int row = e >> 7, k = e & (SC_KMAX - 1);
-            const int zz = zb + row;
-            cplx p = {0., 0.}, mm = {0., 0.}, z = {0., 0.}, q = {0., 0.};
-            if (zz < Nz && k < Nr) {
-                const long o = (long)zz * A.irs + k;
-                const cplx r_ = sc_ld(sr + o), t_ = sc_ld(st + o);
-                const double s_ = iv[k];
-                p = {0.5 * (r_.re + t_.im) * s_, 0.5 * (r_.im - t_.re) * s_};
-                mm = {0.5 * (r_.re - t_.im) * s_, 0.5 * (r_.im + t_.re) * s_};
-                z = sc_ld(sz + o); z = {z.re * s_, z.im * s_};
-                q = sc_ld(sq + o); q = {q.re * s_, q.im * s_};
-            }
+            const long o = (long)min(zb + row, Nz - 1) * A.irs + min(k, Nr - 1);
+            r_[u] = sc_ld(sr + o); t_[u] = sc_ld(st + o); z_[u] = sc_ld(sz + o); q_[u] = sc_ld(sq + o);
+            s_[u] = iv[min(k, Nr - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < NE; u++) {
+            const int e = tid + u * NTHREADS;
+            const int row = e >> 7, k = e & (SC_KMAX - 1);
+            const bool in = (zb + row < Nz) && (k < Nr);
+            const double s = in ? s_[u] : 0.;             // zeros outside the grid
             double *P0 = sc_lds + row * SC_RS + k;
-            P0[0 * SC_PANEL] = p.re;  P0[0 * SC_PANEL + 8 * SC_RS] = p.im;
-            P0[1 * SC_PANEL] = mm.re; P0[1 * SC_PANEL + 8 * SC_RS] = mm.im;
-            P0[2 * SC_PANEL] = z.re;  P0[2 * SC_PANEL + 8 * SC_RS] = z.im;
-            P0[3 * SC_PANEL] = q.re;  P0[3 * SC_PANEL + 8 * SC_RS] = q.im;
+            P0[0 * SC_PANEL] = 0.5 * (r_[u].re + t_[u].im) * s;  P0[0 * SC_PANEL + 8 * SC_RS] = 0.5 * (r_[u].im - t_[u].re) * s;
+            P0[1 * SC_PANEL] = 0.5 * (r_[u].re - t_[u].im) * s;  P0[1 * SC_PANEL + 8 * SC_RS] = 0.5 * (r_[u].im + t_[u].re) * s;
+            P0[2 * SC_PANEL] = z_[u].re * s;  P0[2 * SC_PANEL + 8 * SC_RS] = z_[u].im * s;
+            P0[3 * SC_PANEL] = q_[u].re * s;  P0[3 * SC_PANEL + 8 * SC_RS] = q_[u].im * s;
         }
     }
+    ScStream B;
+    sc_prime(B, A.fwd[3 * m + 0], Nr, n0, li, lk);
     __syncthreads();
 
-    // ---- forward products: Jp, Jm (matrices of p, m), Jz, rho (matrix of order m)
-    double4_t aJ[4][NT];
-    sc_product(sc_lds + 0 * SC_PANEL, A.fwd[3 * m + 0], A.fwd[3 * m + 1], B, Nr, K4, n0, li, lk, aJ[0]);
-    sc_product(sc_lds + 1 * SC_PANEL, A.fwd[3 * m + 1], A.fwd[3 * m + 2], B, Nr, K4, n0, li, lk, aJ[1]);
-    sc_product(sc_lds + 2 * SC_PANEL, A.fwd[3 * m + 2], A.fwd[3 * m + 2], B, Nr, K4, n0, li, lk, aJ[2]);
-    // (the first rows of the first inverse matrix travel during the cell-local update)
-    sc_product(sc_lds + 3 * SC_PANEL, A.fwd[3 * m + 2], A.inv[3 * m + 0], B, Nr, K4, n0, li, lk, aJ[3]);
-    __syncthreads();                 // the source panels are dead: the E, B panels take their place
-
-    // ---- cell-local update of this lane's 2 NT cells
+    // ---- this lane's 2 cells (kz = zb + lk + 4 h, kr = n0 + li): E, B, rho_prev and the tables,
+    // requested in three batches in front of the three forward products.  Cells outside the grid
+    // read a clamped address; their results are never stored.
+    cplx *const *f = A.f + 11 * m;
+    const double *const *tb = A.t + 8 * m;
+    const double *fz = A.fz[m], *fr = A.fr[m];
+    const int nc = min(n0 + li, Nr - 1);
+    long co[2], ci[2];
+    int zc[2];
 #pragma unroll
-    for (int t = 0; t < NT; t++) {
-        const int n = n0 + 16 * t + li;
+    for (int h = 0; h < 2; h++) {
+        zc[h] = min(zb + lk + 4 * h, Nz - 1);
+        co[h] = (long)zc[h] * A.srs + nc; ci[h] = (long)zc[h] * Nr + nc;
+    }
+    cplx c_f[2][7];                    // Ep Em Ez Bp Bm Bz rho_prev
+    double c_t[2][8], c_cz[2];
+
+    // ---- forward products: Jp, Jm (matrices of p, m), then Jz | rho against the matrix of order m
+    double4_t aJ[4];
+    {
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const int row = lk + 4 * h, zz = zb + row;
-            cplx ep = {0., 0.}, em = {0., 0.}, ez = {0., 0.}, bp = {0., 0.}, bm = {0., 0.}, bz = {0., 0.};
-            if (SC_KNOCK != 2 && zz < Nz && n < Nr) {       // (2: timing experiment without the update)
-                const int q = 2 * t + h;
-                const long o = (long)zz * A.srs + n;
-                const double cz = c_cz[q];
-                cplx jp = {cz * aJ[0][t][h], cz * aJ[0][t][2 + h]};
-                cplx jm = {cz * aJ[1][t][h], cz * aJ[1][t][2 + h]};
-                cplx jz = {cz * aJ[2][t][h], cz * aJ[2][t][2 + h]};
-                const cplx rn = {cz * aJ[3][t][h], cz * aJ[3][t][2 + h]};
-                const double rpc = c_t[q][0], rnc = c_t[q][1], jc = c_t[q][2], Cc = c_t[q][3], Sw = c_t[q][4];
-                const double krr = c_t[q][5], kzz = c_t[q][6];
-                ep = c_f[q][0]; em = c_f[q][1]; ez = c_f[q][2];
-                bp = c_f[q][3]; bm = c_f[q][4]; bz = c_f[q][5];
-                const cplx rp = c_f[q][6];
-                // k_psatd_step (fields.hip), same expressions
-                if (A.correct) {
-                    const cplx t1 = sc_rmul(A.inv_dt, sc_sub(rn, rp));
-                    const cplx t2 = sc_rmul(kzz, sc_imul(jz));
-                    const cplx t3 = sc_rmul(krr, sc_sub(jp, jm));
-                    const cplx F = sc_rmul(-c_t[q][7], sc_add(sc_add(t1, t2), t3));
-                    jp = sc_add(jp, sc_rmul(0.5 * krr, F));
-                    jm = sc_add(jm, sc_rmul(-0.5 * krr, F));
-                    jz = sc_add(jz, sc_rmul(kzz, sc_imul(sc_rmul(-1., F))));
-                }
-                sc_stu(f[6] + o, jp); sc_stu(f[7] + o, jm); sc_stu(f[8] + o, jz);
-                cplx rho_diff;
-                if (A.use_true_rho) {
-                    rho_diff = sc_sub(sc_rmul(rnc, rn), sc_rmul(rpc, rp));
-                } else {
-                    const cplx divE = sc_add(sc_rmul(krr, sc_sub(ep, em)), sc_rmul(kzz, sc_imul(ez)));
-                    const cplx divJ = sc_add(sc_rmul(krr, sc_sub(jp, jm)), sc_rmul(kzz, sc_imul(jz)));
-                    rho_diff = sc_sub(sc_rmul((rnc - rpc) * A.eps0, divE), sc_rmul(rnc * A.dt, divJ));
-                }
-                const cplx mihkBz = sc_rmul(0.5 * krr, sc_imul(sc_rmul(-1., bz)));
-                const cplx nep = sc_add(sc_add(sc_rmul(Cc, ep), sc_rmul(0.5 * krr, rho_diff)),
-                        sc_rmul(A.c2 * Sw, sc_sub(sc_add(mihkBz, sc_rmul(kzz, bp)), sc_rmul(A.mu0, jp))));
-                const cplx nem = sc_add(sc_sub(sc_rmul(Cc, em), sc_rmul(0.5 * krr, rho_diff)),
-                        sc_rmul(A.c2 * Sw, sc_sub(sc_sub(mihkBz, sc_rmul(kzz, bm)), sc_rmul(A.mu0, jm))));
-                const cplx nez = sc_add(sc_sub(sc_rmul(Cc, ez), sc_rmul(kzz, sc_imul(rho_diff))),
-                        sc_rmul(A.c2 * Sw, sc_sub(sc_add(sc_rmul(krr, sc_imul(bp)), sc_rmul(krr, sc_imul(bm))),
-                                                  sc_rmul(A.mu0, jz))));
-                const cplx mihkEz = sc_rmul(0.5 * krr, sc_imul(sc_rmul(-1., ez)));
-                const cplx mihkJz = sc_rmul(0.5 * krr, sc_imul(sc_rmul(-1., jz)));
-                const cplx nbp = sc_add(sc_sub(sc_rmul(Cc, bp), sc_rmul(Sw, sc_add(mihkEz, sc_rmul(kzz, ep)))),
-                        sc_rmul(jc, sc_add(mihkJz, sc_rmul(kzz, jp))));
-                const cplx nbm = sc_add(sc_sub(sc_rmul(Cc, bm), sc_rmul(Sw, sc_sub(mihkEz, sc_rmul(kzz, em)))),
-                        sc_rmul(jc, sc_sub(mihkJz, sc_rmul(kzz, jm))));
-                const cplx nbz = sc_add(sc_sub(sc_rmul(Cc, bz),
-                                               sc_rmul(Sw, sc_add(sc_rmul(krr, sc_imul(ep)), sc_rmul(krr, sc_imul(em))))),
-                        sc_rmul(jc, sc_add(sc_rmul(krr, sc_imul(jp)), sc_rmul(krr, sc_imul(jm)))));
-                sc_stu(f[0] + o, nep); sc_stu(f[1] + o, nem); sc_stu(f[2] + o, nez);
-                sc_stu(f[3] + o, nbp); sc_stu(f[4] + o, nbm); sc_stu(f[5] + o, nbz);
-                sc_stu(f[9] + o, rn);                       // push_rho: rho_prev <- rho_next
-                sc_stu(f[10] + o, {0., 0.});
-                ep = nep; em = nem; ez = nez; bp = nbp; bm = nbm; bz = nbz;
+#pragma unroll
+            for (int j = 0; j < 6; j++) c_f[h][j] = sc_ld(f[j] + co[h]);
+            c_f[h][6] = sc_ld(f[9] + co[h]);
+        }
+        double4_t a1[1];
+        sc_product<1>(sc_lds + 0 * SC_PANEL, SC_PANEL, A.fwd[3 * m + 0], A.fwd[3 * m + 1], B, Nr, K4, n0, li, lk, a1);
+        aJ[0] = a1[0];
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) c_t[h][j] = tb[j][ci[h]];
+        sc_product<1>(sc_lds + 1 * SC_PANEL, SC_PANEL, A.fwd[3 * m + 1], A.fwd[3 * m + 2], B, Nr, K4, n0, li, lk, a1);
+        aJ[1] = a1[0];
+        // filter factor of the sources (fz[iz] * fr[ir] * F as in numba_filter_*, k_hankel epilogue)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            c_cz[h] = 1.0;
+            if (fr) { const double cn = 1.0 * fr[nc]; c_cz[h] = fz[zc[h]] * cn; }
+        }
+        double4_t a2[2];
+        // (the first rows of the first inverse matrix travel during the cell-local update)
+        sc_product<2>(sc_lds + 2 * SC_PANEL, SC_PANEL, A.fwd[3 * m + 2], A.inv[3 * m + 0], B, Nr, K4, n0, li, lk, a2);
+        aJ[2] = a2[0]; aJ[3] = a2[1];
+    }
+    __syncthreads();                 // the source panels are dead: the E, B panels take their place
+
+    // ---- cell-local update of this lane's 2 cells
+    const int n = n0 + li;
+    cplx nE[2][6];                   // new Ep Em Ez Bp Bm Bz (stored during the inverse products)
+    bool live[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int row = lk + 4 * h, zz = zb + row;
+        cplx ep = {0., 0.}, em = {0., 0.}, ez = {0., 0.}, bp = {0., 0.}, bm = {0., 0.}, bz = {0., 0.};
+        live[h] = SC_KNOCK != 2 && zz < Nz && n < Nr;       // (2: timing experiment without the update)
+        if (live[h]) {
+            const long o = co[h];
+            const double cz = c_cz[h];
+            cplx jp = {cz * aJ[0][h], cz * aJ[0][2 + h]};
+            cplx jm = {cz * aJ[1][h], cz * aJ[1][2 + h]};
+            cplx jz = {cz * aJ[2][h], cz * aJ[2][2 + h]};
+            const cplx rn = {cz * aJ[3][h], cz * aJ[3][2 + h]};
+            const double rpc = c_t[h][0], rnc = c_t[h][1], jc = c_t[h][2], Cc = c_t[h][3], Sw = c_t[h][4];
+            const double krr = c_t[h][5], kzz = c_t[h][6];
+            ep = c_f[h][0]; em = c_f[h][1]; ez = c_f[h][2];
+            bp = c_f[h][3]; bm = c_f[h][4]; bz = c_f[h][5];
+            const cplx rp = c_f[h][6];
+            // k_psatd_step (fields.hip), same expressions
+            if (A.correct) {
+                const cplx t1 = sc_rmul(A.inv_dt, sc_sub(rn, rp));
+                const cplx t2 = sc_rmul(kzz, sc_imul(jz));
+                const cplx t3 = sc_rmul(krr, sc_sub(jp, jm));
+                const cplx F = sc_rmul(-c_t[h][7], sc_add(sc_add(t1, t2), t3));
+                jp = sc_add(jp, sc_rmul(0.5 * krr, F));
+                jm = sc_add(jm, sc_rmul(-0.5 * krr, F));
+                jz = sc_add(jz, sc_rmul(kzz, sc_imul(sc_rmul(-1., F))));
             }
-            // new E, B -> the A panels of the inverse products (zeros outside the grid)
-            if (n < SC_KMAX) {
-                double *P0 = sc_lds + row * SC_RS + n;
-                P0[0 * SC_PANEL] = ep.re; P0[0 * SC_PANEL + 8 * SC_RS] = ep.im;
-                P0[1 * SC_PANEL] = em.re; P0[1 * SC_PANEL + 8 * SC_RS] = em.im;
-                P0[2 * SC_PANEL] = ez.re; P0[2 * SC_PANEL + 8 * SC_RS] = ez.im;
-                P0[3 * SC_PANEL] = bp.re; P0[3 * SC_PANEL + 8 * SC_RS] = bp.im;
-                P0[4 * SC_PANEL] = bm.re; P0[4 * SC_PANEL + 8 * SC_RS] = bm.im;
-                P0[5 * SC_PANEL] = bz.re; P0[5 * SC_PANEL + 8 * SC_RS] = bz.im;
+            sc_stu(f[6] + o, jp); sc_stu(f[7] + o, jm); sc_stu(f[8] + o, jz);
+            cplx rho_diff;
+            if (A.use_true_rho) {
+                rho_diff = sc_sub(sc_rmul(rnc, rn), sc_rmul(rpc, rp));
+            } else {
+                const cplx divE = sc_add(sc_rmul(krr, sc_sub(ep, em)), sc_rmul(kzz, sc_imul(ez)));
+                const cplx divJ = sc_add(sc_rmul(krr, sc_sub(jp, jm)), sc_rmul(kzz, sc_imul(jz)));
+                rho_diff = sc_sub(sc_rmul((rnc - rpc) * A.eps0, divE), sc_rmul(rnc * A.dt, divJ));
             }
+            const cplx mihkBz = sc_rmul(0.5 * krr, sc_imul(sc_rmul(-1., bz)));
+            const cplx nep = sc_add(sc_add(sc_rmul(Cc, ep), sc_rmul(0.5 * krr, rho_diff)),
+                    sc_rmul(A.c2 * Sw, sc_sub(sc_add(mihkBz, sc_rmul(kzz, bp)), sc_rmul(A.mu0, jp))));
+            const cplx nem = sc_add(sc_sub(sc_rmul(Cc, em), sc_rmul(0.5 * krr, rho_diff)),
+                    sc_rmul(A.c2 * Sw, sc_sub(sc_sub(mihkBz, sc_rmul(kzz, bm)), sc_rmul(A.mu0, jm))));
+            const cplx nez = sc_add(sc_sub(sc_rmul(Cc, ez), sc_rmul(kzz, sc_imul(rho_diff))),
+                    sc_rmul(A.c2 * Sw, sc_sub(sc_add(sc_rmul(krr, sc_imul(bp)), sc_rmul(krr, sc_imul(bm))),
+                                              sc_rmul(A.mu0, jz))));
+            const cplx mihkEz = sc_rmul(0.5 * krr, sc_imul(sc_rmul(-1., ez)));
+            const cplx mihkJz = sc_rmul(0.5 * krr, sc_imul(sc_rmul(-1., jz)));
+            const cplx nbp = sc_add(sc_sub(sc_rmul(Cc, bp), sc_rmul(Sw, sc_add(mihkEz, sc_rmul(kzz, ep)))),
+                    sc_rmul(jc, sc_add(mihkJz, sc_rmul(kzz, jp))));
+            const cplx nbm = sc_add(sc_sub(sc_rmul(Cc, bm), sc_rmul(Sw, sc_sub(mihkEz, sc_rmul(kzz, em)))),
+                    sc_rmul(jc, sc_sub(mihkJz, sc_rmul(kzz, jm))));
+            const cplx nbz = sc_add(sc_sub(sc_rmul(Cc, bz),
+                                           sc_rmul(Sw, sc_add(sc_rmul(krr, sc_imul(ep)), sc_rmul(krr, sc_imul(em))))),
+                    sc_rmul(jc, sc_add(sc_rmul(krr, sc_imul(jp)), sc_rmul(krr, sc_imul(jm)))));
+            sc_stu(f[9] + o, rn);                       // push_rho: rho_prev <- rho_next
+            sc_stu(f[10] + o, {0., 0.});
+            ep = nep; em = nem; ez = nez; bp = nbp; bm = nbm; bz = nbz;
+        }
+        nE[h][0] = ep; nE[h][1] = em; nE[h][2] = ez; nE[h][3] = bp; nE[h][4] = bm; nE[h][5] = bz;
+        // new E, B -> the A panels of the inverse products (zeros outside the grid); panel order
+        // Ep Bp | Em Bm | Ez Bz: the two fields of a product lie next to each other
+        if (n < SC_KMAX) {
+            double *P0 = sc_lds + row * SC_RS + n;
+            P0[0 * SC_PANEL] = ep.re; P0[0 * SC_PANEL + 8 * SC_RS] = ep.im;
+            P0[1 * SC_PANEL] = bp.re; P0[1 * SC_PANEL + 8 * SC_RS] = bp.im;
+            P0[2 * SC_PANEL] = em.re; P0[2 * SC_PANEL + 8 * SC_RS] = em.im;
+            P0[3 * SC_PANEL] = bm.re; P0[3 * SC_PANEL + 8 * SC_RS] = bm.im;
+            P0[4 * SC_PANEL] = ez.re; P0[4 * SC_PANEL + 8 * SC_RS] = ez.im;
+            P0[5 * SC_PANEL] = bz.re; P0[5 * SC_PANEL + 8 * SC_RS] = bz.im;
         }
     }
-    #if SC_KNOCK == 4
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-#else
     __syncthreads();
-#endif
 
-    // ---- inverse products, written to the (kz, r) slab the backward z-FFT reads
-#pragma unroll 1
-    for (int j = 0; j < 6; j++) {
-        double4_t acc[NT];
-        sc_product(sc_lds + j * SC_PANEL, A.inv[3 * m + (j % 3)], j < 5 ? A.inv[3 * m + ((j + 1) % 3)] : nullptr,
-                   B, Nr, K4, n0, li, lk, acc);
-        cplx *o_ = A.out[6 * m + j];
+    // ---- inverse products, E and B of a component against one matrix stream, written to the
+    // (kz, r) slab the backward z-FFT reads (out[6 m + j], j = Ep Em Ez Bp Bm Bz)
 #pragma unroll
-        for (int t = 0; t < NT; t++) {
-            const int n = n0 + 16 * t + li;
+    for (int j = 0; j < 3; j++) {
+        // the new spectral E, B of the update leave in two batches (see the top of the kernel)
+        if (j == 1) {
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+                if (live[h]) { sc_stu(f[0] + co[h], nE[h][0]); sc_stu(f[1] + co[h], nE[h][1]); sc_stu(f[2] + co[h], nE[h][2]); }
+        }
+        if (j == 2) {
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+                if (live[h]) { sc_stu(f[3] + co[h], nE[h][3]); sc_stu(f[4] + co[h], nE[h][4]); sc_stu(f[5] + co[h], nE[h][5]); }
+        }
+        double4_t acc[2];
+        sc_product<2>(sc_lds + 2 * j * SC_PANEL, SC_PANEL, A.inv[3 * m + j], j < 2 ? A.inv[3 * m + j + 1] : nullptr,
+                      B, Nr, K4, n0, li, lk, acc);
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            cplx *o_ = A.out[6 * m + j + 3 * q];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const int zz = zb + lk + 4 * h;
                 if (zz < Nz && n < Nr)
-                    sc_st(o_ + (long)zz * A.ors + n, {1.0 * acc[t][h], 1.0 * acc[t][2 + h]});
+                    sc_st(o_ + (long)zz * A.ors + n, {1.0 * acc[q][h], 1.0 * acc[q][2 + h]});
             }
         }
     }
@@ -351,13 +383,13 @@ extern "C" int fb_spect_cycle_standard(int Nm, const void *const *src, long src_
     const size_t lds_bytes = (size_t)6 * SC_PANEL * 8;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_spect_cycle<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void *)k_spect_cycle, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds_bytes);
         if (e != hipSuccess) return check(e, who);
         attr_done = true;
     }
     dim3 grid((Nz + SC_TZ - 1) / SC_TZ, Nm);
-    // 8 waves of one 16-column tile each (NT = 2, 4 waves of two tiles: 58 against 52 us at C2)
-    hipLaunchKernelGGL(k_spect_cycle<1>, grid, dim3(512), lds_bytes, (hipStream_t)stream, A);
+    // 8 waves of one 16-column tile each (4 waves of two tiles: 58 against 52 us at C2, round 4)
+    hipLaunchKernelGGL(k_spect_cycle, grid, dim3(512), lds_bytes, (hipStream_t)stream, A);
     return check(hipGetLastError(), who);
 }

@@ -58,7 +58,7 @@ def _build():
                       boundaries={'z': 'open', 'r': 'reflective'})
 
 
-def _run(rank, world, port, outdir):
+def _run(rank, world, port, outdir, correct=False):
     import time
     t_start = time.time()
     tlog = os.path.join(ROOT, 'gpurun_out', 'c4_timing')
@@ -90,7 +90,7 @@ def _run(rank, world, port, outdir):
     sim.set_moving_window(v=c)
     mark('particles selected, laser added')
     np.random.seed(12345)              # the angles of the injected plasma: same draws in both runs
-    sim.step(NSTEP, correct_currents=False)
+    sim.step(NSTEP, correct_currents=correct)
     mark('%d steps done' % NSTEP)
     Nz_phys, iz0 = sim.comm.get_Nz_and_iz(local=True, with_damp=False, with_guard=False, rank=rank)
     _, iz_arr = sim.comm.get_Nz_and_iz(local=True, with_damp=True, with_guard=True, rank=rank)
@@ -109,7 +109,7 @@ def _run(rank, world, port, outdir):
         dist.destroy_process_group()
 
 
-def _worker(rank, world, port, outdir, q):
+def _worker(rank, world, port, outdir, q, correct=False):
     try:
         # a rank that is still running after 75 s writes where it is (a hang of one rank
         # stalls all the others in their next exchange)
@@ -119,7 +119,7 @@ def _worker(rank, world, port, outdir, q):
         stack = open(os.path.join(tlog, 'w%d_r%d_stack.log' % (world, rank)), 'w')
         faulthandler.enable(file=stack)          # and on a fatal signal (SIGSEGV, SIGABRT, SIGBUS)
         faulthandler.dump_traceback_later(75, repeat=False, file=stack)
-        _run(rank, world, port, outdir)
+        _run(rank, world, port, outdir, correct)
         faulthandler.cancel_dump_traceback_later()
         q.put((rank, 'ok'))
     except Exception:  # pragma: no cover
@@ -158,7 +158,10 @@ def _loss_report(world, before):
     return path
 
 
-def _launch(world, outdir):
+_RETRIES = [0]
+
+
+def _launch(world, outdir, correct=False):
     # The ranks are processes of ONE host here: keep their BLAS / OpenMP pools small.  The GPU
     # boxes show 256 logical CPUs but grant a quota of 16 cores; eight processes with one
     # 256-thread pool each (scipy pinv of the Hankel matrices, NumPy, torch) spend their time
@@ -170,7 +173,7 @@ def _launch(world, outdir):
     port = _free_port()
     q = ctx.Queue()
     events_before = _cgroup('memory.events')
-    procs = [ctx.Process(target=_worker, args=(r, world, port, outdir, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, outdir, q, correct)) for r in range(world)]
     for p in procs:
         p.start()
     import queue
@@ -203,7 +206,7 @@ def _launch(world, outdir):
     return not lost
 
 
-def _launch_with_retry(world, outdir, attempts=3):
+def _launch_with_retry(world, outdir, attempts=3, correct=False):
     """On the one-GPU test box the 8 rank processes share the GPU; in about one run out of four
     ALL of them vanished at once a few seconds into the run - no Python exception through the
     queue, no faulthandler dump (fatal-signal handler and a 75 s timer armed in every rank; a
@@ -215,8 +218,9 @@ def _launch_with_retry(world, outdir, attempts=3):
     ranks said is kept under gpurun_out/c4_timing/."""
     import warnings
     for attempt in range(attempts):
-        if _launch(world, outdir):
+        if _launch(world, outdir, correct):
             return
+        _RETRIES[0] += 1
         # not a silent pass: the retry shows in the warnings summary of the run, and what could be
         # found out about the loss (exit signals of the ranks, OOM counters of the cgroup, kernel
         # log, GPU memory holders) is under gpurun_out/c4_timing/loss_report_w<world>.txt
@@ -226,7 +230,16 @@ def _launch_with_retry(world, outdir, attempts=3):
                          'gpurun_out/c4_timing/w%d_r*_stack.log)' % (world, attempts, world))
 
 
-def test_c4_lwfa_4096x256_on_8_slabs_reproduces_the_single_domain():
+@pytest.mark.parametrize('correct', [False, True])
+def test_c4_lwfa_4096x256_on_8_slabs_reproduces_the_single_domain(correct):
+    """correct = False: every operation is local within the stencil reach - the 8 slabs reproduce the
+    single domain to rounding.  correct = True: the run as docs/source/example_input/lwfa_script.py
+    makes it (`sim.step` with its default curl-free correction, reference main.py:530-538): every
+    rank inverts the Laplacian of ITS slab before the J guard exchange, so the decomposed scheme
+    differs from the single domain by construction (in the reference too; rank-by-rank parity with
+    the reference is pinned in miniature by tests/test_gpu_multirank_golden.py, mr_lwfa_lin_8r) -
+    here the full-size run must stay within the scheme difference of the single domain, with
+    exactly the same particle set."""
     import helpers
     import atexit
     import shutil
@@ -239,8 +252,10 @@ def test_c4_lwfa_4096x256_on_8_slabs_reproduces_the_single_domain():
     np.save(os.path.join(outdir, 'global_particles.npy'),
             np.array([getattr(glob.ptcl[0], k) for k in helpers.PTCL]))
     del glob
-    _launch_with_retry(1, outdir)
-    _launch_with_retry(world, outdir)
+    _launch_with_retry(1, outdir, correct=correct)
+    _launch_with_retry(world, outdir, correct=correct)
+    # (how often the rank-loss retry had to act in this process: recorded with the achieved figures)
+    achieved('c4 rank-loss retries (count)', float(_RETRIES[0]), 3.5)
     one = np.load(os.path.join(outdir, 'w1_r0.npz'))
     parts = [np.load(os.path.join(outdir, 'w%d_r%d.npz' % (world, r))) for r in range(world)]
     # local grids: 512 physical cells each + 2 x n_guard cells (+ 64 damp and n_guard / 2 inject
@@ -260,7 +275,9 @@ def test_c4_lwfa_4096x256_on_8_slabs_reproduces_the_single_domain():
         for k in keys:
             got = np.concatenate([p[k] for p in parts], axis=0)
             assert got.shape == one[k].shape == (NZ, NR)
-            achieved(None, np.abs(got - one[k]).max() / scale, 1e-12, 'fields ' + grp)      # measured <= 6e-14
+            # (uncorrected: measured <= 6e-14; corrected: the scheme difference, measured ~1e-3 ... 1e-2
+            # on J, far less on E, B after 16 steps)
+            achieved(None, np.abs(got - one[k]).max() / scale, 5e-2 if correct else 1e-12, 'fields ' + grp)
     ref = np.array([one['p_' + k] for k in PTCL])
     got = np.concatenate([np.array([p['p_' + k] for k in PTCL]) for p in parts], axis=1)
     assert got.shape == ref.shape and ref.shape[1] > 9.0e6       # nobody lost, duplicated or mis-injected
@@ -268,8 +285,8 @@ def test_c4_lwfa_4096x256_on_8_slabs_reproduces_the_single_domain():
     o1 = np.lexsort((ref[2], ref[1], ref[0], ref[7]))
     o2 = np.lexsort((got[2], got[1], got[0], got[7]))
     for j, k in enumerate(PTCL):
-        achieved(None, np.abs(got[j][o2] - ref[j][o1]).max() / max(np.abs(ref[j]).max(), 1e-300), 2.5e-12,
-                 'particles')          # measured 2.5e-13
+        achieved(None, np.abs(got[j][o2] - ref[j][o1]).max() / max(np.abs(ref[j]).max(), 1e-300),
+                 1e-3 if correct else 2.5e-12, 'particles')          # uncorrected: measured 2.5e-13
     del one, parts
     shutil.rmtree(outdir, ignore_errors=True)
 
