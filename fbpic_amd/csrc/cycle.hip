@@ -35,9 +35,12 @@ namespace fb {
 
 struct CycleArgs {
     long n;
-    double *x, *y, *z, *ux, *uy, *uz, *ig;
-    const double *w;
+    // (order: the kernel fetches these pointers from the kernel-argument segment in groups - x, y, z,
+    // home | ux, uy, uz, ig - with one scalar load per group, see karg_ptrs)
+    double *x, *y, *z;
     const int *home;                           // cell ir_upper + iz_upper (Nr+1) at the last sort
+    double *ux, *uy, *uz, *ig;
+    const double *w;
     int home_shift;                            // ... minus this: (cells the grid has moved since) x (Nr+1)
     double *Ex, *Ey, *Ez, *Bx, *By, *Bz;       // optional: gathered fields stored
     double invdz, zmin;
@@ -59,7 +62,8 @@ struct CycleArgs {
     cplx *baseJ, *baseR;                       // dep_grids_base() of the two targets
     const double *beta0, *betah;               // Ruyten coefficients, mode 0 / modes >= 1
     int chunks_per_wave;
-    unsigned long long *stats;                 // optional: [1024] strays of the J deposition
+    unsigned long long *stats;                 // optional: [0, 512) strays of the J deposition, [512, 1024) chunks
+                                               // with more than FB_CYCLE_BAD_CHUNK of them
     // RANK mode (fb_gather_push_rank_next_home): no deposition; x is left at x(n+1/2) and the cell
     // of x(n+1) and the particle's rank in it go to the counting-sort workspace
     int *rk_cell, *rk_rank, *rk_count;
@@ -112,6 +116,43 @@ __device__ __forceinline__ T *karg_ptr(int byte_offset)
                  : "=s"(p) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "n"(byte_offset));
     return p;
 }
+// ... and several neighbouring pointers with ONE scalar load and one wait (every karg_ptr is a
+// round trip to the scalar cache that the wave sits out: 20 per chunk before, 5 now)
+template <int N> struct KPtrs { char *p[N]; };
+__device__ __forceinline__ KPtrs<2> karg_ptrs2(int byte_offset)
+{
+    typedef unsigned long v2 __attribute__((ext_vector_type(2)));
+    v2 v;
+    asm volatile("s_load_dwordx4 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
+                 : "=s"(v) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "n"(byte_offset));
+    return {{(char *)v[0], (char *)v[1]}};
+}
+__device__ __forceinline__ KPtrs<4> karg_ptrs4(int byte_offset)
+{
+    typedef unsigned long v4 __attribute__((ext_vector_type(4)));
+    v4 v;
+    asm volatile("s_load_dwordx8 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
+                 : "=s"(v) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "n"(byte_offset));
+    return {{(char *)v[0], (char *)v[1], (char *)v[2], (char *)v[3]}};
+}
+__device__ __forceinline__ KPtrs<8> karg_ptrs8(int byte_offset)
+{
+    typedef unsigned long v8 __attribute__((ext_vector_type(8)));
+    v8 v;
+    asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
+                 : "=s"(v) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "n"(byte_offset));
+    return {{(char *)v[0], (char *)v[1], (char *)v[2], (char *)v[3], (char *)v[4], (char *)v[5], (char *)v[6],
+             (char *)v[7]}};
+}
+#define KOFF(field) ((int)__builtin_offsetof(CycleArgs, field))
+static_assert(__builtin_offsetof(CycleArgs, y) == __builtin_offsetof(CycleArgs, x) + 8 &&
+              __builtin_offsetof(CycleArgs, z) == __builtin_offsetof(CycleArgs, x) + 16 &&
+              __builtin_offsetof(CycleArgs, home) == __builtin_offsetof(CycleArgs, x) + 24 &&
+              __builtin_offsetof(CycleArgs, ux) == __builtin_offsetof(CycleArgs, x) + 32 &&
+              __builtin_offsetof(CycleArgs, ig) == __builtin_offsetof(CycleArgs, x) + 56 &&
+              __builtin_offsetof(CycleArgs, Bz) == __builtin_offsetof(CycleArgs, Ex) + 40 &&
+              __builtin_offsetof(CycleArgs, betah) == __builtin_offsetof(CycleArgs, beta0) + 8,
+              "pointer groups of karg_ptrs");
 #ifdef FB_ISA_MARKS
 #define FB_MARK(x) asm volatile("; MARK " x)
 #else
@@ -126,6 +167,10 @@ __device__ __forceinline__ void fb_wait_vm()
     asm volatile("" ::: "memory");
 }
 #define KP(T, field) karg_ptr<T>((int)__builtin_offsetof(CycleArgs, field))
+// a chunk of 64 particles of which more than this many have left their home cell costs several times
+// the normal chunk (every stray is a gather segment and a scatter of its own): counted for the host's
+// sort policy (a laser wake turns whole regions into such chunks, and their waves are the kernel's tail)
+#define FB_CYCLE_BAD_CHUNK 16
 
 // Front half of a chunk: what can be done as soon as the positions are there - the keys of the
 // home runs, the stencil origin of every particle, which particles are strays, the segment of
@@ -310,13 +355,15 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
     double mux, muy, muz, mig;         // momenta, 1/gamma of the next chunk
     auto load_pos = [&](long b, double &x_, double &y_, double &z_, int &h_) {
         const long i = min(b + lane, n - 1);
-        x_ = KP(const double, x)[i]; y_ = KP(const double, y)[i]; z_ = KP(const double, z)[i];
-        h_ = KP(const int, home)[i];
+        const KPtrs<4> q = karg_ptrs4(KOFF(x));            // x, y, z, home
+        x_ = ((const double *)q.p[0])[i]; y_ = ((const double *)q.p[1])[i]; z_ = ((const double *)q.p[2])[i];
+        h_ = ((const int *)q.p[3])[i];
     };
     auto load_mom = [&](long b) {
         const long i = min(b + lane, n - 1);
-        mux = KP(const double, ux)[i]; muy = KP(const double, uy)[i]; muz = KP(const double, uz)[i];
-        mig = KP(const double, ig)[i];
+        const KPtrs<4> q = karg_ptrs4(KOFF(ux));           // ux, uy, uz, ig
+        mux = ((const double *)q.p[0])[i]; muy = ((const double *)q.p[1])[i]; muz = ((const double *)q.p[2])[i];
+        mig = ((const double *)q.p[3])[i];
     };
     load_pos(base, xn, yn, zn, hn);
     load_mom(base);
@@ -324,7 +371,7 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
     front(fr, base, xn, yn, zn, hn);
     if (A.chunks_per_wave > 1) load_pos(base + 64, xn, yn, zn, hn);
     fb_wait_vm();
-    unsigned int nstray_J = 0;
+    unsigned int nstray_J = 0, nbad = 0;
     for (int ch = 0; ch < A.chunks_per_wave; ch++) {
         const long i = min(base + lane, n - 1);
         const bool act = base + lane < n;
@@ -438,18 +485,27 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
         auto wait_and_store = [&]() {
             fb_wait_vm();
             xn = xq; yn = yq; zn = zq; hn = hq;
+#ifdef FB_KNOCK_STORES
+            asm volatile("" :: "v"(pux), "v"(puy), "v"(puz), "v"(pig), "v"(x1), "v"(y1), "v"(z1));
+            if (false) {
+#else
             if (act) {
+#endif
                 if (store_eb) {
-                    KP(double, Ex)[i] = ex; KP(double, Ey)[i] = ey; KP(double, Ez)[i] = ez;
-                    KP(double, Bx)[i] = bx; KP(double, By)[i] = by; KP(double, Bz)[i] = bz;
+                    const KPtrs<4> e4 = karg_ptrs4(KOFF(Ex));      // Ex, Ey, Ez, Bx
+                    const KPtrs<2> b2 = karg_ptrs2(KOFF(By));      // By, Bz
+                    ((double *)e4.p[0])[i] = ex; ((double *)e4.p[1])[i] = ey; ((double *)e4.p[2])[i] = ez;
+                    ((double *)e4.p[3])[i] = bx; ((double *)b2.p[0])[i] = by; ((double *)b2.p[1])[i] = bz;
                 }
-                KP(double, ux)[i] = pux; KP(double, uy)[i] = puy; KP(double, uz)[i] = puz; KP(double, ig)[i] = pig;
+                const KPtrs<8> q = karg_ptrs8(KOFF(x));            // x, y, z, home, ux, uy, uz, ig
+                ((double *)q.p[4])[i] = pux; ((double *)q.p[5])[i] = puy; ((double *)q.p[6])[i] = puz;
+                ((double *)q.p[7])[i] = pig;
                 if constexpr (RANK) {
                     // the second half push belongs to the sort pass that follows (which deposits J
                     // from x(n+1/2) first): the position is left at x(n+1/2)
-                    KP(double, x)[i] = xh; KP(double, y)[i] = yh; KP(double, z)[i] = zh;
+                    ((double *)q.p[0])[i] = xh; ((double *)q.p[1])[i] = yh; ((double *)q.p[2])[i] = zh;
                 } else {
-                    KP(double, x)[i] = x1; KP(double, y)[i] = y1; KP(double, z)[i] = z1;
+                    ((double *)q.p[0])[i] = x1; ((double *)q.p[1])[i] = y1; ((double *)q.p[2])[i] = z1;
                 }
             }
         };
@@ -501,8 +557,9 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
             return min((int)ceil(A.invdr * (ra - A.rmin) - 0.5), Nr);
         };
         const int irJ = ruyten_index(xh, yh), irR = ruyten_index(x1, y1);
-        const double bJ0 = KP(const double, beta0)[irJ], bJh = KP(const double, betah)[irJ];
-        const double bR0 = KP(const double, beta0)[irR], bRh = KP(const double, betah)[irR];
+        const KPtrs<2> bq = karg_ptrs2(KOFF(beta0));           // beta0, betah
+        const double bJ0 = ((const double *)bq.p[0])[irJ], bJh = ((const double *)bq.p[1])[irJ];
+        const double bR0 = ((const double *)bq.p[0])[irR], bRh = ((const double *)bq.p[1])[irR];
         wait_and_store();
         if constexpr (!P::MERGED) {
             ej.stage_with(true, xh, yh, zh, wj, pux, puy, puz, pig, A.c_light, geom, bJ0, bJh, dkz, dkr, dnb);
@@ -534,6 +591,7 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
             const unsigned long long hmJ = __ballot(homeJ), smJ = __ballot(act && !homeJ);
             const unsigned long long hmR = __ballot(homeR), smR = __ballot(act && !homeR);
             nstray_J += __popcll(smJ);
+            nbad += (__popcll(smJ) > FB_CYCLE_BAD_CHUNK) ? 1u : 0u;
             wave_lds_release();
         FB_MARK("M_SCATTER");
             if (smJ | smR) {
@@ -562,8 +620,11 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
     } else {
         ed.flush(false);
     }
-    if (A.stats && lane == 0)
-        atomicAdd(A.stats + ((blockIdx.x * nwaves + wave) & 1023), (unsigned long long)nstray_J);
+    if (A.stats && lane == 0) {
+        const int slot = (blockIdx.x * nwaves + wave) & 511;
+        atomicAdd(A.stats + slot, (unsigned long long)nstray_J);
+        if (nbad) atomicAdd(A.stats + 512 + slot, (unsigned long long)nbad);
+    }
 }
 
 template <int NM, bool WIDE, bool RANK>

@@ -253,7 +253,11 @@ struct CycleDep {
                 if (jrD < cur_nb && ((neg >> t) & 1u)) v = -v;      // node below the axis: signed fold
                 voff = f_off[t] + (unsigned)((gz - jzD) * rsB + gr * csB);
             }
+#if defined(FB_KNOCK_FLUSH_ATOM)
+            asm volatile("" :: "v"(voff), "v"(v));           // (timing experiment: the flush without its atomics)
+#else
             atomicAdd((double *)(gbase + voff), v);
+#endif
         }
     }
 
@@ -395,7 +399,11 @@ struct CycleDep {
                     if (jrD < nb && ((neg >> t) & 1u)) v = -v;
                     voff = f_off[t] + (unsigned)((gz - jzD) * rsB + gr * csB);
                 }
+#if defined(FB_KNOCK_SCAT_ATOM)
+                asm volatile("" :: "v"(voff), "v"(v));       // (timing experiment: strays without their atomics)
+#else
                 atomicAdd((double *)(gbase + voff), v);
+#endif
             }
         }
     }

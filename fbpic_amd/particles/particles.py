@@ -138,6 +138,16 @@ class Particles(object):
         self.record_home_in_sort_pass = False     # set by Simulation.step for its sorting iterations
         self.cycle_sort_period = int(os.environ.get('FBPIC_AMD_SORT_PERIOD', '3'))
         self.cycle_stray_limit = float(os.environ.get('FBPIC_AMD_STRAY_LIMIT', '0.12'))
+        # ... or when more than `cycle_bad_limit` of the 64-particle chunks hold > 16 such particles (a
+        # laser wake: the strays are not spread out but fill whole regions, whose waves then are the
+        # tail of the launch - C3: 1.9 ms per pass against 1.5 for the two passes of a sorting
+        # iteration).  If already the FIRST pass after a sort reports that, the one-pass form does not
+        # fit the plasma as it is now: the next `cycle_suspend_iterations` iterations are two-pass
+        # (sorting) ones, then one pass probes again.
+        self.cycle_bad_limit = float(os.environ.get('FBPIC_AMD_BAD_CHUNK_LIMIT', '0.01'))
+        self.cycle_suspend_iterations = int(os.environ.get('FBPIC_AMD_SUSPEND', '16'))
+        self._cycle_suspended = 0
+        self.cycle_bad_fraction = None
         self._cycle_since_sort = 0
         self._cycle_stats = None          # device counters / pinned host copy / pending event
         self.cycle_sorts = 0              # diagnostics: sorts and passes of the one-pass cycle
@@ -542,27 +552,41 @@ class Particles(object):
         return n_move * (g0.Nr + 1)
 
     def _cycle_poll(self):
-        """Pick up the stray count of an earlier pass if its copy has landed."""
+        """Take in the counters of the last measured pass.  The read-back was issued right behind that
+        pass; its event is WAITED for here (one iteration later: the host runs at most that far
+        ahead of the device) - polling it with query() made the sequence of one- and two-pass
+        iterations, and with it the summation order of J and rho, depend on host timing."""
         st = self._cycle_stats
-        if st is not None and st[2] is not None and st[2][0].query():
-            total = int(st[1].sum())
-            self.cycle_stray_fraction = float(total - st[3]) / max(st[2][1], 1)
+        if st is not None and st[2] is not None:
+            ev, ntot, r = st[2]
+            ev.synchronize()
+            strays, bad = int(st[1][:512].sum()), int(st[1][512:].sum())
+            self.cycle_stray_fraction = float(strays - st[3][0]) / max(ntot, 1)
+            self.cycle_bad_fraction = float(bad - st[3][1]) / max((ntot + 63) // 64, 1)
             self.cycle_last_stray_fraction = self.cycle_stray_fraction
-            st[3] = total
+            st[3] = (strays, bad)
             st[2] = None
+            if r == 1 and self.cycle_bad_fraction > self.cycle_bad_limit:
+                self._cycle_suspended = self.cycle_suspend_iterations
 
     def _after_home_sort(self):
         """Book-keeping of a sort that has recorded the home cells in `cell_idx`."""
+        self._cycle_poll()
         self._cycle_since_sort = 0
-        if self._cycle_stats is not None and self._cycle_stats[2] is not None:
-            self._cycle_stats[2][0].synchronize()      # (a copy issued at least one pass ago)
-            self._cycle_poll()
         self.cycle_stray_fraction = None
+        self.cycle_bad_fraction = None
         self.cycle_sorts += 1
 
     def cycle_wants_sort(self, fld):
-        """True when the next Particles.cycle of this species would start with a sort."""
-        return bool(self.q != 0 and self.Ntot > 0 and self._cycle_needs_sort(fld.interp[0]))
+        """True when the next Particles.cycle of this species would start with a sort (Simulation.step
+        then runs the two-pass sequence for the iteration, whose second pass sorts)."""
+        if not (self.q != 0 and self.Ntot > 0):
+            return False
+        self._cycle_poll()
+        if self._cycle_suspended > 0:
+            self._cycle_suspended -= 1
+            return True
+        return bool(self._cycle_needs_sort(fld.interp[0]))
 
     def _cycle_needs_sort(self, g0):
         if not self._home_valid or self._cycle_since_sort >= self.cycle_sort_period:
@@ -570,8 +594,9 @@ class Particles(object):
         if self._home_shift(g0) is None:
             return True                      # another grid: the recorded cells are not cells any more
         self._cycle_poll()
-        return (self.cycle_stray_fraction is not None
-                and self.cycle_stray_fraction > self.cycle_stray_limit)
+        if self.cycle_stray_fraction is not None and self.cycle_stray_fraction > self.cycle_stray_limit:
+            return True
+        return self.cycle_bad_fraction is not None and self.cycle_bad_fraction > self.cycle_bad_limit
 
     def cycle(self, fld, comm, dt, store_fields=True, wrap_z=None):
         """gather -> push_p -> push_x(dt/2) -> deposit('J') -> push_x(dt/2) -> deposit('rho') of
@@ -605,9 +630,10 @@ class Particles(object):
             self._after_home_sort()
         t = _capi.torch()
         if self._cycle_stats is None or self._cycle_stats[0].device != self.x.device:
-            # device counters, pinned host copy, (event, Ntot) of a pending read, total last read
+            # device counters, pinned host copy, (event, Ntot, passes since the sort) of a pending
+            # read, totals (strays, bad chunks) last read
             self._cycle_stats = [t.zeros(1024, dtype=t.int64, device=self.x.device),
-                                 t.zeros(1024, dtype=t.int64).pin_memory(), None, 0]
+                                 t.zeros(1024, dtype=t.int64).pin_memory(), None, (0, 0)]
         views = []
         for m in range(Nm):
             views += [grid[m].Er, grid[m].Et, grid[m].Ez, grid[m].Br, grid[m].Bt, grid[m].Bz]
@@ -617,9 +643,9 @@ class Particles(object):
         ruy0 = grid[0].d_ruyten_linear_coef
         ruyh = grid[1 if Nm > 1 else 0].d_ruyten_linear_coef
         stats = self._cycle_stats
-        # (the counters are cumulative - the pass adds to them - and are read back whenever no
-        # earlier read-back is still travelling: one small copy, no memset launch)
-        measure = stats[2] is None
+        # (the counters are cumulative - the pass adds to them; one small copy per pass, no memset)
+        self._cycle_poll()
+        measure = True
         rc = lib.fb_gather_push_deposit_J_rho(
             _SHAPE[self.particle_shape], Nm, self.Ntot, p(self.x), p(self.y), p(self.z),
             p(self.ux), p(self.uy), p(self.uz), p(self.inv_gamma), p(self.w), p(self.cell_idx),
@@ -634,7 +660,7 @@ class Particles(object):
             stats[1].copy_(stats[0], non_blocking=True)
             ev = t.cuda.Event()
             ev.record()
-            stats[2] = (ev, self.Ntot)
+            stats[2] = (ev, self.Ntot, self._cycle_since_sort + 1)
         self._cycle_since_sort += 1
         self.cycle_passes += 1
         self._prerank = None

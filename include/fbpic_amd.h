@@ -365,7 +365,9 @@ int fb_push_x_sort_deposit_J_rho(long n, int ncell, const double *x, const doubl
  * runs of equal cells of the sorted depositions, and particles that have since left their home
  * cell are gathered / deposited on their own.  Any `home_cell` content gives the same result; how
  * many particles take the slow path is what changes, and `stats` (optional, 1024 counters that
- * the call ADDS to) receives their number for the caller's re-sort policy.
+ * the call ADDS to) receives their number for the caller's re-sort policy: the sum of [0, 512) is the
+ * number of such particles (J deposition), the sum of [512, 1024) the number of 64-particle chunks
+ * in which more than 16 particles took it.
  * `home_cell_shift` is subtracted from every home cell before use: n_move (Nr + 1) when the grid
  * has advanced by n_move cells since the sort (moving window, boundaries/moving_window.py:60-239 -
  * the cell of a particle that stays where it is moves n_move rows down), 0 otherwise.

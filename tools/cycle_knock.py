@@ -32,7 +32,7 @@ with GpuMemoryManager(sim):
         r = sim.ptcl[0]._cycle_since_sort
         if r in RS and r not in res['default']:
             saved = [getattr(s, k).clone() for s in sim.ptcl for k in ('ux', 'uy', 'uz', 'inv_gamma')]
-            per = [(s.cycle_sort_period, s.cycle_stray_limit, s._cycle_since_sort) for s in sim.ptcl]
+            per = [(s.cycle_sort_period, s.cycle_stray_limit, s._cycle_since_sort, s.cycle_bad_limit) for s in sim.ptcl]
             wz = (fld.interp[0].zmin, fld.interp[0].zmax)
             for name, l in libs:
                 _capi._lib = l
@@ -40,7 +40,7 @@ with GpuMemoryManager(sim):
                 for rep in range(REPS):
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     for s in sim.ptcl:
-                        s.cycle_sort_period, s.cycle_stray_limit = 10 ** 9, 2.0
+                        s.cycle_sort_period, s.cycle_stray_limit, s.cycle_bad_limit = 10 ** 9, 2.0, 2.0
                     e0.record()
                     for s in sim.ptcl:
                         if s.q != 0:
@@ -49,7 +49,7 @@ with GpuMemoryManager(sim):
                     ms.append(e0.elapsed_time(e1))
                 i = 0
                 for s, pr in zip(sim.ptcl, per):
-                    s.cycle_sort_period, s.cycle_stray_limit, s._cycle_since_sort = pr
+                    s.cycle_sort_period, s.cycle_stray_limit, s._cycle_since_sort, s.cycle_bad_limit = pr
                     for k in ('ux', 'uy', 'uz', 'inv_gamma'):
                         getattr(s, k).copy_(saved[i]); i += 1
                 fld.erase_source_records()
