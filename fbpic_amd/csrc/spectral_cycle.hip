@@ -142,6 +142,13 @@ __device__ __forceinline__ void sc_product(const double *__restrict__ panel, int
 // matrix fragments are already in registers, so the batch gets that many MFMA steps to land and
 // the transfer overlaps the products); J and rho are stored by the update itself, the new E, B
 // in two batches at the start of the second and third inverse product.
+//
+// ONLY_CORRECT (fb_spect_cycle_standard with correct_currents = 2): the launch ends behind the
+// curl-free correction - forward transforms + correction, J and rho_next stored, nothing else
+// touched.  For z-decomposed runs, where the guard cells of the CORRECTED J are added between the
+// correction and the push (main.py:530-542): the transform and the correction were two launches
+// with a round trip of J, rho through the spectral slab between them.
+template <bool ONLY_CORRECT>
 __global__ __launch_bounds__(512) void k_spect_cycle(SpectCycleArgs A)
 {
     constexpr int NTHREADS = 512;
@@ -211,8 +218,10 @@ __global__ __launch_bounds__(512) void k_spect_cycle(SpectCycleArgs A)
     {
 #pragma unroll
         for (int h = 0; h < 2; h++) {
+            if constexpr (!ONLY_CORRECT) {
 #pragma unroll
-            for (int j = 0; j < 6; j++) c_f[h][j] = sc_ld(f[j] + co[h]);
+                for (int j = 0; j < 6; j++) c_f[h][j] = sc_ld(f[j] + co[h]);
+            }
             c_f[h][6] = sc_ld(f[9] + co[h]);
         }
         double4_t a1[1];
@@ -221,7 +230,7 @@ __global__ __launch_bounds__(512) void k_spect_cycle(SpectCycleArgs A)
 #pragma unroll
         for (int h = 0; h < 2; h++)
 #pragma unroll
-            for (int j = 0; j < 8; j++) c_t[h][j] = tb[j][ci[h]];
+            for (int j = (ONLY_CORRECT ? 5 : 0); j < 8; j++) c_t[h][j] = tb[j][ci[h]];
         sc_product<1>(sc_lds + 1 * SC_PANEL, SC_PANEL, A.fwd[3 * m + 1], A.fwd[3 * m + 2], B, Nr, K4, n0, li, lk, a1);
         aJ[1] = a1[0];
         // filter factor of the sources (fz[iz] * fr[ir] * F as in numba_filter_*, k_hankel epilogue)
@@ -232,8 +241,38 @@ __global__ __launch_bounds__(512) void k_spect_cycle(SpectCycleArgs A)
         }
         double4_t a2[2];
         // (the first rows of the first inverse matrix travel during the cell-local update)
-        sc_product<2>(sc_lds + 2 * SC_PANEL, SC_PANEL, A.fwd[3 * m + 2], A.inv[3 * m + 0], B, Nr, K4, n0, li, lk, a2);
+        sc_product<2>(sc_lds + 2 * SC_PANEL, SC_PANEL, A.fwd[3 * m + 2], ONLY_CORRECT ? nullptr : A.inv[3 * m + 0], B,
+                      Nr, K4, n0, li, lk, a2);
         aJ[2] = a2[0]; aJ[3] = a2[1];
+    }
+    if constexpr (ONLY_CORRECT) {
+        // numba_correct_currents_curlfree_standard (fields/numba_methods.py:63-85), expressions of
+        // k_psatd_step; rho_next goes to its own field (the push that follows the J exchange shifts it)
+        const int n = n0 + li;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int zz = zb + lk + 4 * h;
+            if (zz < Nz && n < Nr) {
+                const long o = co[h];
+                const double cz = c_cz[h];
+                cplx jp = {cz * aJ[0][h], cz * aJ[0][2 + h]};
+                cplx jm = {cz * aJ[1][h], cz * aJ[1][2 + h]};
+                cplx jz = {cz * aJ[2][h], cz * aJ[2][2 + h]};
+                const cplx rn = {cz * aJ[3][h], cz * aJ[3][2 + h]};
+                const double krr = c_t[h][5], kzz = c_t[h][6];
+                const cplx rp = c_f[h][6];
+                const cplx t1 = sc_rmul(A.inv_dt, sc_sub(rn, rp));
+                const cplx t2 = sc_rmul(kzz, sc_imul(jz));
+                const cplx t3 = sc_rmul(krr, sc_sub(jp, jm));
+                const cplx F = sc_rmul(-c_t[h][7], sc_add(sc_add(t1, t2), t3));
+                jp = sc_add(jp, sc_rmul(0.5 * krr, F));
+                jm = sc_add(jm, sc_rmul(-0.5 * krr, F));
+                jz = sc_add(jz, sc_rmul(kzz, sc_imul(sc_rmul(-1., F))));
+                sc_st(f[6] + o, jp); sc_st(f[7] + o, jm); sc_st(f[8] + o, jz);
+                sc_st(f[10] + o, rn);
+            }
+        }
+        return;
     }
     __syncthreads();                 // the source panels are dead: the E, B panels take their place
 
@@ -370,26 +409,33 @@ extern "C" int fb_spect_cycle_standard(int Nm, const void *const *src, long src_
         A.fr[i] = (i < Nm && filter_r) ? filter_r[i] : nullptr;
         if ((A.fz[i] == nullptr) != (A.fr[i] == nullptr)) { set_error(who, "filter_z and filter_r go together"); return -1; }
     }
+    if (correct_currents != 2 && (!inv_mats || !out)) { set_error(who, "inv_mats and out are required"); return -1; }
     for (int i = 0; i < 3 * FB_MAX_MODES; i++) {
         A.fwd[i] = i < 3 * Nm ? fwd_mats[i] : nullptr;
-        A.inv[i] = i < 3 * Nm ? inv_mats[i] : nullptr;
+        A.inv[i] = (i < 3 * Nm && inv_mats) ? inv_mats[i] : nullptr;
     }
     for (int i = 0; i < 11 * FB_MAX_MODES; i++) A.f[i] = i < 11 * Nm ? (cplx *)fields[i] : nullptr;
     for (int i = 0; i < 8 * FB_MAX_MODES; i++) A.t[i] = i < 8 * Nm ? tables[i] : nullptr;
-    for (int i = 0; i < 6 * FB_MAX_MODES; i++) A.out[i] = i < 6 * Nm ? (cplx *)out[i] : nullptr;
+    for (int i = 0; i < 6 * FB_MAX_MODES; i++) A.out[i] = (i < 6 * Nm && out) ? (cplx *)out[i] : nullptr;
     A.irs = src_row_stride; A.srs = spect_row_stride; A.ors = out_row_stride;
     A.dt = dt; A.inv_dt = 1. / dt; A.c2 = c * c; A.eps0 = epsilon_0; A.mu0 = mu_0;
     A.correct = correct_currents; A.use_true_rho = use_true_rho; A.Nz = Nz; A.Nr = Nr;
     const size_t lds_bytes = (size_t)6 * SC_PANEL * 8;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_spect_cycle, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void *)k_spect_cycle<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds_bytes);
+        if (e != hipSuccess) return check(e, who);
+        e = hipFuncSetAttribute((const void *)k_spect_cycle<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(4 * SC_PANEL * 8));
         if (e != hipSuccess) return check(e, who);
         attr_done = true;
     }
     dim3 grid((Nz + SC_TZ - 1) / SC_TZ, Nm);
     // 8 waves of one 16-column tile each (4 waves of two tiles: 58 against 52 us at C2, round 4)
-    hipLaunchKernelGGL(k_spect_cycle, grid, dim3(512), lds_bytes, (hipStream_t)stream, A);
+    if (correct_currents == 2)
+        hipLaunchKernelGGL(k_spect_cycle<true>, grid, dim3(512), (size_t)4 * SC_PANEL * 8, (hipStream_t)stream, A);
+    else
+        hipLaunchKernelGGL(k_spect_cycle<false>, grid, dim3(512), lds_bytes, (hipStream_t)stream, A);
     return check(hipGetLastError(), who);
 }

@@ -107,7 +107,7 @@ class Fields(object):
         but psatd_step / spect2interp('EB') in their places finds the grids as after the separate
         calls."""
         if self._pending_hankel is not None:
-            fuse_filter, self._pending_hankel = self._pending_hankel, None
+            (fuse_filter, _), self._pending_hankel = self._pending_hankel, None
             self._hankel_J_and_rho_next(self._src_kz_views(), fuse_filter)
         if self._EB_in_kz_r:
             self._EB_in_kz_r = False
@@ -399,7 +399,7 @@ class Fields(object):
         if from_records and lib.fb_zfft_supported(Nz):
             # the z-FFT gathers its columns straight from the deposition's records
             S = self.source_records()
-            defer_hankel = bool(defer_hankel and self.spect_cycle_supported())
+            defer_hankel = defer_hankel if (defer_hankel and self.spect_cycle_supported()) else False
             dst = self.d_interp[:, 6 * Nm, :] if defer_hankel else self.d_scratch[:, 0, :]
             dst_rs = self.d_interp.stride(0) if defer_hankel else self.d_scratch.stride(0)
             _capi.check(lib.fb_zfft_from_records_consume(
@@ -408,8 +408,9 @@ class Fields(object):
             self._records_clean = True
             if defer_hankel:
                 # psatd_step() runs the transform together with the solver step and the inverse
-                # transform of E, B (spect_cycle); anything else first finishes it on its own
-                self._pending_hankel = bool(fuse_filter)
+                # transform of E, B (spect_cycle) - or, defer_hankel = 'correct' (decomposed domain),
+                # together with the current correction only; anything else first finishes it on its own
+                self._pending_hankel = (bool(fuse_filter), defer_hankel)
                 return
         elif from_records and lib.fb_fft_generic_from_records_supported(Nz):
             # lengths of the two-sweep generic FFT (4416 = 192 x 23): its head gathers the records
@@ -444,15 +445,16 @@ class Fields(object):
             nf, pa(ins), pa(in2), sgn, scr_f[0].stride(0), pa(out), self.d_spect.stride(0),
             pa(mats), pa(sk), pa(fz), pa(fr), 1.0, Nz, Nr, st), 'fb_hankel_rt_to_pm_scaled')
 
-    def spect_cycle(self, correct_currents, use_true_rho):
+    def spect_cycle(self, correct_currents, use_true_rho, only_correct=False):
         """The pending forward Hankel transform of J | rho_next, the solver step
         (correct_currents + push, as psatd_step) and the inverse Hankel transform of the new E, B
         in one launch (fb_spect_cycle_standard); E, B are left in (kz, r) space in the scratch slab
-        for spect2interp('EB')."""
+        for spect2interp('EB').  `only_correct` (decomposed domain): the transform and the
+        curl-free correction only - the J guard exchange and the push follow."""
         from scipy.constants import c, epsilon_0, mu_0
         Nm = self.Nm
         lib, pa, st = _capi.lib(), _capi.ptr_array, _capi.stream()
-        fuse_filter, self._pending_hankel = self._pending_hankel, None
+        (fuse_filter, _), self._pending_hankel = self._pending_hankel, None
         src = self._src_kz_views()                 # [J m0 r,t,z | J m1 ... | rho m0 | rho m1 ...]
         fields, tables, srcs, outs, fwd, inv = [], [], [], [], [], []
         scr = self._field_views(self.d_scratch, 0, 6 * Nm)
@@ -471,10 +473,10 @@ class Fields(object):
         rc = lib.fb_spect_cycle_standard(
             Nm, pa(srcs), self.d_interp.stride(0), pa(iv), pa(fwd), pa(inv),
             pa(fz) if fz else None, pa(fr) if fr else None, pa(fields), self.d_spect.stride(0), pa(tables),
-            self.dt, int(bool(correct_currents)), int(bool(use_true_rho)), c, epsilon_0, mu_0,
-            pa(outs), self.d_scratch.stride(0), self.Nz, self.Nr, st)
+            self.dt, 2 if only_correct else int(bool(correct_currents)), int(bool(use_true_rho)),
+            c, epsilon_0, mu_0, pa(outs), self.d_scratch.stride(0), self.Nz, self.Nr, st)
         _capi.check(rc, 'fb_spect_cycle_standard')
-        self._EB_in_kz_r = True
+        self._EB_in_kz_r = not only_correct
 
     def spect2interp(self, fieldtype):
         """inverse DHT(r) then inverse FFT(z) (reference: fields.py:370-429)."""
@@ -590,11 +592,11 @@ class Fields(object):
         (correction of all modes, one launch), then correct_currents=False (push + rho
         shift of all modes, one launch).  `n_move` != 0: the moving window's translation of
         E, B, rho_prev and J by n_move cells rides along (fb_psatd_step_standard_shift)."""
-        if self._pending_hankel is not None and not only_correct and not n_move \
-                and not self._EB_in_kz_r:
+        if self._pending_hankel is not None and not n_move and not self._EB_in_kz_r \
+                and (self._pending_hankel[1] == 'correct') == bool(only_correct):
             self._touch(keep_pending=True)
             self._need_gpu()
-            self.spect_cycle(correct_currents, use_true_rho)
+            self.spect_cycle(correct_currents, use_true_rho, only_correct=only_correct)
             return
         self._touch()
         self._need_gpu()

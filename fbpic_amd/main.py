@@ -394,6 +394,20 @@ class Simulation(object):
                     and comm.nz_damp == 0 and comm.moving_win is None and self.v_comoving is None
                     and not self.mirrors and self.fld.current_correction == 'curl-free')
 
+    def _hankel_deferral(self):
+        """How the forward Hankel transform of the freshly deposited J, rho_next is run: True - with
+        the solver step and the inverse transform of E, B (single periodic domain, _spectral_cycle_ok);
+        'correct' - with the curl-free correction, in front of the J guard exchange of a decomposed
+        domain (the in-step transform is only reached there when the correction will run: the
+        uncorrected deposits exchange their guard cells on the interpolation grid); False - on its own."""
+        if self._spectral_cycle_ok():
+            return True
+        if (self._in_step and not self.reference_sequence and self.comm.size > 1
+                and self.v_comoving is None and not self.mirrors
+                and self.fld.current_correction == 'curl-free'):
+            return 'correct'
+        return False
+
     def _particles_one_pass(self, store_fields, wrap_z, correct_currents, use_true_rho):
         """gather, push_p, push_x, deposit('J'), push_x, deposit('rho_next') (main.py:469-528) as
         one pass per species; J and rho_next are then transformed together."""
@@ -405,7 +419,7 @@ class Simulation(object):
             species.cycle(fld, self.comm, self.dt, store_fields=store_fields, wrap_z=wrap_z)
             species.keep_fields_sorted = False
         fld.interp2spect_J_and_rho_next(fuse_filter=self.filter_currents, from_records=True,
-                                        defer_hankel=self._spectral_cycle_ok())
+                                        defer_hankel=self._hankel_deferral())
         # (what deposit() records: single domain only when these are True, see _one_pass_ok)
         fld.exchanged_source['J'] = (correct_currents is False)
         fld.exchanged_source['rho_next'] = (use_true_rho is True)
@@ -667,7 +681,7 @@ class Simulation(object):
                 self._J_transform_pending = False
                 fld.interp2spect_J_and_rho_next(fuse_filter=self.filter_currents,
                                                 from_records=records,
-                                                defer_hankel=self._spectral_cycle_ok())
+                                                defer_hankel=self._hankel_deferral())
             else:
                 self._flush_J_transform()
                 fld.interp2spect(fieldtype, fuse_divide_by_volume=True,

@@ -496,7 +496,12 @@ int fb_push_eb_comoving(void *Ep, void *Em, void *Ez, void *Bp, void *Bm, void *
  *   fields[11m ..], tables[8m ..] : as fb_psatd_step_standard
  *   out[6m ..]   : E (p, m, z), B (p, m, z) of mode m in (kz, r) space: the input of fb_zfft_pm_to_rt
  * Must not alias: src and out (different workgroups read / write the same rows of different fields).
- * Nr <= 128 (fb_spect_cycle_supported); correct_currents 0 / 1. */
+ * Nr <= 128 (fb_spect_cycle_supported); correct_currents 0 / 1, or
+ * correct_currents = 2: the launch ends behind the curl-free correction - identical to
+ *   fb_hankel_rt_to_pm_scaled(...) + fb_psatd_step_standard(..., correct_currents = 2, ...):
+ * the corrected J and rho_next are stored, E, B, rho_prev are not touched, inv_mats / out may be
+ * NULL.  For z-decomposed runs, whose J guard cells are added between the correction and the push
+ * (main.py:530-542). */
 int fb_spect_cycle_supported(int Nm, int Nr);
 int fb_spect_cycle_standard(int Nm, const void *const *src, long src_row_stride,
                             const double *const *invvol, const double *const *fwd_mats,

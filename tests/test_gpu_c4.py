@@ -316,3 +316,8 @@ def test_bench_strong_scaling_dry_run_on_8_ranks():
     assert out['n_gpus'] == 8 and out['scaling'] == 'strong' and out['steps'] == 4
     assert out['config']['particles'] == 4194304 and out['value'] > 0
     assert 'x8' in out['config']['parallelism']
+    # the line carries the other scaling too (BASELINE's metric names the fixed box, the driver's
+    # contract fixed work per GPU): here 8 slabs of 1024 rows
+    other = out['other_scaling']
+    assert other['scaling'] == 'weak' and other['particles'] == 8 * 4194304 and other['value'] > 0
+    assert other['rows_per_rank'] == 1024

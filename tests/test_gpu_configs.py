@@ -308,8 +308,11 @@ def test_c3_lwfa_full_size():
     assert nstep * per_cell_z <= n1 - n0 <= (nstep + sim.comm.nz_damp + sim.comm.n_guard
                                              + 2 * sim.comm.exchange_period) * per_cell_z
     assert 0.01 < umax < 50.
-    # most iterations are one pass over the particles (re-keyed home cells, see Particles._home_shift)
-    assert s.cycle_passes >= nstep // 2, (s.cycle_passes, s.cycle_sorts)
+    # the moving window does not rule the one-pass form out (re-keyed home cells, Particles._home_shift):
+    # it is probed after the sorts - and given up again for `cycle_suspend_iterations` iterations
+    # each time the wake behind the a0 = 4 pulse fills whole chunks with particles that have left
+    # their home cell (the bad-chunk policy, particles.py)
+    assert s.cycle_passes >= 1 and s.cycle_passes + s.cycle_sorts >= nstep - 2, (s.cycle_passes, s.cycle_sorts)
     print('C3: %d -> %d macroparticles over %d steps, %d one-pass iterations' % (n0, n1, nstep, s.cycle_passes))
 
 

@@ -146,7 +146,7 @@ def _launch(kind, name, world, backend='gloo'):
     return [np.load(os.path.join(outdir, 'r%d.npz' % r)) for r in range(world)]
 
 
-def _compare(got, g, tag, rank, tol_f, tol_p, nfields=10, ptcl=True, worst=None):
+def _compare(got, g, tag, rank, tol_f, tol_p, nfields=10, ptcl=True, worst=None, global_particle_scale=False):
     ref = g['%s_r%d_interp' % (tag, rank)]
     Nm = ref.shape[0]
     for m in range(Nm):
@@ -172,10 +172,16 @@ def _compare(got, g, tag, rank, tol_f, tol_p, nfields=10, ptcl=True, worst=None)
     o1 = np.lexsort((refp[2], refp[1], refp[0], refp[7]))
     o2 = np.lexsort((gotp[2], gotp[1], gotp[0], gotp[7]))
     for j, k in enumerate(PTCL):
-        # scale: max of the attribute over ALL ranks (the momenta of a slab the laser has not
-        # reached are rounding noise of the fields: nothing to compare them with on their own)
-        sc = max(np.abs(g['%s_r%d_ptcl0' % (tag, r)][j]).max() if g['%s_r%d_ptcl0' % (tag, r)].size else 0.
-                 for r in range(int(g['nranks'])))
+        # scale: the rank's own maximum of the attribute.  Only the 8-rank laser-wakefield fixture
+        # compares against the maximum over ALL ranks (`global_particle_scale`): there the momenta
+        # of a slab the laser has not reached are rounding noise of the fields - nothing to compare
+        # them with on their own; everywhere else a rank whose momenta are small must still be
+        # right relative to ITS data.
+        if global_particle_scale:
+            sc = max(np.abs(g['%s_r%d_ptcl0' % (tag, r)][j]).max() if g['%s_r%d_ptcl0' % (tag, r)].size else 0.
+                     for r in range(int(g['nranks'])))
+        else:
+            sc = np.abs(refp[j]).max() if refp.size else 0.
         if sc > 0:
             err = np.abs(gotp[j][o2] - refp[j][o1]).max() / sc
             if worst is not None:
@@ -261,7 +267,8 @@ def test_decomposed_lwfa_8_ranks_with_current_correction_vs_reference_ranks():
     moved = 0
     for upto in steps:
         for r in range(8):
-            _compare(got[r], g, 's%d' % upto, r, 2.5e-12, 2.5e-12, ptcl=(upto == steps[-1]), worst=worst)
+            _compare(got[r], g, 's%d' % upto, r, 2.5e-12, 2.5e-12, ptcl=(upto == steps[-1]), worst=worst,
+                     global_particle_scale=True)
     # the fixture does hand particles over between all neighbours: every inner rank ends with
     # particles it did not start with (the plasma is at rest in the lab, the window moves 7 cells)
     for r in range(1, 8):
