@@ -56,9 +56,16 @@ template <int NM> struct CycleDepLayout {
     static constexpr int ROW_SJ = 1, ROW_TJ = 2, ROW_AJ = 2 + NTR, ROW_CJ = ROW_AJ + 3;
     static constexpr int ROW_SR = ROW_CJ + NCS, ROW_TR = ROW_SR + 1, ROW_AR = ROW_SR + 1 + NTR, ROW_CR = ROW_AR + 1;
     static constexpr int NROWS = ROW_CR + NCS;
-    // row stride in doubles: the (row, particle) pairs of a fragment read - up to 16 rows x 4
-    // consecutive particles - fall two by two on the 32 bank pairs (the rate of a 64-lane b64 read)
-    static constexpr int PAD = 66;
+    // row stride in doubles, ODD: a 64-lane ds_read_b64 is served in four passes of 16 lanes, and the
+    // 16 lanes of a pass (one particle, up to 15 different rows) must fall on 16 different 8-byte slots
+    // of the 128-B LDS word - slot = (row PAD + particle) mod 16.  With 66 the rows of the two engines
+    // (8 rows apart) aliased: SQ_LDS_BANK_CONFLICT 312 cycles per 64 particles; 65: 12; 67: 0
+    // (profiles/r05_sq_onepass.txt).  15 rows x 67 + the 4.7 KB gather panel = 12 776 B per wave: 12
+    // one-wave workgroups share a CU up to 12 800 B, 11 from 12 896 B on (tools/lds_probe.hip).
+#ifndef FB_CD_PAD
+#define FB_CD_PAD 67
+#endif
+    static constexpr int PAD = FB_CD_PAD;
     // tiles of 4 amplitudes: the largest variant decides (J, modes >= 1)
     static constexpr int NTL = (NAJH > 4) ? (NAJH + 3) / 4 : 1;
     static constexpr int WAVE_DOUBLES = NROWS * PAD + 4;
@@ -156,16 +163,15 @@ struct CycleDep {
         cr0 = jrA ? 1. : 0.; cr1 = jrA ? -1. : 1.;
         cur_z = DEP_NOKEY; cur_r = DEP_NOKEY; cur_nb = 0;
         // The last step of a run reads up to 3 particles beyond it (masked weights, but the values
-        // must be finite): columns 64, 65 of every row and the 4 doubles behind the last row are
+        // must be finite): the columns from 64 on of every row and the 4 doubles behind the last row are
         // never staged - zero them once.
         if (lane < L::NROWS) {
-            *(double *)(P + (lane * PAD + 64) * 8) = 0.;
-            *(double *)(P + (lane * PAD + 65) * 8) = 0.;
+#pragma unroll
+            for (int cpad = 64; cpad < PAD; cpad++) *(double *)(P + (lane * PAD + cpad) * 8) = 0.;
         }
         if (lane < 4) *(double *)(P + (L::NROWS * PAD + lane) * 8) = 0.;
         // the row of ones (Y of the mode-0 amplitudes): written once
         *(double *)(P + (L::ROW_ONE * PAD + lane) * 8) = 1.;
-        if (lane < 2) *(double *)(P + (L::ROW_ONE * PAD + 64 + lane) * 8) = 1.;
     }
 
     // ---- phase 1, lane = particle: amplitudes, first shape factors, stencil key of engine E

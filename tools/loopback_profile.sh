@@ -12,7 +12,7 @@ import sqlite3, glob
 db = glob.glob('gpurun_out/loop/stats/**/*.db', recursive=True)[0]
 cur = sqlite3.connect(db).cursor()
 rows = cur.execute('select name, start, end from kernels order by start').fetchall()
-g = [i for i, r in enumerate(rows) if 'k_gather' in r[0]]
+g = [i for i, r in enumerate(rows) if 'k_gather' in r[0] or 'k_cycle_linear' in r[0]]   # one per step
 # steps 16..27 of the timed call: between two particle exchanges
 i0, i1 = g[-11], g[-1]
 busy = sum(r[2] - r[1] for r in rows[i0:i1])
