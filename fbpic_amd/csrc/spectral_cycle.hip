@@ -29,6 +29,15 @@
 
 namespace fb {
 
+#ifdef SC_TRACE
+// timing experiment (tools/sc_trace.py): shader-clock stamps of wave 0 of every workgroup at the phase
+// boundaries of k_spect_cycle<false>
+__device__ unsigned long long sc_trace_buf[4096 * 8];
+#define SC_STAMP(i) do { if (tid == 0) sc_trace_buf[((blockIdx.y * gridDim.x + blockIdx.x) & 4095) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SC_STAMP(i) do { } while (0)
+#endif
+
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ cplx sc_add(cplx a, cplx b) { return {a.re + b.re, a.im + b.im}; }
@@ -161,6 +170,7 @@ __global__ __launch_bounds__(512) void k_spect_cycle(SpectCycleArgs A)
     const int Nz = A.Nz, Nr = A.Nr;
     const int K4 = (Nr + 4 * SC_PF - 1) / (4 * SC_PF) * SC_PF;     // MFMA steps over K (multiple of SC_PF)
     const int n0 = 16 * wave;
+    SC_STAMP(0);
 
     // ---- sources -> LDS panels [field][i = kz_local + 8 ri][k = r]: p, m, z, rho
     // (p = (r - i t) / 2, m = (r + i t) / 2, each times 1 / volume: spectral_transformer.py:208-210
@@ -195,6 +205,7 @@ __global__ __launch_bounds__(512) void k_spect_cycle(SpectCycleArgs A)
     ScStream B;
     sc_prime(B, A.fwd[3 * m + 0], Nr, n0, li, lk);
     __syncthreads();
+    SC_STAMP(1);
 
     // ---- this lane's 2 cells (kz = zb + lk + 4 h, kr = n0 + li): E, B, rho_prev and the tables,
     // requested in three batches in front of the three forward products.  Cells outside the grid
@@ -245,6 +256,7 @@ __global__ __launch_bounds__(512) void k_spect_cycle(SpectCycleArgs A)
                       Nr, K4, n0, li, lk, a2);
         aJ[2] = a2[0]; aJ[3] = a2[1];
     }
+    SC_STAMP(2);
     if constexpr (ONLY_CORRECT) {
         // numba_correct_currents_curlfree_standard (fields/numba_methods.py:63-85), expressions of
         // k_psatd_step; rho_next goes to its own field (the push that follows the J exchange shifts it)
@@ -350,7 +362,9 @@ __global__ __launch_bounds__(512) void k_spect_cycle(SpectCycleArgs A)
             P0[5 * SC_PANEL] = bz.re; P0[5 * SC_PANEL + 8 * SC_RS] = bz.im;
         }
     }
+    SC_STAMP(3);
     __syncthreads();
+    SC_STAMP(4);
 
     // ---- inverse products, E and B of a component against one matrix stream, written to the
     // (kz, r) slab the backward z-FFT reads (out[6 m + j], j = Ep Em Ez Bp Bm Bz)
@@ -380,12 +394,20 @@ __global__ __launch_bounds__(512) void k_spect_cycle(SpectCycleArgs A)
                     sc_st(o_ + (long)zz * A.ors + n, {1.0 * acc[q][h], 1.0 * acc[q][2 + h]});
             }
         }
+        SC_STAMP(5 + j);
     }
 }
 
 }  // namespace fb
 
 using namespace fb;
+
+#ifdef SC_TRACE
+extern "C" int fb_debug_sc_trace(unsigned long long *host_out, int n)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(sc_trace_buf), (size_t)n * 8);
+}
+#endif
 
 extern "C" int fb_spect_cycle_supported(int Nm, int Nr)
 {
