@@ -632,10 +632,18 @@ def pmc_traffic(entry, tag=''):
     f, w = pick(fetch[-1]), pick(write[-1])
     if f is None or w is None:
         return {}
-    return {'traffic': (2.0 * float(f['avg_value']) + float(w['avg_value'])) * 1024.0,
-            'traffic_source': '%s + %s (2 x FETCH_SIZE + WRITE_SIZE, KiB -> B, per launch of %s)'
-                              % (os.path.basename(fetch[-1]), os.path.basename(write[-1]),
-                                 f['kernel'])}
+    out = {'traffic': (2.0 * float(f['avg_value']) + float(w['avg_value'])) * 1024.0,
+           'traffic_source': '%s + %s (2 x FETCH_SIZE + WRITE_SIZE, KiB -> B, per launch of %s)'
+                             % (os.path.basename(fetch[-1]), os.path.basename(write[-1]),
+                                f['kernel'])}
+    # the box the counter passes ran on (tools/profile_round.sh writes it next to the CSVs): a static
+    # figure of another run, usually of another box of the pool than this line's
+    box = fetch[-1].replace('_pmc_fetch_size.csv', '_pmc_box.json')
+    try:
+        out['traffic_box'] = json.load(open(box))
+    except (OSError, ValueError):
+        out['traffic_box'] = None
+    return out
 
 
 def available_cores():

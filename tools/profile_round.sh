@@ -19,6 +19,14 @@ for d in $PASSES; do
   rocprofv3 $OPT -d /root/repo/gpurun_out/$TAG/$d -o r -- $CMD > /root/repo/gpurun_out/$TAG/$d.log 2>&1
 done
 cd /root/repo
+# which box the counters come from (bench.py prints it next to roofline.traffic: the passes are runs of
+# their own, usually on another box of the pool than the bench line that quotes them)
+python - > gpurun_out/${TAG}_pmc_box.json <<'PY'
+import json, sys
+sys.path.insert(0, '/root/repo')
+import torch, bench
+print(json.dumps(bench.device_identity(torch)))
+PY
 for d in $PASSES; do
   db=$(find gpurun_out/$TAG/$d -name '*.db' | head -1)
   mode=pmc; [ $d = stats ] && mode=stats
