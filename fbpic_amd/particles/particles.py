@@ -551,27 +551,30 @@ class Particles(object):
             return None
         return n_move * (g0.Nr + 1)
 
-    def _cycle_poll(self):
-        """Take in the counters of the last measured pass.  The read-back was issued right behind that
-        pass; its event is WAITED for here (one iteration later: the host runs at most that far
-        ahead of the device) - polling it with query() made the sequence of one- and two-pass
-        iterations, and with it the summation order of J and rho, depend on host timing."""
+    def _cycle_poll(self, lag=1):
+        """Take in the counters of earlier passes, in order, leaving the `lag` most recent read-backs
+        in flight.  A read-back is issued right behind its pass and its event is WAITED for here, at a
+        fixed distance (Particles.cycle polls with lag 1 in front of a pass: the decision of iteration k
+        rests on the passes up to k - 2, and the host can still run two iterations ahead of the device)
+        - polling with query() made the sequence of one- and two-pass iterations, and with it the
+        summation order of J and rho, depend on host timing."""
         st = self._cycle_stats
-        if st is not None and st[2] is not None:
-            ev, ntot, r = st[2]
+        while st is not None and len(st[2]) > lag:
+            ev, ntot, r, buf, gen = st[2].pop(0)
             ev.synchronize()
-            strays, bad = int(st[1][:512].sum()), int(st[1][512:].sum())
-            self.cycle_stray_fraction = float(strays - st[3][0]) / max(ntot, 1)
-            self.cycle_bad_fraction = float(bad - st[3][1]) / max((ntot + 63) // 64, 1)
-            self.cycle_last_stray_fraction = self.cycle_stray_fraction
+            strays, bad = int(buf[:512].sum()), int(buf[512:].sum())
+            f_stray = float(strays - st[3][0]) / max(ntot, 1)
+            f_bad = float(bad - st[3][1]) / max((ntot + 63) // 64, 1)
             st[3] = (strays, bad)
-            st[2] = None
-            if r == 1 and self.cycle_bad_fraction > self.cycle_bad_limit:
+            self.cycle_last_stray_fraction = f_stray
+            if gen == self.cycle_sorts:
+                # (a pass of the order before the latest sort says nothing about the present one)
+                self.cycle_stray_fraction, self.cycle_bad_fraction = f_stray, f_bad
+            if r == 1 and f_bad > self.cycle_bad_limit:
                 self._cycle_suspended = self.cycle_suspend_iterations
 
     def _after_home_sort(self):
         """Book-keeping of a sort that has recorded the home cells in `cell_idx`."""
-        self._cycle_poll()
         self._cycle_since_sort = 0
         self.cycle_stray_fraction = None
         self.cycle_bad_fraction = None
@@ -630,10 +633,10 @@ class Particles(object):
             self._after_home_sort()
         t = _capi.torch()
         if self._cycle_stats is None or self._cycle_stats[0].device != self.x.device:
-            # device counters, pinned host copy, (event, Ntot, passes since the sort) of a pending
-            # read, totals (strays, bad chunks) last read
+            # device counters, ring of pinned host copies, pending reads (event, Ntot, passes since the
+            # sort, host copy) oldest first, totals (strays, bad chunks) last read, passes measured
             self._cycle_stats = [t.zeros(1024, dtype=t.int64, device=self.x.device),
-                                 t.zeros(1024, dtype=t.int64).pin_memory(), None, (0, 0)]
+                                 [t.zeros(1024, dtype=t.int64).pin_memory() for _ in range(3)], [], (0, 0), 0]
         views = []
         for m in range(Nm):
             views += [grid[m].Er, grid[m].Et, grid[m].Ez, grid[m].Br, grid[m].Bt, grid[m].Bz]
@@ -657,10 +660,12 @@ class Particles(object):
             p(stats[0]) if measure else None, self._home_shift(g0), st)
         _capi.check(rc, 'fb_gather_push_deposit_J_rho')
         if measure:
-            stats[1].copy_(stats[0], non_blocking=True)
+            buf = stats[1][stats[4] % 3]           # (at most two read-backs are in flight)
+            stats[4] += 1
+            buf.copy_(stats[0], non_blocking=True)
             ev = t.cuda.Event()
             ev.record()
-            stats[2] = (ev, self.Ntot, self._cycle_since_sort + 1)
+            stats[2].append((ev, self.Ntot, self._cycle_since_sort + 1, buf, self.cycle_sorts))
         self._cycle_since_sort += 1
         self.cycle_passes += 1
         self._prerank = None

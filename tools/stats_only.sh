@@ -11,7 +11,7 @@ db = glob.glob('gpurun_out/v5/stats/**/*.db', recursive=True)[0]
 cur = sqlite3.connect(db).cursor()
 rows = cur.execute('select name, start, end from kernels order by start').fetchall()
 # steady-state window: last 6 steps = find k_gather launches
-g = [i for i, r in enumerate(rows) if 'k_gather' in r[0]]
+g = [i for i, r in enumerate(rows) if 'k_gather' in r[0] or 'k_cycle_linear' in r[0]]   # one per step
 i0, i1 = g[-7], g[-1]
 busy = sum(r[2] - r[1] for r in rows[i0:i1])
 span = rows[i1][1] - rows[i0][1]
