@@ -629,6 +629,14 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
 
 template <int NM, bool WIDE, bool RANK>
 __global__ __launch_bounds__(256) void k_cycle_linear(CycleArgs A) { cycle_linear_body<NM, WIDE, RANK>(A); }
+// The ranking form has no deposition panel (4.7 KB of LDS per wave) and needs 129-136 VGPRs: asked to fit
+// 128, the compiler finds them without a spill (Nm = 2: 126) and a fourth wave per SIMD fits.
+#ifndef FB_CYCLE_RANK_WAVES
+#define FB_CYCLE_RANK_WAVES 4
+#endif
+template <int NM, bool WIDE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FB_CYCLE_RANK_WAVES, FB_CYCLE_RANK_WAVES)))
+void k_cycle_rank(CycleArgs A) { cycle_linear_body<NM, WIDE, true>(A); }
 
 template <int NM, bool WIDE, bool RANK = false>
 static int launch_cycle_linear(const CycleArgs &A0, hipStream_t s)
@@ -651,8 +659,12 @@ static int launch_cycle_linear(const CycleArgs &A0, hipStream_t s)
     A.chunks_per_wave = cpw;
     const long total_waves = (nchunks + cpw - 1) / cpw;
     const long nblocks = xcd_grid((total_waves + nwaves - 1) / nwaves);
-    hipLaunchKernelGGL((k_cycle_linear<NM, WIDE, RANK>), dim3((unsigned)nblocks), dim3(64 * nwaves),
-                       wave_bytes * nwaves, s, A);
+    if constexpr (RANK)
+        hipLaunchKernelGGL((k_cycle_rank<NM, WIDE>), dim3((unsigned)nblocks), dim3(64 * nwaves),
+                           wave_bytes * nwaves, s, A);
+    else
+        hipLaunchKernelGGL((k_cycle_linear<NM, WIDE, false>), dim3((unsigned)nblocks), dim3(64 * nwaves),
+                           wave_bytes * nwaves, s, A);
     return check(hipGetLastError(), RANK ? "fb_gather_push_rank_next_home" : "fb_gather_push_deposit_J_rho");
 }
 
