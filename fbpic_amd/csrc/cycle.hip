@@ -155,6 +155,12 @@ static_assert(__builtin_offsetof(CycleArgs, y) == __builtin_offsetof(CycleArgs, 
               "pointer groups of karg_ptrs");
 #ifdef FB_ISA_MARKS
 #define FB_MARK(x) asm volatile("; MARK " x)
+#elif defined(FB_CYCLE_TRACE)
+// timing experiment (tools/cycle_trace.py): shader-clock time a wave spends between the marks of the chunk
+// loop, summed per mark over all waves of the launch
+__device__ unsigned long long cycle_trace_buf[16];
+#define FB_MARK(x) do { const unsigned long long t_ = __builtin_readcyclecounter(); \
+                        tr_acc[tr_k] += t_ - tr_t; tr_t = t_; tr_k = (tr_k + 1) % 9; } while (0)
 #else
 #define FB_MARK(x)
 #endif
@@ -332,7 +338,9 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
         // segment of this lane: its run, or - a stray - one of its own behind the runs
         f.myseg = g_home ? __popcll(g_runs & le) - 1 : ngruns + __popcll(straym & lt);
         f.rem_r = g_runs; f.rem_s = straym;
+#ifndef FB_KNOCK_NODES            // (timing experiment: no node loads for the next chunk)
         request(f, min(NSEG, f.nseg));
+#endif
     };
 
     const long chunk0 = (xcd_block_id() * nwaves + wave) * A.chunks_per_wave;
@@ -372,6 +380,10 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
     if (A.chunks_per_wave > 1) load_pos(base + 64, xn, yn, zn, hn);
     fb_wait_vm();
     unsigned int nstray_J = 0, nbad = 0;
+#ifdef FB_CYCLE_TRACE
+    unsigned long long tr_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tr_t = __builtin_readcyclecounter();
+    int tr_k = 0;          // slot k: time from mark k - 1 (or the loop end) to mark k
+#endif
     for (int ch = 0; ch < A.chunks_per_wave; ch++) {
         const long i = min(base + lane, n - 1);
         const bool act = base + lane < n;
@@ -557,9 +569,13 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
             return min((int)ceil(A.invdr * (ra - A.rmin) - 0.5), Nr);
         };
         const int irJ = ruyten_index(xh, yh), irR = ruyten_index(x1, y1);
+#ifdef FB_KNOCK_BETA              // (timing experiment: no Ruyten loads)
+        const double bJ0 = 0.01 * irJ, bJh = 0.02 * irJ, bR0 = 0.01 * irR, bRh = 0.02 * irR;
+#else
         const KPtrs<2> bq = karg_ptrs2(KOFF(beta0));           // beta0, betah
         const double bJ0 = ((const double *)bq.p[0])[irJ], bJh = ((const double *)bq.p[1])[irJ];
         const double bR0 = ((const double *)bq.p[0])[irR], bRh = ((const double *)bq.p[1])[irR];
+#endif
         wait_and_store();
         if constexpr (!P::MERGED) {
             ej.stage_with(true, xh, yh, zh, wj, pux, puy, puz, pig, A.c_light, geom, bJ0, bJh, dkz, dkr, dnb);
@@ -620,6 +636,12 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
     } else {
         ed.flush(false);
     }
+#ifdef FB_CYCLE_TRACE
+    if constexpr (!RANK) {
+        if (lane == 0)
+            for (int k = 0; k < 9; k++) atomicAdd(&cycle_trace_buf[k], tr_acc[k]);
+    }
+#endif
     if (A.stats && lane == 0) {
         const int slot = (blockIdx.x * nwaves + wave) & 511;
         atomicAdd(A.stats + slot, (unsigned long long)nstray_J);
@@ -629,14 +651,10 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
 
 template <int NM, bool WIDE, bool RANK>
 __global__ __launch_bounds__(256) void k_cycle_linear(CycleArgs A) { cycle_linear_body<NM, WIDE, RANK>(A); }
-// The ranking form has no deposition panel (4.7 KB of LDS per wave) and needs 129-136 VGPRs: asked to fit
-// 128, the compiler finds them without a spill (Nm = 2: 126) and a fourth wave per SIMD fits.
-#ifndef FB_CYCLE_RANK_WAVES
-#define FB_CYCLE_RANK_WAVES 4
-#endif
-template <int NM, bool WIDE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FB_CYCLE_RANK_WAVES, FB_CYCLE_RANK_WAVES)))
-void k_cycle_rank(CycleArgs A) { cycle_linear_body<NM, WIDE, true>(A); }
+// (The ranking form has no deposition panel - 4.7 KB of LDS per wave - and needs 129-136 VGPRs; asked to
+// fit 128 the compiler finds them without a spill at Nm = 2, and a fourth wave per SIMD fits: measured
+// SLOWER, 0.165 against 0.156 ms per launch at C2 - more waves in flight span more of the grid than the
+// XCD's L2 keeps, as with longer per-wave ranges.  Not used.)
 
 template <int NM, bool WIDE, bool RANK = false>
 static int launch_cycle_linear(const CycleArgs &A0, hipStream_t s)
@@ -659,12 +677,8 @@ static int launch_cycle_linear(const CycleArgs &A0, hipStream_t s)
     A.chunks_per_wave = cpw;
     const long total_waves = (nchunks + cpw - 1) / cpw;
     const long nblocks = xcd_grid((total_waves + nwaves - 1) / nwaves);
-    if constexpr (RANK)
-        hipLaunchKernelGGL((k_cycle_rank<NM, WIDE>), dim3((unsigned)nblocks), dim3(64 * nwaves),
-                           wave_bytes * nwaves, s, A);
-    else
-        hipLaunchKernelGGL((k_cycle_linear<NM, WIDE, false>), dim3((unsigned)nblocks), dim3(64 * nwaves),
-                           wave_bytes * nwaves, s, A);
+    hipLaunchKernelGGL((k_cycle_linear<NM, WIDE, RANK>), dim3((unsigned)nblocks), dim3(64 * nwaves),
+                       wave_bytes * nwaves, s, A);
     return check(hipGetLastError(), RANK ? "fb_gather_push_rank_next_home" : "fb_gather_push_deposit_J_rho");
 }
 
@@ -678,6 +692,15 @@ static int launch_cycle(const CycleArgs &A, bool wide, bool rank, hipStream_t s)
 }  // namespace fb
 
 using namespace fb;
+
+#ifdef FB_CYCLE_TRACE
+extern "C" int fb_debug_cycle_trace(unsigned long long *host_out, int reset)
+{
+    int r = (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(cycle_trace_buf), 16 * 8);
+    if (reset) { unsigned long long z[16] = {0}; r |= (int)hipMemcpyToSymbol(HIP_SYMBOL(cycle_trace_buf), z, 16 * 8); }
+    return r;
+}
+#endif
 
 extern "C" int fb_gather_push_deposit_supported(int shape, int Nm)
 {
