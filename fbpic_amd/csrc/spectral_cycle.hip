@@ -14,8 +14,13 @@
 // (kz, kr), so after the forward products every lane holds J and rho_next of its own cells in its
 // accumulators, updates them with E, B, rho_prev read once from the spectral slab, writes the
 // slab, and passes the new E, B to the inverse products through LDS (the K dimension of the
-// inverse transform runs over kr: all four waves need all of it).  1024 x 128, Nm = 2: 256
+// inverse transform runs over kr: all eight waves need all of it).  1024 x 128, Nm = 2: 256
 // workgroups = one per CU, two waves per SIMD, 320 v_mfma_f64_16x16x4 per wave back to back.
+// Round 5: the fields that share a Hankel matrix (Jz | rho; E and B of one component) are multiplied
+// against one stream of its fragments, and the memory operations are ordered for the in-order
+// vmcnt counter (see k_spect_cycle): 56 -> 50 us inside a step.  Nr <= 128 on purpose: every
+// workgroup streams every matrix once, which only pays where a transform is one under-filled
+// generation of workgroups.
 //
 // MFMA fragments (cdna_hip_programming.md section 3): A lane l -> A[i = l & 15][k = l >> 4],
 // B lane l -> B[k = l >> 4][j = l & 15], D reg r of lane l -> D[i = (l >> 4) + 4 r][j = l & 15].
@@ -24,7 +29,7 @@
 // lane, no shuffle before the cell-local update.
 #include "fb_common.h"
 #ifndef SC_KNOCK
-#define SC_KNOCK 0                 // timing experiments (tools/sc_time.py): 1 .. 4 drop one part each
+#define SC_KNOCK 0                 // timing experiments (tools/sc_time.py): 1 .. 3 drop one part each
 #endif
 
 namespace fb {
