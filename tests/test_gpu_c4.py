@@ -116,9 +116,19 @@ def _worker(rank, world, port, outdir, q, correct=False):
         import faulthandler
         tlog = os.path.join(ROOT, 'gpurun_out', 'c4_timing')
         os.makedirs(tlog, exist_ok=True)
-        stack = open(os.path.join(tlog, 'w%d_r%d_stack.log' % (world, rank)), 'w')
+        # (appended, not truncated: the retry that follows a lost rank used to overwrite what the
+        # lost rank had dumped - round 5 caught a SIGABRT of one rank and found its dump empty)
+        stack = open(os.path.join(tlog, 'w%d_r%d_stack.log' % (world, rank)), 'a')
+        stack.write('---- pid %d, correct=%s\n' % (os.getpid(), correct))
+        stack.flush()
         faulthandler.enable(file=stack)          # and on a fatal signal (SIGSEGV, SIGABRT, SIGBUS)
         faulthandler.dump_traceback_later(75, repeat=False, file=stack)
+        # what the runtime libraries print before they abort (a GPU memory access fault of the HSA
+        # runtime, an uncaught C++ exception of the transport) goes to the rank's own file
+        err = open(os.path.join(tlog, 'w%d_r%d_stderr.log' % (world, rank)), 'a')
+        err.write('---- pid %d, correct=%s\n' % (os.getpid(), correct))
+        err.flush()
+        os.dup2(err.fileno(), 2)
         _run(rank, world, port, outdir, correct)
         faulthandler.cancel_dump_traceback_later()
         q.put((rank, 'ok'))
