@@ -48,7 +48,7 @@ _SIGNATURES = {
     'fb_push_x_sort_deposit_rho': (I, [L, I, P, P, P, P, P, P, P, D, D, D, D, D, D, D, I, D, D, I, I, _PP,
                                        _PP, P, P, P, P, Z, I, I, I, D, _PP, L, L, P, P, P]),
     'fb_push_x_sort_deposit_J_rho': (I, [L, I, P, P, P, P, P, P, P, D, D, D, D, D, D, D, I, D, D, I, I, _PP,
-                                         _PP, P, P, P, P, Z, I, I, I, D, D, _PP, L, L, _PP, L, L, P, P, P]),
+                                         _PP, P, P, P, P, Z, I, I, I, D, D, _PP, L, L, _PP, L, L, P, P, I, P]),
     'fb_gather_push_deposit_supported': (I, [I, I]),
     'fb_gather_push_deposit_J_rho': (I, [I, I, L, P, P, P, P, P, P, P, P, P, D, D, D, I, D, D, I, _PP, L,
                                          P, P, P, P, P, P, D, D, D, D, D, D, D, _PP, L, L, _PP, L, L,
@@ -109,7 +109,7 @@ _SIGNATURES = {
 
 EXPORTS = tuple(_SIGNATURES)
 # FB_ABI_VERSION of include/fbpic_amd.h the signatures above were written against
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class BackendError(RuntimeError):

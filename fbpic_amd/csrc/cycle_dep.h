@@ -149,7 +149,13 @@ struct CycleDep {
                 else if (v == 1) { ri = a & 1; comp = (a >> 1) % 3; m = 1 + (a >> 1) / 3; }
                 else if (v == 3) { ri = a & 1; m = 1 + (a >> 1); }
             }
-            double *fp = e ? (double *)GR.g[m] : (double *)GJ.g[comp + 3 * m];
+            // (selected with static indices: a lane-dependent index into the by-value pointer tables
+            // would send them to scratch memory)
+            double *fp = nullptr;
+#pragma unroll
+            for (int i = 0; i < 3 * NM; i++) fp = (!e && i == comp + 3 * m) ? (double *)GJ.g[i] : fp;
+#pragma unroll
+            for (int i = 0; i < NM; i++) fp = (e && i == m) ? (double *)GR.g[i] : fp;
             fp += ri;
             f_off[t] = (unsigned)((char *)fp - gbase) + (unsigned)(jzD * rsB);
             valid |= ok ? (1u << t) : 0u;
@@ -367,6 +373,35 @@ struct CycleDep {
                 product(p, e);
             }
             p = e;
+        }
+    }
+
+    // ---- a chunk in which the stencils of the two engines differ for MANY particles (a laser wake:
+    // fast particles change cell within the half push between the two depositions): two traversals,
+    // each engine on the runs of ITS OWN keys, the other engine's mode-0 amplitudes zero meanwhile -
+    // every particle takes part in a run, nothing is scattered one by one.  (The flush of a run writes
+    // only the non-zero sums, i.e. those of the engine that is being traversed.)
+    __device__ __forceinline__ void reduce_split(int cnt, bool act, int jkz, int jkr, int jnb,
+                                                 int rkz, int rkr, int rnb)
+    {
+        double *Pd = (double *)P;
+        const unsigned long long actm = __ballot(act);
+        double a0[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) { a0[a] = Pd[(L::ROW_AJ + a) * PAD + lane]; Pd[(L::ROW_AJ + a) * PAD + lane] = 0.; }
+        wave_lds_release();
+        {
+            const int pz = __shfl_up(rkz, 1), pr = __shfl_up(rkr, 1);
+            reduce(cnt, __ballot(act && (lane == 0 || rkz != pz || rkr != pr)), actm, rkz, rkr, rnb);
+        }
+        wave_lds_acquire();
+#pragma unroll
+        for (int a = 0; a < 3; a++) Pd[(L::ROW_AJ + a) * PAD + lane] = a0[a];
+        Pd[L::ROW_AR * PAD + lane] = 0.;
+        wave_lds_release();
+        {
+            const int pz = __shfl_up(jkz, 1), pr = __shfl_up(jkr, 1);
+            reduce(cnt, __ballot(act && (lane == 0 || jkz != pz || jkr != pr)), actm, jkz, jkr, jnb);
         }
     }
 

@@ -29,6 +29,7 @@
 // 1e-13 * max|F| (tests/test_cpu_gpu_deposition.py:96).
 #include "fb_common.h"
 #include "dep_engine.h"
+#include "cycle_dep.h"
 
 namespace fb {
 
@@ -261,6 +262,104 @@ __global__ __launch_bounds__(256) void k_perm_deposit_J_rho(long n, double q, do
     }
     ej.flush(false);
     er.flush(false);
+}
+
+// Round 5: the same pass with the merged engine of the one-pass cycle (cycle_dep.h) - J and rho staged
+// together, ONE traversal of the runs.  The stream is in destination order, i.e. sorted by the cell of
+// the pushed position: the runs are those of the rho keys (exact), and a particle whose position
+// BEFORE the push has another stencil (it crosses a cell boundary within this half push) is a stray of
+// the J engine only, written out directly.  Linear shape, both depositions on the same grid geometry,
+// targets addressed from one base with the same strides (the in-step records); anything else takes
+// k_perm_deposit_J_rho.  16 ppc (C3 / C4) halves the run length of C2 and doubles the flushes per
+// particle: that is where one traversal instead of two pays most.
+#ifndef FB_PERM_SPLIT_AT
+#define FB_PERM_SPLIT_AT 6         // strays of the J engine per 64 particles from which a chunk is traversed twice
+#endif
+template <int NM>
+__global__ __launch_bounds__(256) void k_perm_deposit_J_rho_merged(long n, double q, double c_light,
+        DepGeom g, DepGrids GJ, DepGrids GR, long rs, cplx *gbase,
+        const double *__restrict__ beta0, const double *__restrict__ betah,
+        int chunks_per_wave, PermArgs PM)
+{
+    using ED = CycleDep<NM>;
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    ED ed;
+    ed.init(lds + (size_t)wave * ED::L::WAVE_DOUBLES, lane, GJ, rs, GR, rs, g.Nz, g.Nr, gbase);
+
+    const long chunk0 = (xcd_block_id() * nwaves + wave) * chunks_per_wave;
+    double pn[8];
+    // (lanes beyond the last particle stage a harmless particle of weight 0)
+    pn[0] = 1. / g.invdr; pn[1] = 0.; pn[2] = g.zmin + 1. / g.invdz; pn[3] = 0.; pn[4] = 0.; pn[5] = 0.; pn[6] = 0.; pn[7] = 1.;
+    int idx_n = 0, idx_c = 0, idx_nn = 0;
+    auto prefetch = [&](long ip) {
+        if (ip < n) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) pn[k] = PM.src.p[k][idx_n];
+        }
+    };
+    if (chunk0 * 64 + lane < n) idx_n = PM.sidx[chunk0 * 64 + lane];
+    prefetch(chunk0 * 64 + lane);
+    idx_c = idx_n;
+    if (chunks_per_wave > 1 && (chunk0 + 1) * 64 + lane < n) idx_nn = PM.sidx[(chunk0 + 1) * 64 + lane];
+    for (int ch = 0; ch < chunks_per_wave; ch++) {
+        const long base = (chunk0 + ch) * 64;
+        if (base >= n) break;
+        const long ip = base + lane;
+        const bool act = ip < n;
+        const int cnt = (int)min((long)64, n - base);
+        double pc[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) pc[k] = pn[k];
+        if (ch > 0) idx_c = idx_n;
+        idx_n = idx_nn;
+        if (ch + 1 < chunks_per_wave) prefetch(ip + 64);
+        if (ch + 2 < chunks_per_wave && ip + 128 < n) idx_nn = PM.sidx[ip + 128];
+        const double wj = act ? q * pc[6] : 0.;
+        // pending push_x (expression of k_push_x), attributes written at the sorted slot
+        const double gi = pc[7];
+        const double xj = pc[0] + PM.chdt * gi * PM.px * pc[3];
+        const double yj = pc[1] + PM.chdt * gi * PM.py * pc[4];
+        const double zj = pc[2] + PM.chdt * gi * PM.pz * pc[5];
+        // Ruyten coefficients of both positions (DepEngine::ruyten_index)
+        const double r0 = sqrt(pc[0] * pc[0] + pc[1] * pc[1]), r1 = sqrt(xj * xj + yj * yj);
+        const int irJ = min((int)ceil(g.invdr * (r0 - g.rmin) - 0.5), g.Nr);
+        const int irR = min((int)ceil(g.invdr * (r1 - g.rmin) - 0.5), g.Nr);
+        const double bJ0 = beta0[irJ], bJh = betah[irJ], bR0 = beta0[irR], bRh = betah[irR];
+        if (act) {
+            PM.dst.p[0][ip] = xj; PM.dst.p[1][ip] = yj; PM.dst.p[2][ip] = zj;
+            PM.dst.p[3][ip] = pc[3]; PM.dst.p[4][ip] = pc[4]; PM.dst.p[5][ip] = pc[5];
+            PM.dst.p[6][ip] = pc[6]; PM.dst.p[7][ip] = gi;
+            // (static indices: a run-time index into the by-value pointer tables sends them to scratch)
+#pragma unroll
+            for (int k = 8; k < 16; k++)
+                if (k < PM.nattr) PM.dst.p[k][ip] = PM.src.p[k][idx_c];
+            if (PM.cell_sorted) PM.cell_sorted[ip] = PM.cell[idx_c];
+        }
+        int jkz, jkr, jnb, rkz, rkr, rnb;
+        ed.template stage<0>(pc[0], pc[1], pc[2], wj, pc[3], pc[4], pc[5], gi, c_light, g, bJ0, bJh, jkz, jkr, jnb);
+        ed.template stage<1>(xj, yj, zj, wj, 0., 0., 0., 0., 0., g, bR0, bRh, rkz, rkr, rnb);
+        const int pkz = __shfl_up(rkz, 1), pkr = __shfl_up(rkr, 1);
+        const unsigned long long runstarts = __ballot(act && (lane == 0 || rkz != pkz || rkr != pkr));
+        const bool homeJ = act && jkz == rkz && jkr == rkr && jnb == rnb;
+        const unsigned long long smJ = __ballot(act && !homeJ);
+        wave_lds_release();
+        if (__popcll(smJ) > FB_PERM_SPLIT_AT) {
+            // (C3: a quarter of the window's electrons are in the wake; scattering each of them cost
+            // 0.95 ms per launch where the two engines of k_perm_deposit_J_rho take 0.70)
+            ed.reduce_split(cnt, act, jkz, jkr, jnb, rkz, rkr, rnb);
+        } else {
+            if (smJ) {
+                ed.scatter_strays(smJ, 0ull, jkz, jkr, jnb, rkz, rkr, rnb);
+                ed.zero_amplitudes(!homeJ, false);
+                wave_lds_release();
+            }
+            ed.reduce(cnt, runstarts, __ballot(act), rkz, rkr, rnb);
+        }
+        wave_lds_acquire();
+    }
+    ed.flush(false);
 }
 
 static int dep_waves_per_workgroup(size_t wave_bytes) { return lds_waves_per_workgroup(wave_bytes); }
@@ -502,6 +601,25 @@ static int launch_perm_J_rho(long n, double q, double c, const DepGeom &gJ, cons
     return check(hipGetLastError(), "fb_push_x_sort_deposit_J_rho");
 }
 
+template <int NM>
+static int launch_perm_J_rho_merged(long n, double q, double c, const DepGeom &g, const DepGrids &GJ,
+                                    const DepGrids &GR, long rs, cplx *gbase, const double *b0,
+                                    const double *bh, const PermArgs &PM, hipStream_t s)
+{
+    const size_t wave_bytes = 8 * (size_t)CycleDep<NM>::L::WAVE_DOUBLES;
+    const int nwaves = 1;          // (as launch_perm_J_rho)
+    const long nchunks = (n + 63) / 64;
+    const long target_waves = 256L * 64;
+    int cpw = (int)((nchunks + target_waves - 1) / target_waves);
+    if (cpw < 1) cpw = 1;
+    if (cpw > 64) cpw = 64;
+    const long total_waves = (nchunks + cpw - 1) / cpw;
+    const long nblocks = xcd_grid((total_waves + nwaves - 1) / nwaves);
+    hipLaunchKernelGGL((k_perm_deposit_J_rho_merged<NM>), dim3((unsigned)nblocks), dim3(64 * nwaves),
+                       wave_bytes * nwaves, s, n, q, c, g, GJ, GR, rs, gbase, b0, bh, cpw, PM);
+    return check(hipGetLastError(), "fb_push_x_sort_deposit_J_rho");
+}
+
 extern "C" int fb_push_x_sort_deposit_J_rho(long n, int ncell, const double *x, const double *y,
         const double *z, const double *ux, const double *uy, const double *uz,
         const double *inv_gamma, double c, double dt, double x_push, double y_push, double z_push,
@@ -511,7 +629,7 @@ extern "C" int fb_push_x_sort_deposit_J_rho(long n, int ncell, const double *x, 
         void *workspace, size_t workspace_bytes, int preranked,
         int shape, int Nm, double q, double zmin_J, void *const *J, long J_row_stride,
         long J_col_stride, void *const *rho, long row_stride, long col_stride,
-        const double *ruyten_m0, const double *ruyten_mh, void *stream)
+        const double *ruyten_m0, const double *ruyten_mh, int engine, void *stream)
 {
     const char *who = "fb_push_x_sort_deposit_J_rho";
     hipStream_t s = (hipStream_t)stream;
@@ -541,6 +659,26 @@ extern "C" int fb_push_x_sort_deposit_J_rho(long n, int ncell, const double *x, 
         GR.g[i] = i < Nm ? (cplx *)rho[i] : nullptr;
     }
     const DepGeom gJ = {invdz, zmin_J, Nz, invdr, rmin, Nr}, gR = {invdz, zmin, Nz, invdr, rmin, Nr};
+#ifndef FB_PERM_TWO_ENGINES
+    // engine: 0 / 2 = the merged engine where it applies, 1 = the two engines one after the other (the
+    // faster form where many particles change cell within the push - a laser wake: C3 0.70 against
+    // 0.77-0.82 ms per launch, while a thermal plasma at 32 ppc takes 0.208 against 0.231 merged)
+    if (engine != 1 && shape == FB_SHAPE_LINEAR && zmin_J == zmin && J_row_stride == row_stride && GJ.cs == GR.cs) {
+        // one base for both targets (views of one record array, fields of one slab): merged engine
+        cplx *bj = dep_grids_base(GJ, 3 * Nm, J_row_stride, Nz), *br = dep_grids_base(GR, Nm, row_stride, Nz);
+        if (bj && br) {
+            const uintptr_t lo = (uintptr_t)bj < (uintptr_t)br ? (uintptr_t)bj : (uintptr_t)br;
+            uintptr_t hi = 0;
+            for (int i = 0; i < 3 * Nm; i++) if ((uintptr_t)GJ.g[i] > hi) hi = (uintptr_t)GJ.g[i];
+            for (int i = 0; i < Nm; i++) if ((uintptr_t)GR.g[i] > hi) hi = (uintptr_t)GR.g[i];
+            if ((double)(hi - lo) + 16. * (double)row_stride * (double)(Nz + 1) < 4294967296.) {
+#define LPM(NM_) launch_perm_J_rho_merged<NM_>(n, q, c, gR, GJ, GR, row_stride, (cplx *)lo, ruyten_m0, ruyten_mh, PM, s)
+                return Nm == 1 ? LPM(1) : Nm == 2 ? LPM(2) : Nm == 3 ? LPM(3) : LPM(4);
+#undef LPM
+            }
+        }
+    }
+#endif
 #define LPJR(SH, NM_) launch_perm_J_rho<SH, NM_>(n, q, c, gJ, gR, GJ, J_row_stride, GR, row_stride, \
                                                  ruyten_m0, ruyten_mh, PM, s)
     if (shape == FB_SHAPE_LINEAR)

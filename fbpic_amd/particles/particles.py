@@ -793,7 +793,11 @@ class Particles(object):
                 p(self.prefix_sum), p(self._sort_ws), self._sort_ws.shape[0], preranked,
                 _SHAPE[self.particle_shape], Nm, self.q, g0.zmin, _capi.ptr_array(jviews),
                 jviews[0].stride(0), jviews[0].stride(1), _capi.ptr_array(views),
-                views[0].stride(0), views[0].stride(1), p(ruy0), p(ruyh), st)
+                views[0].stride(0), views[0].stride(1), p(ruy0), p(ruyh),
+                # (a plasma that has just turned the one-pass form off - whole chunks of particles that
+                # change cell every step - also wants the two depositions of this pass one after the other)
+                1 if (self._cycle_suspended > 0 or (self.cycle_bad_fraction or 0.) > self.cycle_bad_limit) else 0,
+                st)
             _capi.check(rc, 'fb_push_x_sort_deposit_J_rho')
         else:
             rc = lib.fb_push_x_sort_deposit_rho(

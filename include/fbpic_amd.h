@@ -36,7 +36,7 @@ extern "C" {
 /* ---- runtime ---------------------------------------------------------------- */
 /* revision of this header; fb_abi_version() returns the one the library was built from (the
  * Python binding refuses a library of another revision) */
-#define FB_ABI_VERSION 5
+#define FB_ABI_VERSION 6
 int fb_abi_version(void);
 const char *fb_last_error(void);
 /* utils/cuda.py:261-299 (GPU selection) -> explicit device binding per process */
@@ -339,7 +339,11 @@ int fb_push_x_sort_deposit_rho(long n, int ncell, const double *x, const double 
  * it, stores all attributes at the sorted slot and deposits its charge from the pushed position:
  * the stand-alone J pass (64 B per particle read again) disappears and the arithmetic of both
  * depositions overlaps the memory stalls of the permutation.  zmin_J: grid position for the J
- * deposit (= zmin unless the grid moved in between).  Nm <= 4. */
+ * deposit (= zmin unless the grid moved in between).  Nm <= 4.
+ * engine: 0 = the library's choice - for the linear shape, both depositions on one grid geometry and
+ * targets with one base and the same strides, J and rho are staged together and reduced in ONE
+ * traversal of the runs (csrc/cycle_dep.h), else one after the other; 1 = always one after the
+ * other (faster where many particles change cell within the push: a laser wake); same results. */
 int fb_push_x_sort_deposit_J_rho(long n, int ncell, const double *x, const double *y,
                                  const double *z, const double *ux, const double *uy,
                                  const double *uz, const double *inv_gamma, double c, double dt,
@@ -351,7 +355,7 @@ int fb_push_x_sort_deposit_J_rho(long n, int ncell, const double *x, const doubl
                                  int shape, int Nm, double q, double zmin_J, void *const *J,
                                  long J_row_stride, long J_col_stride, void *const *rho,
                                  long row_stride, long col_stride, const double *ruyten_m0,
-                                 const double *ruyten_mh, void *stream);
+                                 const double *ruyten_mh, int engine, void *stream);
 
 /* The particle work of a whole PIC step in ONE pass (csrc/cycle.hip): identical result to
  *   fb_gather_push(shape, Nm, n, x .. inv_gamma, ..., dt, dt_x, wrap_zmin, wrap_zmax)   main.py:469-490

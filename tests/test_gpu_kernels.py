@@ -1076,9 +1076,11 @@ def test_push_sort_deposit_rho_fused(hip, oracle, shape, Nm, preranked, nattr, r
             assert rel_err(host(views[m]), red) < 1e-13, m
 
 
-@pytest.mark.parametrize('shape,Nm,records', [(1, 2, True), (1, 1, False), (3, 2, False), (3, 4, False),
-                                              (1, 3, True)])
-def test_push_sort_deposit_J_rho_fused(hip, oracle, shape, Nm, records):
+@pytest.mark.parametrize('shape,Nm,records,engine', [(1, 2, True, 0), (1, 1, False, 0), (3, 2, False, 0),
+                                                     (3, 4, False, 0), (1, 3, True, 0),
+                                                     # engine 1: the two depositions one after the other
+                                                     (1, 2, True, 1), (1, 4, False, 0)])
+def test_push_sort_deposit_J_rho_fused(hip, oracle, shape, Nm, records, engine):
     """fb_push_x_sort_deposit_J_rho == fb_deposit_J (positions before the push, its own zmin) then
     fb_push_x_sort_deposit_rho: same sorted particle arrays (bit-identical pushed positions), J
     and rho equal to the separate launches and to the oracle depositions (1e-13)."""
@@ -1128,7 +1130,7 @@ def test_push_sort_deposit_J_rho_fused(hip, oracle, shape, Nm, records):
         n, ncell, p(src[0]), p(src[1]), p(src[2]), p(src[3]), p(src[4]), p(src[5]), p(src[7]),
         c, dt, 1., 1., 1., *geom, 8, hip.ptr_array(src), hip.ptr_array(dst), None, p(si), p(pre),
         p(ws), nb, 0, shape, Nm, q, 0., hip.ptr_array(jv), jv[0].stride(0), jv[0].stride(1),
-        hip.ptr_array(rv), rv[0].stride(0), rv[0].stride(1), p(ruy0), p(ruyh), hip.stream()),
+        hip.ptr_array(rv), rv[0].stride(0), rv[0].stride(1), p(ruy0), p(ruyh), engine, hip.stream()),
         'push_x_sort_deposit_J_rho')
     sidx, prefix = host(si), host(pre)
     assert np.array_equal(np.sort(sidx), np.arange(n, dtype=np.int32))
