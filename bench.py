@@ -595,7 +595,7 @@ def roofline(kern, ceil=None, profiled_workload=True):
 _KERNEL_OF = {
     'fb_gather_push': ('k_gather<',), 'fb_gather': ('k_gather<',),
     'fb_gather_push_rank_next': ('k_gather',),
-    'fb_push_x_sort_deposit_J_rho': ('k_perm_deposit_J_rho<',),
+    'fb_push_x_sort_deposit_J_rho': ('k_perm_deposit_J_rho',),
     'fb_gather_push_deposit_J_rho': ('k_cycle_linear<',),
     'fb_deposit_J_rank_next': ('k_deposit<', ', 3, ', 'true, true>'),
     'fb_deposit_J': ('k_deposit<', ', 3, '), 'fb_deposit_rho': ('k_deposit<', ', 1, '),
