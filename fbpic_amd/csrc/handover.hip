@@ -68,12 +68,20 @@ __global__ __launch_bounds__(256) void k_handover_select_pack(long n, const doub
             }
         }
     }
-    // the last workgroup to finish writes the message headers
+    // the last workgroup to finish writes the message headers.  ALL waves of a workgroup must have
+    // added their particles before its thread 0 reports the workgroup as finished: without the
+    // barrier in front of that increment (rounds 3 and 4) the header could be written while the other
+    // three waves of the last workgroup - or of any other one - were still counting, i.e. up to a
+    // few waves' worth of particles too small.  The receiver then posted a remainder message 64
+    // particles shorter than the sender's (gloo: "op.preamble.length <= op.nbytes", abort of that rank:
+    // the rank loss of tests/test_gpu_c4.py, 1 run in ~20) - or, within the capacity, dropped them.
     __threadfence();
+    __syncthreads();
     __shared__ bool last;
     if (threadIdx.x == 0) last = (atomicAdd(counts + 7, 1ull) == (unsigned long long)gridDim.x - 1);
     __syncthreads();
     if (last && threadIdx.x == 0) {
+        __threadfence();
         const unsigned long long nl = atomicAdd(counts + 0, 0ull), nr = atomicAdd(counts + 1, 0ull);
         if (send_left) send_left[0] = (double)nl;
         if (send_right) send_right[0] = (double)nr;

@@ -55,6 +55,25 @@ def test_select_pack_full_scan(n):
         assert np.array_equal(rows, A[:, got_idx])               # packed values = the selected particles
 
 
+def test_select_pack_header_is_the_final_count_every_time():
+    """The message header is written by the last workgroup to finish - after EVERY wave of every
+    workgroup has added its particles.  (Rounds 3-4: thread 0 of a workgroup reported it finished
+    without waiting for its other waves; once in ~20 runs of the 8-slab C4 test a header was a few
+    waves' worth of particles short of the count the host read later, the receiver posted a
+    remainder message 64 particles shorter than the sender's, and the transport aborted that rank.)
+    Many launches with most particles leaving, headers against the counts and the expected sets."""
+    import torch
+    n = 1 << 20
+    A, arrs = _setup(n, 5)
+    zlo, zhi = 0.45, 0.55
+    nl, nr = int((A[2] < zlo).sum()), int((A[2] > zhi).sum())
+    cap = 1024                      # (tiny messages: the launch is the selection and the counting)
+    for rep in range(60):
+        sl, sr, idx, counts = _select(arrs, n, zlo, zhi, cap, cap, n)
+        assert counts[0] == nl and counts[1] == nr
+        assert float(sl[0]) == nl and float(sr[0]) == nr, rep
+
+
 def test_select_pack_overflow_and_open_end():
     """More leavers than the message holds: the header still carries the full count, the index
     list is complete and the first `cap` are packed (the caller sends the rest in a second
