@@ -144,8 +144,8 @@ class Particles(object):
         # iteration).  If already the FIRST pass after a sort reports that, the one-pass form does not
         # fit the plasma as it is now: the next `cycle_suspend_iterations` iterations are two-pass
         # (sorting) ones, then one pass probes again.
-        self.cycle_bad_limit = float(os.environ.get('FBPIC_AMD_BAD_CHUNK_LIMIT', '0.01'))
-        self.cycle_suspend_iterations = int(os.environ.get('FBPIC_AMD_SUSPEND', '16'))
+        self.cycle_bad_limit = 0.01
+        self.cycle_suspend_iterations = 16
         self._cycle_suspended = 0
         self.cycle_bad_fraction = None
         self._cycle_since_sort = 0
