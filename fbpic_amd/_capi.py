@@ -19,6 +19,7 @@ _PP = ctypes.POINTER(P)   # host array of device pointers
 _SIGNATURES = {
     'fb_abi_version': (I, []),
     'fb_last_error': (ctypes.c_char_p, []),
+    'fb_build_info': (ctypes.c_char_p, []),
     'fb_set_device': (I, [I]),
     'fb_sync': (I, [P]),
     'fb_comm_unique_id': (I, [P]),
@@ -109,7 +110,7 @@ _SIGNATURES = {
 
 EXPORTS = tuple(_SIGNATURES)
 # FB_ABI_VERSION of include/fbpic_amd.h the signatures above were written against
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class BackendError(RuntimeError):
@@ -225,7 +226,7 @@ class _TimedLib(object):
 
     def __getattr__(self, name):
         f = getattr(self._real, name)
-        if not name.startswith('fb_') or name in ('fb_last_error', 'fb_abi_version',
+        if not name.startswith('fb_') or name in ('fb_last_error', 'fb_build_info', 'fb_abi_version',
                                                   'fb_sort_workspace_bytes', 'fb_bin_sort_workspace_bytes', 'fb_handover_workspace_bytes', 'fb_fft_plan_create',
                                                   'fb_fft_plan_destroy', 'fb_sync', 'fb_set_device', 'fb_gather_push_deposit_supported', 'fb_spect_cycle_supported', 'fb_comm_unique_id', 'fb_comm_init', 'fb_comm_destroy', 'fb_zfft_supported', 'fb_fft_generic_supported', 'fb_fft_generic_from_records_supported'):
             return f

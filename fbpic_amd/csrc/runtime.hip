@@ -23,6 +23,10 @@ int check(hipError_t e, const char *where)
 
 extern "C" int fb_abi_version(void) { return FB_ABI_VERSION; }
 extern "C" const char *fb_last_error(void) { return fb::g_err; }
+#ifndef FB_BUILD_INFO
+#define FB_BUILD_INFO "unknown (built without the Makefile)"
+#endif
+extern "C" const char *fb_build_info(void) { return FB_BUILD_INFO; }
 extern "C" int fb_set_device(int device) { return fb::check(hipSetDevice(device), "fb_set_device"); }
 extern "C" int fb_sync(void *stream)
 {

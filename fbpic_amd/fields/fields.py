@@ -89,6 +89,7 @@ class Fields(object):
         # the interpolation slab), and E, B already in (kz, r) space in the scratch slab
         # (`_EB_in_kz_r`) for the spect2interp('EB') that follows.
         self.fuse_spectral_cycle = os.environ.get('FBPIC_AMD_FUSE_SPECT', '1') != '0'
+        self.spect_cycle_launches = 0        # diagnostics: fused forward Hankel + solver + inverse Hankel launches
         self._pending_hankel = None
         self._EB_in_kz_r = False
 
@@ -476,6 +477,7 @@ class Fields(object):
             self.dt, 2 if only_correct else int(bool(correct_currents)), int(bool(use_true_rho)),
             c, epsilon_0, mu_0, pa(outs), self.d_scratch.stride(0), self.Nz, self.Nr, st)
         _capi.check(rc, 'fb_spect_cycle_standard')
+        self.spect_cycle_launches += 1
         self._EB_in_kz_r = not only_correct
 
     def spect2interp(self, fieldtype):

@@ -308,7 +308,9 @@ class Simulation(object):
             # An iteration that has to re-sort runs the two-pass sequence instead: its second pass
             # walks the particles in destination order anyway and records the home cells for the
             # one-pass iterations that follow (a stand-alone sort moves 176 B per particle)
-            sorting = one_pass and any(sp.cycle_wants_sort(fld) for sp in ptcl)
+            # (every species is asked, whatever the others answer: the question also takes in the
+            # species' pending counter read-backs and counts its suspension window down)
+            sorting = one_pass and any([sp.cycle_wants_sort(fld) for sp in ptcl])
             for species in ptcl:
                 species.record_home_in_sort_pass = sorting
             if one_pass and not sorting:

@@ -582,7 +582,10 @@ class Particles(object):
 
     def cycle_wants_sort(self, fld):
         """True when the next Particles.cycle of this species would start with a sort (Simulation.step
-        then runs the two-pass sequence for the iteration, whose second pass sorts)."""
+        then runs the two-pass sequence for the iteration, whose second pass sorts).  Called ONCE per
+        iteration and species (Simulation.step asks every species, without short-circuit): it is the
+        iteration tick of the policy - it takes in the pending counter read-backs and counts the
+        suspension window down."""
         if not (self.q != 0 and self.Ntot > 0):
             return False
         self._cycle_poll()

@@ -36,9 +36,12 @@ extern "C" {
 /* ---- runtime ---------------------------------------------------------------- */
 /* revision of this header; fb_abi_version() returns the one the library was built from (the
  * Python binding refuses a library of another revision) */
-#define FB_ABI_VERSION 6
+#define FB_ABI_VERSION 7
 int fb_abi_version(void);
 const char *fb_last_error(void);
+/* target architecture and the effective compiler options of the build (incl. whether hipcc accepted the
+ * tuned scheduling options of the one-pass particle kernel); bench.py logs it next to its numbers */
+const char *fb_build_info(void);
 /* utils/cuda.py:261-299 (GPU selection) -> explicit device binding per process */
 int fb_set_device(int device);
 int fb_sync(void *stream);

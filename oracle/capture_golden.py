@@ -650,10 +650,64 @@ def cap_uniform_rho():
     # The assertions are analytic (rho = -n e inside the plasma); no fixture needed.
 
 
+def c3_thin_rows(Nz_local, iz_slab):
+    """z rows of the local grid stored by the C3 fixture: 20 around the plasma slab, 28 spread over
+    the grid (guard and damping cells at both ends included)."""
+    near = np.arange(iz_slab - 10, iz_slab + 10)
+    far = np.linspace(0, Nz_local - 1, 28).astype(int)
+    return np.unique(np.clip(np.concatenate([near, far]), 0, Nz_local - 1))
+
+
+def cap_c3_thin():
+    """BASELINE configs[2] on its OWN grid (4096 x 256, Nm = 2, open z, moving window at c, a0 = 4
+    Gaussian pulse: docs/source/example_input/lwfa_script.py) with a plasma slab of two cells inside
+    the pulse (2 x 2 x 4 macroparticles per cell, 7360 in all), 3 steps.  The interpreted reference
+    needs ~1 h for this; stored: every particle array of the final state, 48 z rows of every grid
+    (s3_rows) and, for the rows that are not stored, sum and sum of squares of every grid."""
+    import time
+    from fbpic.main import Simulation
+    from fbpic.lpa_utils.laser import add_laser_pulse, GaussianLaser
+    zmin, zmax, rmax = -10.e-6, 30.e-6, 20.e-6
+    Nz, Nr, Nm = 4096, 256, 2
+    dz = (zmax - zmin) / Nz
+    dt = dz / c
+    z_slab = 15.e-6
+    np.random.seed(0)
+    t0 = time.time()
+    sim = Simulation(Nz, zmax, Nr, rmax, Nm, dt, zmin=zmin, p_zmin=z_slab, p_zmax=z_slab + 2 * dz,
+                     p_rmin=0., p_rmax=18.e-6, p_nz=2, p_nr=2, p_nt=4, n_e=4.e24,
+                     n_order=-1, particle_shape='linear', verbose_level=0,
+                     boundaries={'z': 'open', 'r': 'reflective'})
+    add_laser_pulse(sim, GaussianLaser(a0=4., waist=5.e-6, tau=16.e-15, z0=15.e-6))
+    sim.set_moving_window(v=c)
+    print('built', time.time() - t0, 'Ntot', sim.ptcl[0].Ntot, 'local Nz', sim.fld.Nz, flush=True)
+    nstep = 3
+    res = dict(Nz=Nz, Nr=Nr, Nm=Nm, zmin=zmin, zmax=zmax, rmax=rmax, dt=dt, z_slab=z_slab, nstep=nstep,
+               Nz_local=sim.fld.Nz, n_guard=sim.comm.n_guard, n_inject=sim.comm.n_inject,
+               nz_damp=sim.comm.nz_damp)
+    res['s0_ptcl0'] = np.array([getattr(sim.ptcl[0], k) for k in PTCL[:8]])
+    for it in range(nstep):
+        t0 = time.time()
+        sim.step(1, show_progress=False)
+        print('step', it, time.time() - t0, flush=True)
+    g0 = sim.fld.interp[0]
+    iz_slab = int(round((z_slab - g0.zmin) / dz))
+    rows = c3_thin_rows(sim.fld.Nz, iz_slab)
+    full = np.array([[getattr(sim.fld.interp[m], k) for k in INTERP] for m in range(Nm)])
+    res['s3_rows'] = rows
+    res['s3_interp_rows'] = full[:, :, rows, :]
+    res['s3_interp_sum'] = full.sum(axis=(2, 3))
+    res['s3_interp_sum2'] = (np.abs(full)**2).sum(axis=(2, 3))
+    res['s3_interp_max'] = np.abs(full).max(axis=(2, 3))
+    res['s3_zmin'] = g0.zmin
+    res['s3_ptcl0'] = np.array([getattr(sim.ptcl[0], k) for k in PTCL[:8]])
+    save('c3_thin_slab', **res)
+
+
 ALL = dict(push=cap_push, gather=cap_gather, deposit=cap_deposit, grid_setup=cap_grid_setup,
            spectral=cap_spectral, cycle=cap_cycle, bunch=cap_bunch, lwfa=cap_lwfa,
            galilean=cap_galilean, crossdep=cap_crossdep,
-           laser_profiles=cap_laser_profiles)
+           laser_profiles=cap_laser_profiles, c3_thin=cap_c3_thin)
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(ALL)

@@ -36,11 +36,22 @@ _ACHIEVED = []
 # wider bound the test states - so that a bound can never again be six orders of magnitude wider
 # than what the kernels deliver (in round 3 such a bound hid an open-boundary damping that was
 # applied twice per step: 4e-8 under a 1e-9 ... 1e-8 bound).
+def newest_clamp_file():
+    """tests/golden/achieved_rNN.json with the largest round NUMBER (r100 sorts after r99)."""
+    import glob
+    import re
+    best = None
+    for path in glob.glob(os.path.join(GOLDEN, 'achieved_r*.json')):
+        m = re.match(r'achieved_r(\d+)\.json$', os.path.basename(path))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), path)
+    return best[1] if best else None
+
+
 try:
-    import glob as _glob
     import json as _json
-    _MEASURED = _json.load(open(sorted(_glob.glob(os.path.join(GOLDEN, 'achieved_r*.json')))[-1]))
-except (OSError, ValueError, IndexError):
+    _MEASURED = {k: v for k, v in _json.load(open(newest_clamp_file())).items() if not k.startswith('__')}
+except (OSError, ValueError, TypeError):
     _MEASURED = {}
 
 
@@ -74,9 +85,16 @@ def achieved(name, err, tol, what=''):
         if what:
             name += ' ' + what
     ref = _MEASURED.get(name)
+    stated = float(tol)
     if ref is not None and _clamp_applies():
-        tol = min(float(tol), max(10. * ref, 5e-15))
+        tol = min(stated, max(10. * ref, 5e-15))
     _ACHIEVED.append((name, float(err), float(tol)))
+    if err >= tol and err < stated:
+        # the CONTRACT (the tolerance the test states) holds; what failed is the
+        # regression clamp = 10 x this build's own earlier measurement on MI355X
+        raise AssertionError('%s: %.3e is within the stated tolerance %.1e but above the regression clamp %.3e '
+                             '(10 x the figure measured in earlier rounds, tests/golden/achieved_r*.json)'
+                             % (name, err, stated, tol))
     assert err < tol, (name, err, tol)
 
 

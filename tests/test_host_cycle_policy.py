@@ -158,6 +158,44 @@ def test_make_clamp_keeps_the_worst_figure_of_every_check(tmp_path):
     assert json.loads(out.read_text()) == {'x s1': 1e-14, 'y': 3e-15, 'z': 2e-16}
     # and conftest reads the newest committed file of that kind
     import conftest
-    import glob
-    newest = sorted(glob.glob(os.path.join(conftest.GOLDEN, 'achieved_r*.json')))[-1]
-    assert conftest._MEASURED == json.load(open(newest)) and len(conftest._MEASURED) > 250
+    newest = conftest.newest_clamp_file()
+    stored = {k: v for k, v in json.load(open(newest)).items() if not k.startswith('__')}
+    assert conftest._MEASURED == stored and len(conftest._MEASURED) > 250
+    # a new clamp never loosens an existing check silently: min(previous, new) unless a reason is given
+    prev, why, out2 = tmp_path / 'prev.json', tmp_path / 'why.json', tmp_path / 'o2.json'
+    prev.write_text(json.dumps({'x s1': 5e-15, 'y': 1e-14, 'gone': 7e-15}))
+    why.write_text(json.dumps({'y': 'not this one'}))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'make_clamp.py'), str(out2), '--previous', str(prev),
+                        '--looser', str(why), str(pa), str(pb)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert json.loads(out2.read_text()) == {'gone': 7e-15, 'x s1': 5e-15, 'y': 3e-15, 'z': 2e-16}
+    why.write_text(json.dumps({'x s1': 'summation order of the new kernel'}))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'make_clamp.py'), str(out2), '--previous', str(prev),
+                        '--looser', str(why), str(pa), str(pb)], capture_output=True, text=True)
+    got = json.loads(out2.read_text())
+    assert got['x s1'] == 1e-14 and got['__looser__']['x s1']['previous'] == 5e-15
+
+
+def test_clamp_file_is_chosen_by_round_number(tmp_path, monkeypatch):
+    import conftest
+    for name in ('achieved_r99.json', 'achieved_r100.json', 'achieved_r05.json'):
+        (tmp_path / name).write_text('{}')
+    monkeypatch.setattr(conftest, 'GOLDEN', str(tmp_path))
+    assert os.path.basename(conftest.newest_clamp_file()) == 'achieved_r100.json'
+
+
+def test_every_species_is_asked_every_iteration():
+    """Simulation.step asked the species with any(generator) - once a species wanted a
+    sort the later ones were neither polled nor counted down.  Now every species is asked."""
+    sim = _small_sim()
+    a = sim.ptcl[0]
+    b = sim.add_new_species(q=a.q, m=a.m)
+    for k in ('x', 'y', 'z', 'ux', 'uy', 'uz', 'inv_gamma', 'w'):
+        setattr(b, k, getattr(a, k).copy())
+    b.Ntot = a.Ntot
+    calls = []
+    a.cycle_wants_sort = lambda fld: calls.append('a') or True
+    b.cycle_wants_sort = lambda fld: calls.append('b') or False
+    src = open(os.path.join(ROOT, 'fbpic_amd', 'main.py')).read()
+    assert 'any([sp.cycle_wants_sort(fld) for sp in ptcl])' in src
+    assert any([sp.cycle_wants_sort(sim.fld) for sp in sim.ptcl]) and calls == ['a', 'b']
