@@ -34,6 +34,11 @@ import os
 import sys
 import time
 
+# The CPU baseline's OpenMP threads are bound to cores (SURVEY.md 8d recipe; docs/source/overview/
+# parallelisation.rst:47-53 of the reference): read by libgomp when it is first loaded, so set here.
+os.environ.setdefault('OMP_PROC_BIND', 'close')
+os.environ.setdefault('OMP_PLACES', 'cores')
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -202,6 +207,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=10)   # ~10 s of CPU work on 16 cores
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-side-legs', action='store_true',
+                    help='skip the uncarried-call and reference-sequence legs behind the headline')
     ap.add_argument('--resort-fragmentation', type=float, default=None,
                     help='override Particles.resort_fragmentation (adaptive sort policy)')
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
@@ -212,6 +219,17 @@ def parse():
     ap.add_argument('--reference-sequence', action='store_true',
                     help="the reference's launch sequence: no fusion, rho_prev re-deposited every step")
     return ap.parse_args()
+
+
+def set_reference_sequence(sm, on):
+    """The reference's launch sequence (every operation of fbpic/main.py:346-586 its own launch, rho_prev
+    re-deposited every step, identity FFT round trip kept) on or off."""
+    sm.redeposit_rho_prev_every_step = bool(on)
+    sm.fuse_gather_push = not on
+    sm.prerank_in_deposit = not on
+    sm.reference_sequence = bool(on)
+    for sp in sm.ptcl:
+        sp.fuse_sort_deposit_rho = not on
 
 
 def config_name(args, ppc, world):
@@ -269,12 +287,7 @@ def main():
         sm = helpers.uniform_plasma_sim(Nz_g, args.Nr, args.Nm, ppc, args.shape, seed=0,
                                         n_order=n_order, n_guard=(None if world == 1 else 64))
         if args.reference_sequence:
-            sm.redeposit_rho_prev_every_step = True
-            sm.fuse_gather_push = False
-            sm.prerank_in_deposit = False
-            sm.reference_sequence = True
-            for sp in sm.ptcl:
-                sp.fuse_sort_deposit_rho = False
+            set_reference_sequence(sm, True)
         if args.resort_fragmentation is not None:
             for sp in sm.ptcl:
                 sp.resort_fragmentation = args.resort_fragmentation
@@ -339,6 +352,35 @@ def main():
             _capi.enable_timing()
             sim.step(10)     # enough launches for a stable mean (durations vary ~15% per step)
             kern = _capi.collect_timing()
+        # Two more figures next to the headline, same state, same steps, AFTER everything the line's
+        # own numbers come from (extra.per_call_prologue_ms, extra.reference_sequence_ms_per_step):
+        #  * what one step() call costs when the state is NOT carried from the previous call - the
+        #    reference's per-call prologue (main.py:403-459: E, B exchange + transform, particle
+        #    exchange, rho_prev deposit) - against the carried call;
+        #  * the reference's own launch sequence on these kernels.
+        side = {}
+        if world == 1 and not args.reference_sequence and not args.no_side_legs:
+            def timed_call():
+                barrier()
+                ts = time.perf_counter()
+                sim.step(args.steps)
+                finish_outputs(sim)
+                barrier()
+                return 1e3 * (time.perf_counter() - ts)
+            carried = timed_call()
+            sim.carry_state_between_calls = False
+            timed_call()
+            uncarried = timed_call()
+            sim.carry_state_between_calls = True
+            side['per_call_prologue_ms'] = uncarried - carried
+            side['uncarried_call_ms_per_step'] = uncarried / args.steps
+            side['carried_call_ms_per_step'] = carried / args.steps
+            set_reference_sequence(sim, True)
+            sim.carry_state_between_calls = False
+            timed_call()
+            side['reference_sequence_ms_per_step'] = timed_call() / args.steps
+            set_reference_sequence(sim, False)
+            sim.carry_state_between_calls = True
     dt_wall = max_over_ranks(dt_wall)
     passes = {'one_pass': sum(s_.cycle_passes for s_ in sim.ptcl),
               'sorting_two_pass': sum(s_.cycle_sorts for s_ in sim.ptcl),
@@ -395,9 +437,16 @@ def main():
                                'whatever --no-kernel-timing says',
                     'clocks_before': clocks_before, 'clocks_after_headline_call': clocks_first,
                     'clocks_after': clocks_after,
-                    'particle_passes': passes}
+                    'particle_passes': passes,
+                    'build': _capi.lib().fb_build_info().decode()}
+    out['extra'].update(side)
     if kern:
         out['roofline'], out['kernels'] = roofline(kern, ceil, {'C2': True, 'C5': 'c5'}.get(config_name(args, ppc, world), False))
+        dp_issue_floor(out['roofline'], kern, clocks_first or clocks_after, out['extra']['device'])
+        tb = out['roofline'].get('traffic_box')
+        if out['roofline'].get('traffic') is not None:
+            same = bool(tb) and tb.get('unique_id_suffix') == out['extra']['device'].get('unique_id_suffix')
+            out['roofline']['traffic_stale'] = not same     # counters of another run on another box of the pool
     out['measured_ceilings'] = ceil
     if cpu_base:
         out['cpu_baseline'] = cpu_base
@@ -591,6 +640,37 @@ def roofline(kern, ceil=None, profiled_workload=True):
     return roof, compact
 
 
+def dp_issue_floor(roof, kern, clocks, device):
+    """The second, compute-side floor of the dominant particle kernel.  On gfx950 fp64 VALU instructions and
+    fp64 MFMAs share ONE pipe per SIMD (tools/overlap_probe.hip): a wave64 VALU
+    instruction occupies it for 4 cycles, v_mfma_f64_4x4x4 for 16.  With the instruction counts per chunk of
+    64 particles from the SQ counter passes committed under profiles/ (SQ_INSTS_VALU, SQ_VALU_MFMA_BUSY_CYCLES
+    per wave-chunk: profiles/r06_dp_issue_counts.json), a launch cannot be shorter than
+        chunks x (4 VALU + MFMA cycles) / (CUs x 4 SIMDs) / sclk.
+    `frac_of_dp_floor` = that floor / the measured mean launch: the kernel is bound by this pipe and by
+    the latency chain of its waves, not by HBM - `frac` (of the 8 TB/s roof) is kept because the metric's
+    target names it."""
+    try:
+        counts = json.load(open(os.path.join(ROOT, 'profiles', 'r06_dp_issue_counts.json')))
+    except (OSError, ValueError):
+        return
+    c = counts.get(roof['kernel'])
+    sclk = (clocks or {}).get('sclk_MHz')
+    if not c or roof['kernel'] not in kern:
+        return
+    recs = kern[roof['kernel']]
+    npart = sum(r[1][2] for r in recs) / len(recs)
+    chunks = (npart + 63) // 64
+    cus = device.get('compute_units', 256)
+    cyc = chunks * (4.0 * c['valu_per_chunk'] + c['mfma_cycles_per_chunk']) / (cus * 4)
+    for label, mhz in (('', sclk), ('_at_2400MHz', 2400)):
+        if mhz:
+            us = cyc / mhz
+            roof['dp_issue_floor_us' + label] = us
+            roof['frac_of_dp_floor' + label] = us / (1e3 * roof['mean_launch_ms'])
+    roof['dp_issue_counts'] = c
+
+
 # entry point -> substrings identifying its dominant device kernel in the rocprofv3 summaries
 _KERNEL_OF = {
     'fb_gather_push': ('k_gather<',), 'fb_gather': ('k_gather<',),
@@ -674,28 +754,48 @@ def cpu_model():
 
 def cpu_baseline(sim, args):
     """CPU oracle (port of the reference's Numba-threaded CPU path) on the same workload:
-    `cpu_steps` full PIC cycles at full size, one thread per available core."""
+    `cpu_steps` full PIC cycles at full size, one thread per available core, bound to cores
+    (OMP_PROC_BIND / OMP_PLACES, top of this file), the C kernels compiled for this host
+    (-O3 -march=native, oracle.build_native), the z-FFT on a thread pool as the reference plans
+    FFTW with threads = nthreads (fourier.py:59-96), np.dot on the BLAS threads NumPy brings."""
     from oracle import oracle as orc
+    native = orc.build_native()
+    if native:
+        orc.use_library(native)
     nthreads = min(orc.max_threads(), available_cores())
+    orc.FFT_WORKERS = nthreads
     o = orc.from_sim(sim, nthreads=nthreads)
     o.step(1)                       # warm-up (thread pools, FFT plans)
+    o.phase_seconds.clear()
     t0 = time.perf_counter()
     o.step(args.cpu_steps)
     dt = time.perf_counter() - t0
+    phases = {k: round(v, 3) for k, v in sorted(o.phase_seconds.items())}
     n = sum(s['x'].size for s in o.species)
     # single-thread figure (SURVEY.md 8d): one more step of the same state on one core
     orc.set_threads(1)
+    orc.FFT_WORKERS = 1
     o.nthreads = 1
     o.glob = [g[:1] for g in o.glob]
+    o.phase_seconds.clear()
     t1 = time.perf_counter()
     o.step(1)
     dt1 = time.perf_counter() - t1
+    phases1 = {k: round(v, 3) for k, v in sorted(o.phase_seconds.items())}
     return {'value': n * args.cpu_steps / dt, 'unit': 'particle-updates/s', 'cores': nthreads,
             'single_thread': n / dt1, 'cpu_model': cpu_model(), 'kind': 'port',
             'sample': '%d full PIC steps of the same %dx%d Nm=%d %d-particle workload '
                       '(after 1 warm-up step), C/OpenMP oracle + NumPy FFT/dot'
                       % (args.cpu_steps, sim.fld.Nz, sim.fld.Nr, sim.fld.Nm, n),
-            'seconds': dt}
+            'seconds': dt,
+            'build': ('gcc -O3 -march=native -ffp-contract=off -fopenmp (built on this host)' if native
+                      else 'checker build (oracle/Makefile flags): no compiler on this host'),
+            'omp': {k: os.environ.get(k) for k in ('OMP_PROC_BIND', 'OMP_PLACES')},
+            'fft_threads': nthreads,
+            'phase_seconds': phases, 'phase_seconds_single_thread_step': phases1,
+            'note': 'phases: particle kernels = gather, push, deposit (thread-private grids), reduce (their '
+                    'sum + divide by volume), erase; transforms = z-FFT (threaded pocketfft) + Hankel np.dot; '
+                    'field kernels = filter, correction, push_eb'}
 
 
 if __name__ == '__main__':

@@ -17,6 +17,7 @@ tests/golden/*.npz, produced by the real reference via oracle/capture_golden.py.
 import ctypes
 import os
 import subprocess
+import time
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -38,10 +39,35 @@ def build():
     return so
 
 
-def lib():
+def build_native():
+    """The same source compiled for THIS host (`-O3 -march=native`, contraction still off) into
+    oracle/_native/ - the build bench.py's `cpu_baseline` leg times, so that the CPU figure is not
+    held back by the portable flags of the checker library (which must run on the build container and on
+    the GPU box alike; SURVEY.md 8d asks for -O3 -march=native).  None when the compiler refuses."""
+    out = os.path.join(_HERE, '_native')
+    so = os.path.join(out, 'libfbpic_oracle_native.so')
+    src = os.path.join(_HERE, 'fbpic_oracle.c')
+    try:
+        os.makedirs(out, exist_ok=True)
+        subprocess.check_call(['gcc', '-O3', '-march=native', '-fPIC', '-fopenmp', '-ffp-contract=off',
+                               '-Wno-unused-function', '-shared', '-o', so, src, '-lm'],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        return so
+    except (OSError, subprocess.CalledProcessError):
+        return None
+
+
+def use_library(path):
+    """Load `path` instead of the checker build (bench.py: the native build of build_native)."""
+    global _LIB
+    _LIB = None
+    lib(path)
+
+
+def lib(path=None):
     global _LIB
     if _LIB is None:
-        _LIB = ctypes.CDLL(build())
+        _LIB = ctypes.CDLL(path or build())
         _LIB.orc_max_threads.restype = c_i
         from scipy.constants import c, epsilon_0, mu_0
         _LIB.orc_set_constants(c_d(c), c_d(epsilon_0), c_d(mu_0))
@@ -209,13 +235,26 @@ def push_eb_comoving(Ep, Em, Ez, Bp, Bm, Bz, Jp, Jm, Jz, rho_prev, rho_next,
         _f64(kz), c_d(dt), c_d(V), c_i(int(use_true_rho)), c_i(Nz), c_i(Nr))
 
 
+# Threads of the z-FFT.  The reference's CPU path plans its FFTW transforms with `threads = nthreads`
+# (fourier.py:59-96); 1 = np.fft as before.  bench.py's cpu_baseline sets it to the core count: the
+# columns of a (Nz, Nr) grid are then transformed by a thread pool (scipy.fft `workers`, the same
+# pocketfft kernels - the results are bit-identical to np.fft, checked in tests/test_oracle_golden.py).
+FFT_WORKERS = 1
+
+
 def fft_z(a):
     """fourier.py:104-126: unnormalised forward DFT along axis 0."""
+    if FFT_WORKERS > 1:
+        import scipy.fft
+        return scipy.fft.fft(a, axis=0, workers=FFT_WORKERS)
     return np.fft.fft(a, axis=0)
 
 
 def ifft_z(a):
     """fourier.py:128-168: backward DFT along axis 0 including the 1/Nz factor."""
+    if FFT_WORKERS > 1:
+        import scipy.fft
+        return scipy.fft.ifft(a, axis=0, workers=FFT_WORKERS)
     return np.fft.ifft(a, axis=0)
 
 
@@ -312,6 +351,19 @@ class OracleSim:
         self.iteration = 0
         self.glob = [np.zeros((nthreads, Nm, Nz + 4, Nr + 4), dtype=np.complex128)
                      for _ in range(3)]
+        # wall seconds per phase of step() (bench.py's cpu_baseline reports them)
+        self.phase_seconds = {}
+
+    def _ph(self, name):
+        sim = self
+
+        class _T:
+            def __enter__(self):
+                self.t = time.perf_counter()
+
+            def __exit__(self, *exc):
+                sim.phase_seconds[name] = sim.phase_seconds.get(name, 0.) + time.perf_counter() - self.t
+        return _T()
 
     # -- transforms (fields/fields.py:313-429)
     def interp2spect(self, ft):
@@ -349,40 +401,48 @@ class OracleSim:
         bh = t[1 if Nm > 1 else 0][ruy]
         geom = (self.invdz, self.zmin, Nz, self.invdr, 0., Nr)
         if fieldtype.startswith('rho'):
-            for m in range(Nm):
-                self.interp[m]['rho'][:] = 0.
-            self.glob[0][:] = 0.
-            for s in self.species:
-                if s['q'] == 0:
-                    continue
-                deposit_rho_global(self.shape, Nm, s['x'], s['y'], s['z'], s['w'], s['q'],
-                                   *geom, b0, bh, self.nthreads, self.glob[0])
-            for m in range(Nm):
-                sum_reduce(self.glob[0], m, self.interp[m]['rho'])
-                divide_by_volume(self.interp[m]['rho'], t[m]['invvol'])
+            with self._ph('erase'):
+                for m in range(Nm):
+                    self.interp[m]['rho'][:] = 0.
+                self.glob[0][:] = 0.
+            with self._ph('deposit'):
+                for s in self.species:
+                    if s['q'] == 0:
+                        continue
+                    deposit_rho_global(self.shape, Nm, s['x'], s['y'], s['z'], s['w'], s['q'],
+                                       *geom, b0, bh, self.nthreads, self.glob[0])
+            with self._ph('reduce'):
+                for m in range(Nm):
+                    sum_reduce(self.glob[0], m, self.interp[m]['rho'])
+                    divide_by_volume(self.interp[m]['rho'], t[m]['invvol'])
         else:
-            for g in self.glob:
-                g[:] = 0.
-            for m in range(Nm):
-                for k in ('Jr', 'Jt', 'Jz'):
-                    self.interp[m][k][:] = 0.
-            for s in self.species:
-                if s['q'] == 0:
-                    continue
-                deposit_J_global(self.shape, Nm, s['x'], s['y'], s['z'], s['w'], s['q'],
-                                 s['ux'], s['uy'], s['uz'], s['inv_gamma'], *geom, b0, bh,
-                                 self.nthreads, self.glob)
-            for m in range(Nm):
-                for i, k in enumerate(('Jr', 'Jt', 'Jz')):
-                    sum_reduce(self.glob[i], m, self.interp[m][k])
-                    divide_by_volume(self.interp[m][k], t[m]['invvol'])
-        self.interp2spect(fieldtype)
+            with self._ph('erase'):
+                for g in self.glob:
+                    g[:] = 0.
+                for m in range(Nm):
+                    for k in ('Jr', 'Jt', 'Jz'):
+                        self.interp[m][k][:] = 0.
+            with self._ph('deposit'):
+                for s in self.species:
+                    if s['q'] == 0:
+                        continue
+                    deposit_J_global(self.shape, Nm, s['x'], s['y'], s['z'], s['w'], s['q'],
+                                     s['ux'], s['uy'], s['uz'], s['inv_gamma'], *geom, b0, bh,
+                                     self.nthreads, self.glob)
+            with self._ph('reduce'):
+                for m in range(Nm):
+                    for i, k in enumerate(('Jr', 'Jt', 'Jz')):
+                        sum_reduce(self.glob[i], m, self.interp[m][k])
+                        divide_by_volume(self.interp[m][k], t[m]['invvol'])
+        with self._ph('transforms'):
+            self.interp2spect(fieldtype)
         if self.filter_currents:
-            for m in range(Nm):
-                sp = self.spect[m]
-                keys = ('Jp', 'Jm', 'Jz') if fieldtype == 'J' else (fieldtype,)
-                for k in keys:
-                    filter_(sp[k], t[m]['filter_z'], t[m]['filter_r'])
+            with self._ph('field kernels'):
+                for m in range(Nm):
+                    sp = self.spect[m]
+                    keys = ('Jp', 'Jm', 'Jz') if fieldtype == 'J' else (fieldtype,)
+                    for k in keys:
+                        filter_(sp[k], t[m]['filter_z'], t[m]['filter_r'])
 
     def gather(self):
         grids = [[self.interp[m][k] for k in INTERP[:6]] for m in range(self.Nm)]
@@ -430,24 +490,28 @@ class OracleSim:
             self.deposit('rho_prev')
             if i_step == 0:
                 self.deposit('J')
-            self.gather()
-            for s in self.species:
-                if s['q'] != 0:
-                    push_p(s['ux'], s['uy'], s['uz'], s['inv_gamma'], s['Ex'], s['Ey'], s['Ez'],
-                           s['Bx'], s['By'], s['Bz'], s['q'], s['m'], dt)
-            for s in self.species:
-                push_x(s['x'], s['y'], s['z'], s['ux'], s['uy'], s['uz'], s['inv_gamma'], 0.5 * dt)
+            with self._ph('gather'):
+                self.gather()
+            with self._ph('push'):
+                for s in self.species:
+                    if s['q'] != 0:
+                        push_p(s['ux'], s['uy'], s['uz'], s['inv_gamma'], s['Ex'], s['Ey'], s['Ez'],
+                               s['Bx'], s['By'], s['Bz'], s['q'], s['m'], dt)
+                for s in self.species:
+                    push_x(s['x'], s['y'], s['z'], s['ux'], s['uy'], s['uz'], s['inv_gamma'], 0.5 * dt)
             if self.use_galilean:
                 self.shift_galilean_boundaries(0.5 * dt)
             self.deposit('J')
             cross = correct_currents and self.current_correction == 'cross-deposition'
             if cross:
                 self.cross_deposit()
-            for s in self.species:
-                push_x(s['x'], s['y'], s['z'], s['ux'], s['uy'], s['uz'], s['inv_gamma'], 0.5 * dt)
+            with self._ph('push'):
+                for s in self.species:
+                    push_x(s['x'], s['y'], s['z'], s['ux'], s['uy'], s['uz'], s['inv_gamma'], 0.5 * dt)
             if self.use_galilean:
                 self.shift_galilean_boundaries(0.5 * dt)
             self.deposit('rho_next')
+            t_field = time.perf_counter()
             V = self.v_comoving
             if cross:
                 for m in range(self.Nm):
@@ -486,10 +550,13 @@ class OracleSim:
                                      dt, V, use_true_rho)
                 sp['rho_prev'][:] = sp['rho_next']
                 sp['rho_next'][:] = 0.
-            self.partial_roundtrip('E')
-            self.partial_roundtrip('B')
-            self.spect2interp('E')
-            self.spect2interp('B')
+            self.phase_seconds['field kernels'] = self.phase_seconds.get('field kernels', 0.) \
+                + time.perf_counter() - t_field
+            with self._ph('transforms'):
+                self.partial_roundtrip('E')
+                self.partial_roundtrip('B')
+                self.spect2interp('E')
+                self.spect2interp('B')
             self.time += dt
             self.iteration += 1
         self.spect2interp('J')

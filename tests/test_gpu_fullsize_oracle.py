@@ -12,11 +12,18 @@ charge conservation, round trips) and the one-pass / fused-spectral step to the 
   C3  the 4096 x 256 moving-window laser-wakefield grid with a thin plasma slab (reference
       fixture, see test_c3_full_grid_vs_reference_golden).
 
-Bars (the reference's own): fields <= 1e-12 of the largest component of their group
-(/root/reference/tests/test_cpu_gpu_deposition.py:96 asks 1e-13 of ONE deposition; after n whole
-steps the order of the deposition atomics has been amplified by the plasma response, see
-DESIGN.md section 2), particles <= 1e-13 matched one to one, cell indices of the final state
-bit-exact wherever the particle is not within 1e-9 of a cell boundary (SURVEY.md 8c tie mask).
+Bars: B and rho <= 1e-13 of the largest component of their group (the reference's own CPU <-> GPU bar
+for one deposition, /root/reference/tests/test_cpu_gpu_deposition.py:96), particles <= 1e-13 matched
+one to one, cell indices of the final state bit-exact wherever the particle is not within 1e-9 of a
+cell boundary (SURVEY.md 8c tie mask).  E and J: 1e-13 WITHOUT the curl-free current correction
+(`correct_currents=False`), 2e-11 with it - the correction adds i k / k^2 (rho_next - rho_prev) / dt
+to J (fields/numba_methods.py:63-85): the rounding difference of two depositions of a UNIFORM density
+(2e-15 of n e, whatever the summation order) is divided by dt and by k >= 2 pi / (Nz dz), i.e.
+multiplied by Nz / 2 pi = 163 cells and by n e c / |J| ~ 560 at u_th = 0.01 before it meets J.
+Measured (tools/c2_parity_growth.py, profiles/r06_c2_parity_growth.txt): HIP against the oracle
+4e-12 (E), 3.6e-12 (J) after the first step, falling to 8e-13 / 1.2e-12 by step 5; two ORACLE runs that
+differ only in their OpenMP thread count (3 / 16: the same arithmetic in another summation order in the
+cells a thread boundary cuts) 4e-13 ... 3e-12 over the same steps; at 32 x 16 the same quantity is 1e-13.
 Particles are matched through their weights: every macroparticle gets a unique weight
 w_i (1 + i 2^-44) on BOTH sides (same seeded input), so the pairing does not depend on the positions
 that are being compared.
@@ -37,7 +44,8 @@ def _tag_weights(sim):
 
 
 def _compare_fields(sim, orc, Nm, tol, what):
-    worst = 0.
+    """tol: {'E': ..., 'B': ..., 'J': ..., 'r': ...} (first letter of the field name)."""
+    worst = {}
     for m in range(Nm):
         for k in INTERP:
             grp = [kk for kk in INTERP if kk[0] == k[0]]
@@ -45,8 +53,8 @@ def _compare_fields(sim, orc, Nm, tol, what):
             if scale == 0:
                 continue
             err = np.abs(np.asarray(getattr(sim.fld.interp[m], k)) - orc.interp[m][k]).max() / scale
-            worst = max(worst, err)
-            achieved(None, err, tol, what)
+            worst[k[0]] = max(worst.get(k[0], 0.), err)
+            achieved(None, err, tol[k[0]], '%s %s' % (what, {'E': 'E', 'B': 'B', 'J': 'J', 'r': 'rho'}[k[0]]))
     return worst
 
 
@@ -76,7 +84,8 @@ def _compare_particles(oracle, sim, orc, tol, what):
     return worst
 
 
-def test_c2_full_size_vs_oracle(oracle):
+@pytest.mark.parametrize('correct', [True, False])
+def test_c2_full_size_vs_oracle(oracle, correct):
     """BASELINE configs[1] = the bench workload, every array of it, against the oracle."""
     from fbpic_amd.main import GpuMemoryManager
     import torch
@@ -88,7 +97,7 @@ def test_c2_full_size_vs_oracle(oracle):
     s.keep_sort_outputs = True
     nstep = 5
     with GpuMemoryManager(sim):
-        sim.step(nstep)
+        sim.step(nstep, correct_currents=correct)
         # the final sort of the HIP path: cell index of every particle (bit-exact below), sorted
         s.sort_particles(sim.fld)
         ci = s.cell_idx.cpu().numpy()
@@ -97,8 +106,9 @@ def test_c2_full_size_vs_oracle(oracle):
     # the path under test is the benchmarked one: one-pass iterations and the fused spectral launch
     assert s.cycle_passes >= 3 and s.cycle_sorts >= 1, (s.cycle_passes, s.cycle_sorts)
     assert sim.fld.spect_cycle_launches >= nstep - 1, sim.fld.spect_cycle_launches
-    orc.step(nstep)
-    wf = _compare_fields(sim, orc, 2, 1e-12, 'fields vs oracle s5')
+    orc.step(nstep, correct_currents=correct)
+    ej = 2e-11 if correct else 1e-13
+    wf = _compare_fields(sim, orc, 2, {'E': ej, 'J': ej, 'B': 1e-13, 'r': 1e-13}, 'vs oracle s5')
     wp = _compare_particles(oracle, sim, orc, 1e-13, 'particles vs oracle s5')
     # cell index of the product's own sort == the oracle's cell-index arithmetic on the product's own
     # positions, for EVERY particle (same expression, no tie mask needed), and the order is sorted
@@ -106,22 +116,26 @@ def test_c2_full_size_vs_oracle(oracle):
     ref_ci = oracle.cell_index(xs, ys, zs, g0.invdz, g0.zmin, g0.Nz, g0.invdr, g0.rmin, g0.Nr)
     assert np.array_equal(ci, ref_ci)
     assert np.all(np.diff(ci) >= 0)
-    print('C2 full size, %d steps: fields %.2e, particles %.2e vs the oracle; %d one-pass iterations, %d sorts'
-          % (nstep, wf, wp, s.cycle_passes, s.cycle_sorts))
+    print('C2 full size, %d steps, correction %s: fields %s, particles %.2e vs the oracle; %d one-pass iterations, '
+          '%d sorts' % (nstep, correct, {k: '%.1e' % v for k, v in wf.items()}, wp, s.cycle_passes, s.cycle_sorts))
 
 
-def test_c5_full_grid_vs_oracle(oracle):
+@pytest.mark.parametrize('correct,nstep', [(True, 3), (False, 2)])
+def test_c5_full_grid_vs_oracle(oracle, correct, nstep):
     """BASELINE configs[4] on its full 2048 x 512 grid, Nm = 4, cubic; 16 macroparticles per cell
-    (p_nz = p_nr = 1, p_nt = 16) instead of 64 so that the oracle steps it in seconds."""
+    (p_nz = p_nr = 1, p_nt = 16) instead of 64 so that the oracle steps it in seconds.  E and J with the
+    current correction: 2e-10 (measured 1e-11 / 4e-11: Nz = 2048 doubles the amplification named in the
+    header, 16 instead of 32 macroparticles per cell raise n e c / |J|); without it 1e-13 like B and rho."""
     from fbpic_amd.main import GpuMemoryManager
     sim = helpers.uniform_plasma_sim(2048, 512, 4, (1, 1, 16), 'cubic', seed=0)
     assert sim.ptcl[0].Ntot == 2048 * 512 * 16
     _tag_weights(sim)
     orc = helpers.oracle_from_sim(oracle, sim, nthreads=16)
-    nstep = 3
     with GpuMemoryManager(sim):
-        sim.step(nstep)
-    orc.step(nstep)
-    wf = _compare_fields(sim, orc, 4, 1e-12, 'fields vs oracle s3')
-    wp = _compare_particles(oracle, sim, orc, 1e-13, 'particles vs oracle s3')
-    print('C5 full grid (16 ppc), %d steps: fields %.2e, particles %.2e vs the oracle' % (nstep, wf, wp))
+        sim.step(nstep, correct_currents=correct)
+    orc.step(nstep, correct_currents=correct)
+    ej = 2e-10 if correct else 1e-13
+    wf = _compare_fields(sim, orc, 4, {'E': ej, 'J': ej, 'B': 1e-13, 'r': 1e-13}, 'vs oracle s%d' % nstep)
+    wp = _compare_particles(oracle, sim, orc, 1e-13, 'particles vs oracle s%d' % nstep)
+    print('C5 full grid (16 ppc), %d steps, correction %s: fields %s, particles %.2e vs the oracle'
+          % (nstep, correct, {k: '%.1e' % v for k, v in wf.items()}, wp))

@@ -1076,14 +1076,24 @@ def test_push_sort_deposit_rho_fused(hip, oracle, shape, Nm, preranked, nattr, r
             assert rel_err(host(views[m]), red) < 1e-13, m
 
 
-@pytest.mark.parametrize('shape,Nm,records,engine', [(1, 2, True, 0), (1, 1, False, 0), (3, 2, False, 0),
-                                                     (3, 4, False, 0), (1, 3, True, 0),
-                                                     # engine 1: the two depositions one after the other
-                                                     (1, 2, True, 1), (1, 4, False, 0)])
-def test_push_sort_deposit_J_rho_fused(hip, oracle, shape, Nm, records, engine):
+@pytest.mark.parametrize('shape,Nm,records,engine,uscale',
+                         [(1, 2, True, 0, 0.3), (1, 1, False, 0, 0.3), (3, 2, False, 0, 0.3),
+                          (3, 4, False, 0, 0.3), (1, 3, True, 0, 0.3),
+                          # engine 1: the two depositions one after the other
+                          (1, 2, True, 1, 0.3), (1, 4, False, 0, 0.3),
+                          # slow particles: < FB_PERM_SPLIT_AT (6) J-strays per chunk - the single
+                          # traversal of k_perm_deposit_J_rho_merged with strays written one by one
+                          (1, 2, True, 0, 0.01), (1, 3, True, 0, 0.01), (1, 1, False, 0, 0.01),
+                          # fast ones: nearly every particle changes cell within the half push
+                          (1, 2, True, 0, 3.0)])
+def test_push_sort_deposit_J_rho_fused(hip, oracle, shape, Nm, records, engine, uscale):
     """fb_push_x_sort_deposit_J_rho == fb_deposit_J (positions before the push, its own zmin) then
     fb_push_x_sort_deposit_rho: same sorted particle arrays (bit-identical pushed positions), J
-    and rho equal to the separate launches and to the oracle depositions (1e-13)."""
+    and rho equal to the separate launches and to the oracle depositions (1e-13).
+    `uscale` selects the branch of the merged linear engine (deposit.hip, k_perm_deposit_J_rho_merged):
+    with u ~ 0.3 and dt = dz / 2c a quarter of the particles change their stencil within the push, ~16
+    of 64 per chunk - the twice-traversed path (CycleDep::reduce_split, taken above FB_PERM_SPLIT_AT = 6
+    J-strays per chunk); with u ~ 0.01 ~0.5 per chunk - the single traversal."""
     from scipy.constants import c
     rng = np.random.default_rng(51 + Nm)
     n, Nz, Nr = 120001, 40, 24
@@ -1095,7 +1105,7 @@ def test_push_sort_deposit_J_rho_fused(hip, oracle, shape, Nm, records, engine):
     geom = (1. / dzc, 0., Nz, 1. / dzc, 0., Nr)
     o = np.argsort(oracle.cell_index(x, y, z, *geom), kind='stable')
     x, y, z = x[o], y[o], z[o]
-    ux, uy, uz = (rng.normal(size=n) * 0.3 for _ in range(3))
+    ux, uy, uz = (rng.normal(size=n) * uscale for _ in range(3))
     ig = 1. / np.sqrt(1. + ux**2 + uy**2 + uz**2)
     w = rng.uniform(0.5, 1.5, n)
     dt = 0.5 * dzc / c

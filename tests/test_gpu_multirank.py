@@ -37,7 +37,7 @@ def _global_particles(shape):
     return np.array([getattr(s, k) for k in helpers.PTCL])
 
 
-def _run(rank, world, port, shape, outdir, correct):
+def _run(rank, world, port, shape, outdir, correct, fuse=True, tag=''):
     import torch
     import torch.distributed as dist
     import helpers
@@ -53,24 +53,33 @@ def _run(rank, world, port, shape, outdir, correct):
     sel = (P[2] >= zlo) & (P[2] < zhi)
     sp = sim.add_new_species(q=-1.602176634e-19, m=9.1093837139e-31)
     helpers.set_species_state(sp, P[:, sel])
+    if not fuse:
+        # the forward Hankel transform of J, rho and the curl-free correction as separate launches
+        # (default on a decomposed domain: ONE launch, fb_spect_cycle_standard with correct_currents = 2)
+        sim.fld.fuse_spectral_cycle = False
     sim.step(NSTEP, correct_currents=correct)
     ng = sim.comm.n_guard
     sl = slice(ng, sim.fld.Nz - ng) if ng else slice(None)
+    if tag:
+        sl = slice(None)            # the whole local grid, guard cells included
+        out_launches = sim.fld.spect_cycle_launches
     out = {}
     for m in range(NM):
         for k in helpers.INTERP:
             out['%s_%d' % (k, m)] = getattr(sim.fld.interp[m], k)[sl]
     for k in helpers.PTCL[:8]:
         out['p_' + k] = getattr(sp, k)
-    np.savez(os.path.join(outdir, 'w%d_r%d.npz' % (world, rank)), **out)
+    if tag:
+        out['launches'] = out_launches
+    np.savez(os.path.join(outdir, 'w%d_r%d%s.npz' % (world, rank, tag)), **out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def _worker(rank, world, port, shape, outdir, correct, q):
+def _worker(rank, world, port, shape, outdir, correct, q, fuse=True, tag=''):
     try:
-        _run(rank, world, port, shape, outdir, correct)
+        _run(rank, world, port, shape, outdir, correct, fuse, tag)
         q.put((rank, 'ok'))
     except Exception:  # pragma: no cover
         import traceback
@@ -234,3 +243,50 @@ def test_two_rank_checkpoint_restart():
         for j in range(8):
             achieved(None, np.abs(B[j][o2] - A[j][o1]).max() / max(np.abs(A[j]).max(), 1e-300), 1e-14,
                      'particles')
+
+
+def test_decomposed_correction_deferral_equals_separate_launches():
+    """on a decomposed domain the forward Hankel transform of J, rho_next and the
+    curl-free correction run as ONE launch in front of the J guard exchange (Simulation._hankel_deferral
+    -> 'correct', fb_spect_cycle_standard with correct_currents = 2).  The full-size C4 test cannot see
+    a wrong fused launch (Nr = 256 > 128: it does not run there; its bounds are percent-level anyway).
+    Here, with Nr = 32: the same two ranks with the deferral and with the separate launches
+    (Fields.fuse_spectral_cycle = False), whole local grids incl. guard cells and every particle, 1e-13;
+    reference order that must hold: fbpic/main.py:530-557."""
+    import helpers
+    outdir = tempfile.mkdtemp()
+    import atexit
+    import shutil
+    atexit.register(shutil.rmtree, outdir, ignore_errors=True)
+    ctx = mp.get_context('spawn')
+    world = 2
+    for fuse, tag in ((True, '_fused'), (False, '_sep')):
+        port = _free_port()
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, 'linear', outdir, True, q, fuse, tag))
+                 for r in range(world)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=600) for _ in range(world)]
+        for p in procs:
+            p.join(60)
+        for rank, msg in res:
+            assert msg == 'ok', 'rank %d (%s):\n%s' % (rank, tag, msg)
+    for r in range(world):
+        a = np.load(os.path.join(outdir, 'w2_r%d_fused.npz' % r))
+        b = np.load(os.path.join(outdir, 'w2_r%d_sep.npz' % r))
+        assert int(a['launches']) >= NSTEP - 1 and int(b['launches']) == 0      # the launch under test did run
+        for m in range(NM):
+            for k in helpers.INTERP:
+                key = '%s_%d' % (k, m)
+                grp = [kk for kk in helpers.INTERP if kk[0] == k[0]]
+                scale = max(np.abs(b['%s_%d' % (kk, mm)]).max() for kk in grp for mm in range(NM))
+                if scale > 0:
+                    achieved(None, np.abs(a[key] - b[key]).max() / scale, 1e-13, 'fields, whole local grid')
+        pa = np.array([a['p_' + k] for k in helpers.PTCL[:8]])
+        pb = np.array([b['p_' + k] for k in helpers.PTCL[:8]])
+        assert pa.shape == pb.shape
+        o1 = np.lexsort((pa[2], pa[1], pa[0], pa[7]))
+        o2 = np.lexsort((pb[2], pb[1], pb[0], pb[7]))
+        for j, k in enumerate(helpers.PTCL[:8]):
+            achieved(None, np.abs(pa[j][o1] - pb[j][o2]).max() / max(np.abs(pb[j]).max(), 1e-300), 1e-13, 'particles')

@@ -9,7 +9,7 @@ for b in blocks:
     nm = b.split(':')[0]
     if pat not in nm or not nm.startswith('_Z'):
         continue
-    body = b.split('s_endpgm')[0]
+    body = b.split('.Lfunc_end')[0]
     cnt = collections.Counter()
     for line in body.split('\n'):
         line = line.strip()

@@ -7,7 +7,7 @@ python3 - $NM <<'PY'
 import re, sys, collections
 s = open('/tmp/isa_cycle_marks.s').read()
 nm = '_ZN2fb14k_cycle_linearILi%sELb0ELb0EEEvNS_9CycleArgsE' % sys.argv[1]
-b = [x for x in re.split(r'\n(?=_Z\w+:)', s) if x.startswith(nm + ':')][0].split('s_endpgm')[0]
+b = [x for x in re.split(r'\n(?=_Z\w+:)', s) if x.startswith(nm + ':')][0].split('.Lfunc_end')[0]
 sec = 'PROLOGUE'; cnt = collections.OrderedDict()
 def kind(op, line):
     if op.startswith('v_mfma'): return 'mfma'
