@@ -20,6 +20,11 @@ _SIGNATURES = {
     'fb_abi_version': (I, []),
     'fb_last_error': (ctypes.c_char_p, []),
     'fb_build_info': (ctypes.c_char_p, []),
+    'fb_last_error_string': (ctypes.c_char_p, []),
+    'fb_malloc': (I, [Z, ctypes.POINTER(P)]),
+    'fb_free': (I, [P]),
+    'fb_h2d': (I, [P, P, Z, P]),
+    'fb_d2h': (I, [P, P, Z, P]),
     'fb_set_device': (I, [I]),
     'fb_sync': (I, [P]),
     'fb_comm_unique_id': (I, [P]),
@@ -226,7 +231,7 @@ class _TimedLib(object):
 
     def __getattr__(self, name):
         f = getattr(self._real, name)
-        if not name.startswith('fb_') or name in ('fb_last_error', 'fb_build_info', 'fb_abi_version',
+        if not name.startswith('fb_') or name in ('fb_last_error', 'fb_last_error_string', 'fb_build_info', 'fb_abi_version', 'fb_malloc', 'fb_free', 'fb_h2d', 'fb_d2h',
                                                   'fb_sort_workspace_bytes', 'fb_bin_sort_workspace_bytes', 'fb_handover_workspace_bytes', 'fb_fft_plan_create',
                                                   'fb_fft_plan_destroy', 'fb_sync', 'fb_set_device', 'fb_gather_push_deposit_supported', 'fb_spect_cycle_supported', 'fb_comm_unique_id', 'fb_comm_init', 'fb_comm_destroy', 'fb_zfft_supported', 'fb_fft_generic_supported', 'fb_fft_generic_from_records_supported'):
             return f

@@ -76,31 +76,38 @@ struct CycleArgs {
 // measured too: 266-273 us against 266-274 at C2, profiles/README.md.)
 // WIDE: grids / deposition targets that are not within 4 GiB of each other (separately allocated
 // arrays): 64-bit pointers per lane instead of a scalar base + 32-bit lane offsets.
-template <int NM, bool WIDE> struct CyclePlan {
-    static constexpr int S = 2;
+template <int SHAPE, int NM, bool WIDE> struct CyclePlan {
+    static constexpr int S = ShapeTraits<SHAPE>::S, H = ShapeTraits<SHAPE>::H;
     static constexpr int NV = S * S * 6 * NM;              // complex node values of a segment
     static constexpr int NVL = (NV + 63) / 64;             // ... per lane
-    static constexpr int NSEG = (NVL == 1) ? 6 : 3;        // segments staged per round
+    // segments staged per round (cubic: 3 KB per segment at Nm = 2, 6 KB at Nm = 4)
+    static constexpr int NSEG = (NVL == 1) ? 6 : (S == 2 ? 3 : 2);
     // panel stride in doubles: load j of a segment fills the 16-B slots 64 j ... of its lanes
     // (only NV of them in all), + a 16-B pad (segments start on different banks)
     static constexpr int PSTR = 2 * NV + 2;
     // WIDE: the two DepEngines one after the other on one panel (64-bit pointers per lane); else the
     // merged engine of cycle_dep.h (J and rho staged together, one traversal of the runs).
     // (-DFB_CYCLE_TWO_ENGINES: round 4's form of the 32-bit path as well, for A/B builds)
+    // Cubic shape (round 6): the two DepEngines (node-row MFMA blocks, dep_engine.h), 32-bit offsets.
 #ifdef FB_CYCLE_TWO_ENGINES
     static constexpr bool MERGED = false;
 #else
-    static constexpr bool MERGED = !WIDE;
+    static constexpr bool MERGED = !WIDE && SHAPE == FB_SHAPE_LINEAR;
 #endif
-    using EJ = DepEngine<FB_SHAPE_LINEAR, 3, NM, true, !WIDE && !MERGED>;
-    using ER = DepEngine<FB_SHAPE_LINEAR, 1, NM, true, !WIDE && !MERGED>;
+    using EJ = DepEngine<SHAPE, 3, NM, true, !WIDE && !MERGED>;
+    using ER = DepEngine<SHAPE, 1, NM, true, !WIDE && !MERGED>;
     using ED = CycleDep<NM>;
     static constexpr int DEP2_DOUBLES = EJ::L::WAVE_DOUBLES > ER::L::WAVE_DOUBLES ? EJ::L::WAVE_DOUBLES
                                                                                   : ER::L::WAVE_DOUBLES;
     static constexpr int DEP_DOUBLES = MERGED ? ED::L::WAVE_DOUBLES : DEP2_DOUBLES;
     static constexpr int GATHER_DOUBLES = NSEG * PSTR;
-    // the two panels do not share LDS: the node values of chunk c+1 arrive while chunk c deposits
-    static constexpr int WAVE_DOUBLES = GATHER_DOUBLES + DEP_DOUBLES;
+    // Linear shape: the two panels do not share LDS - the node values of chunk c+1 arrive while chunk c
+    // deposits.  Cubic shape, Nm >= 3: they DO (the gather panel lies on top of the deposition panel:
+    // 18 KB per wave at Nm = 4 instead of 30, i.e. 8 waves per CU instead of 5), and the node values of
+    // chunk c+1 are requested at the END of chunk c.
+    static constexpr bool OVERLAY = (SHAPE == FB_SHAPE_CUBIC) && NM >= 3;
+    static constexpr int WAVE_DOUBLES = OVERLAY ? (GATHER_DOUBLES > DEP_DOUBLES ? GATHER_DOUBLES : DEP_DOUBLES)
+                                                : GATHER_DOUBLES + DEP_DOUBLES;
 };
 
 // Array pointers are fetched from the kernel-argument segment where they are used (one scalar
@@ -196,14 +203,14 @@ struct CycleFront {
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *glb_ptr_t;
 
-template <int NM, bool WIDE, bool RANK>
+template <int SHAPE, int NM, bool WIDE, bool RANK>
 __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
 {
-    using P = CyclePlan<NM, WIDE>;
+    using P = CyclePlan<SHAPE, NM, WIDE>;
     using EJ = typename P::EJ;
     using ER = typename P::ER;
     using ED = typename P::ED;
-    constexpr int S = 2, NV = P::NV, NVL = P::NVL, NSEG = P::NSEG, PSTR = P::PSTR;
+    constexpr int S = P::S, H = P::H, NV = P::NV, NVL = P::NVL, NSEG = P::NSEG, PSTR = P::PSTR;
     extern __shared__ double lds[];
     const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -211,7 +218,7 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
     // and, behind it, the panel of the deposition engines
     // (RANK mode has no deposition panel)
     double *gpanel = lds + (size_t)wave * (RANK ? P::GATHER_DOUBLES : P::WAVE_DOUBLES);
-    double *dpanel = gpanel + P::GATHER_DOUBLES;
+    double *dpanel = P::OVERLAY ? gpanel : gpanel + P::GATHER_DOUBLES;
     const long n = A.n;
     const int Nz = A.Nz, Nr = A.Nr, ncol = Nr + 1;
     const long rs = A.rsG;
@@ -234,8 +241,8 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
     const unsigned long long le = (2ull << lane) - 1ull, lt = (1ull << lane) - 1ull;
 
     // staging role of this lane in the gather: node value o = lane + 64 j of every segment
-    // (node (jz, jr) = the two low bits of the lane, field lane / 4 + 16 j)
-    const int st_jr = lane & 1, st_jz = (lane >> 1) & 1;
+    // (node (jz, jr) = the low bits of the lane - 64 is a multiple of S S -, field o / (S S))
+    const int st_jr = lane & (S - 1), st_jz = (lane / S) & (S - 1);
     // its field as a 32-bit byte offset from the lowest of the grids (scalar base + lane offset
     // addressing; the host has checked that all of them lie within 4 GiB)
     unsigned st_rel[NVL];
@@ -287,7 +294,7 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
             }
         }
     };
-    auto front = [&](CycleFront &f, long base, double xj, double yj, double zj, int hn) {
+    auto front = [&](CycleFront &f, long base, double xj, double yj, double zj, int hn, bool ask) {
         // (Lanes beyond the last particle hold a copy of it - load_pos - and compute along: only
         // the masks, the stores and the deposited weight know that they are not particles.  The
         // chunk loop then has no divergent region around its arithmetic.)
@@ -312,7 +319,7 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
         const int hc = hn - A.home_shift;
         const int hzu = (int)floor(((double)hc + 0.5) * A.inv_ncol);
         const int hru = hc - hzu * ncol;
-        f.hkz = hzu - 1; f.hkr = hru - 1; f.hnb = 1 - hru;
+        f.hkz = hzu - H; f.hkr = hru - H; f.hnb = H - hru;
         const int hprev = __shfl_up(hc, 1);
         f.runstarts = __ballot(act && (lane == 0 || hc != hprev));
         // own stencil origin (threading_methods.py:108-117)
@@ -321,7 +328,8 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
         const double r_cell = A.invdr * (rj - A.rmin) - 0.5;
         const double z_cell = A.invdz * (zj - A.zmin) - 0.5;
         const bool inside = act && rj < A.rmax_gather;
-        const int kr = (int)floor(r_cell), kz = (int)floor(z_cell);
+        // (cubic: threading_methods.py:312-321 - the stencil starts one node below the lower node)
+        const int kr = (int)floor(r_cell) - (H - 1), kz = (int)floor(z_cell) - (H - 1);
         f.kz = kz; f.kr = kr;
         const bool g_home = inside && kz == f.hkz && kr == f.hkr;
         const unsigned long long g_homem = __ballot(g_home);
@@ -339,7 +347,7 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
         f.myseg = g_home ? __popcll(g_runs & le) - 1 : ngruns + __popcll(straym & lt);
         f.rem_r = g_runs; f.rem_s = straym;
 #ifndef FB_KNOCK_NODES            // (timing experiment: no node loads for the next chunk)
-        request(f, min(NSEG, f.nseg));
+        if (ask) request(f, min(NSEG, f.nseg));
 #endif
     };
 
@@ -376,7 +384,7 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
     load_pos(base, xn, yn, zn, hn);
     load_mom(base);
     CycleFront fr;
-    front(fr, base, xn, yn, zn, hn);
+    front(fr, base, xn, yn, zn, hn, true);
     if (A.chunks_per_wave > 1) load_pos(base + 64, xn, yn, zn, hn);
     fb_wait_vm();
     unsigned int nstray_J = 0, nbad = 0;
@@ -404,31 +412,48 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
             load_mom(nbase);
             if (ch + 2 < A.chunks_per_wave) load_pos(nbase + 64, xq, yq, zq, hq);
         }
-        // ---- gather: shape factors (threading_methods.py:108-117), cos, sin
+        // ---- gather: shape factors (threading_methods.py:108-117, 312-321), cos, sin
         double cs, sn, Sz[S], Sr[S];
-        bool axis;
+        int nbel;                     // stencil columns below the axis (0 .. H)
         {
             const double rj = fr.rj;
             const double r_cell = A.invdr * (rj - A.rmin) - 0.5;
             const double z_cell = A.invdz * (zj - A.zmin) - 0.5;
             const int kr = fr.kr, kz = fr.kz;
-            Sr[0] = (kr + 1) - r_cell; Sr[1] = r_cell - kr;
-            Sz[0] = (kz + 1) - z_cell; Sz[1] = z_cell - kz;
-            axis = kr < 0;
+            if constexpr (SHAPE == FB_SHAPE_LINEAR) {
+                Sr[0] = (kr + 1) - r_cell; Sr[1] = r_cell - kr;
+                Sz[0] = (kz + 1) - z_cell; Sz[1] = z_cell - kz;
+            } else {
+                double l = r_cell - kr;
+                double a = l - 2., b = l - 1., cc = 2. - l, d = 1. - l;
+                Sr[0] = -1. / 6. * (a * (a * a));
+                Sr[1] = 1. / 6. * (3. * (b * (b * b)) - 6. * (b * b) + 4.);
+                Sr[2] = 1. / 6. * (3. * (cc * (cc * cc)) - 6. * (cc * cc) + 4.);
+                Sr[3] = -1. / 6. * (d * (d * d));
+                l = z_cell - kz;
+                a = l - 2.; b = l - 1.; cc = 2. - l; d = 1. - l;
+                Sz[0] = -1. / 6. * (a * (a * a));
+                Sz[1] = 1. / 6. * (3. * (b * (b * b)) - 6. * (b * b) + 4.);
+                Sz[2] = 1. / 6. * (3. * (cc * (cc * cc)) - 6. * (cc * cc) + 4.);
+                Sz[3] = -1. / 6. * (d * (d * d));
+            }
+            nbel = -kr;
             const double invr = 1. / rj;
             cs = (rj != 0.) ? xj * invr : 1.;
             sn = (rj != 0.) ? yj * invr : 0.;
         }
-        // Weights of the 2 x 2 nodes.  Stencil column 0 of a particle in the first half cell lies
-        // below the axis: its node values are those of the mirror node times -(-1)^m (r, t
-        // components) or +(-1)^m (z) (gathering/inline_functions.py:70-79) - the sign goes to the
-        // weight here ((-w) v = -(w v) exactly: the same sums as k_gather's signed panel values)
-        double wp[S][S], wm[S];
+        // Weights of the S x S nodes.  The stencil columns of a particle near the axis that lie
+        // below it (jr < nbel: one for the linear shape, up to two for the cubic one) take the values
+        // of their mirror nodes times -(-1)^m (r, t components) or +(-1)^m (z)
+        // (gathering/inline_functions.py:70-79, 151-158) - the sign goes to the weight here ((-w) v =
+        // -(w v) exactly: the same sums as k_gather's signed panel values)
+        double wp[S][S], wm[S][H];
 #pragma unroll
         for (int jz = 0; jz < S; jz++) {
-            wp[jz][0] = Sz[jz] * Sr[0];
-            wp[jz][1] = Sz[jz] * Sr[1];
-            wm[jz] = axis ? -wp[jz][0] : wp[jz][0];
+#pragma unroll
+            for (int jr = 0; jr < S; jr++) wp[jz][jr] = Sz[jz] * Sr[jr];
+#pragma unroll
+            for (int jr = 0; jr < H; jr++) wm[jz][jr] = (jr < nbel) ? -wp[jz][jr] : wp[jz][jr];
         }
         FB_MARK("M_EVAL");
         double F[6] = {0., 0., 0., 0., 0., 0.};
@@ -458,7 +483,7 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
 #pragma unroll
                             for (int jr = 0; jr < S; jr++) {
                                 const double2 v = *(const double2 *)(Pf + 2 * (jz * S + jr));
-                                const double w_ = (jr == 0 && neg) ? wm[jz] : wp[jz][jr];
+                                const double w_ = (jr < H && neg) ? wm[jz][jr] : wp[jz][jr];
                                 fr_ = __builtin_fma(w_, v.x, fr_); fi_ = __builtin_fma(w_, v.y, fi_);
                             }
                         // m = 0: exptheta = 1 + 0i and factor = 1 (as in k_gather)
@@ -477,7 +502,7 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
         FB_MARK("M_FRONT");
         // ---- front half of the next chunk: its node loads travel during the rest of this one
         if (more) {
-            front(fr, nbase, xn, yn, zn, hn);
+            front(fr, nbase, xn, yn, zn, hn, !P::OVERLAY);
         }
 
         FB_MARK("M_VAY");
@@ -583,6 +608,7 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
                 const bool home = act && dkz == hkz && dkr == hkr && dnb == hnb;
                 const unsigned long long hm = __ballot(home), sm = __ballot(act && !home);
                 nstray_J += __popcll(sm);
+                nbad += (__popcll(sm) > FB_CYCLE_BAD_CHUNK) ? 1u : 0u;
                 wave_lds_release();
                 ej.reduce_home(cnt, runstarts, hm, hkz, hkr, hnb);
                 ej.scatter_strays(sm, dkz, dkr, dnb);
@@ -623,6 +649,12 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
         }
         FB_MARK("M_END");
         if (!more) break;
+        if constexpr (P::OVERLAY) {
+            // the panel is free again (every LDS read of the depositions has returned): the node values
+            // of the next chunk leave now
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            request(fr, min(NSEG, fr.nseg));
+        }
         base = nbase;
     }
     if constexpr (RANK) {
@@ -650,16 +682,20 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
 }
 
 template <int NM, bool WIDE, bool RANK>
-__global__ __launch_bounds__(256) void k_cycle_linear(CycleArgs A) { cycle_linear_body<NM, WIDE, RANK>(A); }
+__global__ __launch_bounds__(256) void k_cycle_linear(CycleArgs A) { cycle_linear_body<FB_SHAPE_LINEAR, NM, WIDE, RANK>(A); }
+// cubic shape (round 6): the same pass with the 4 x 4 stencil - lane-by-lane stencil sums from the staged
+// node values, the two cubic DepEngines on the home runs
+template <int NM, bool WIDE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_cycle_cubic(CycleArgs A) { cycle_linear_body<FB_SHAPE_CUBIC, NM, WIDE, false>(A); }
 // (The ranking form has no deposition panel - 4.7 KB of LDS per wave - and needs 129-136 VGPRs; asked to
 // fit 128 the compiler finds them without a spill at Nm = 2, and a fourth wave per SIMD fits: measured
 // SLOWER, 0.165 against 0.156 ms per launch at C2 - more waves in flight span more of the grid than the
 // XCD's L2 keeps, as with longer per-wave ranges.  Not used.)
 
-template <int NM, bool WIDE, bool RANK = false>
+template <int SHAPE, int NM, bool WIDE, bool RANK = false>
 static int launch_cycle_linear(const CycleArgs &A0, hipStream_t s)
 {
-    using P = CyclePlan<NM, WIDE>;
+    using P = CyclePlan<SHAPE, NM, WIDE>;
     CycleArgs A = A0;
     const size_t wave_bytes = 8 * (size_t)(RANK ? P::GATHER_DOUBLES : P::WAVE_DOUBLES);
     // one wave per workgroup (nothing is shared between the waves of this kernel): 0.260 against
@@ -677,16 +713,22 @@ static int launch_cycle_linear(const CycleArgs &A0, hipStream_t s)
     A.chunks_per_wave = cpw;
     const long total_waves = (nchunks + cpw - 1) / cpw;
     const long nblocks = xcd_grid((total_waves + nwaves - 1) / nwaves);
-    hipLaunchKernelGGL((k_cycle_linear<NM, WIDE, RANK>), dim3((unsigned)nblocks), dim3(64 * nwaves),
-                       wave_bytes * nwaves, s, A);
+    if constexpr (SHAPE == FB_SHAPE_CUBIC)
+        hipLaunchKernelGGL((k_cycle_cubic<NM, WIDE>), dim3((unsigned)nblocks), dim3(64 * nwaves),
+                           wave_bytes * nwaves, s, A);
+    else
+        hipLaunchKernelGGL((k_cycle_linear<NM, WIDE, RANK>), dim3((unsigned)nblocks), dim3(64 * nwaves),
+                           wave_bytes * nwaves, s, A);
     return check(hipGetLastError(), RANK ? "fb_gather_push_rank_next_home" : "fb_gather_push_deposit_J_rho");
 }
 
 template <int NM>
-static int launch_cycle(const CycleArgs &A, bool wide, bool rank, hipStream_t s)
+static int launch_cycle(const CycleArgs &A, int shape, bool wide, bool rank, hipStream_t s)
 {
-    if (rank) return wide ? launch_cycle_linear<NM, true, true>(A, s) : launch_cycle_linear<NM, false, true>(A, s);
-    return wide ? launch_cycle_linear<NM, true>(A, s) : launch_cycle_linear<NM, false>(A, s);
+    constexpr int L = FB_SHAPE_LINEAR, C = FB_SHAPE_CUBIC;
+    if (shape == C) return wide ? launch_cycle_linear<C, NM, true>(A, s) : launch_cycle_linear<C, NM, false>(A, s);
+    if (rank) return wide ? launch_cycle_linear<L, NM, true, true>(A, s) : launch_cycle_linear<L, NM, false, true>(A, s);
+    return wide ? launch_cycle_linear<L, NM, true>(A, s) : launch_cycle_linear<L, NM, false>(A, s);
 }
 
 }  // namespace fb
@@ -704,7 +746,7 @@ extern "C" int fb_debug_cycle_trace(unsigned long long *host_out, int reset)
 
 extern "C" int fb_gather_push_deposit_supported(int shape, int Nm)
 {
-    return shape == FB_SHAPE_LINEAR && Nm >= 1 && Nm <= 4;
+    return (shape == FB_SHAPE_LINEAR || shape == FB_SHAPE_CUBIC) && Nm >= 1 && Nm <= 4;
 }
 
 static int cycle_entry(const char *who, bool rank, int shape, int Nm, long n,
@@ -720,8 +762,9 @@ static int cycle_entry(const char *who, bool rank, int shape, int Nm, long n,
         int *rk_cell, int *rk_rank, int *rk_count, int home_cell_shift, void *stream)
 {
     if (n <= 0) return 0;
-    if (!fb_gather_push_deposit_supported(shape, Nm)) {
-        set_error(who, "linear shape, Nm = 1..4 (use the separate entry points otherwise)");
+    if (!fb_gather_push_deposit_supported(shape, Nm) || (rank && shape != FB_SHAPE_LINEAR)) {
+        set_error(who, rank ? "linear shape, Nm = 1..4 (use the separate entry points otherwise)"
+                            : "linear or cubic shape, Nm = 1..4 (use the separate entry points otherwise)");
         return -1;
     }
     if (!home_cell) { set_error(who, "home_cell (cell of every particle at the last sort) is required"); return -1; }
@@ -788,10 +831,10 @@ static int cycle_entry(const char *who, bool rank, int shape, int Nm, long n,
     A.rk_cell = rk_cell; A.rk_rank = rk_rank; A.rk_count = rk_count;
     hipStream_t s = (hipStream_t)stream;
     switch (Nm) {
-    case 1: return launch_cycle<1>(A, wide, rank, s);
-    case 2: return launch_cycle<2>(A, wide, rank, s);
-    case 3: return launch_cycle<3>(A, wide, rank, s);
-    default: return launch_cycle<4>(A, wide, rank, s);
+    case 1: return launch_cycle<1>(A, shape, wide, rank, s);
+    case 2: return launch_cycle<2>(A, shape, wide, rank, s);
+    case 3: return launch_cycle<3>(A, shape, wide, rank, s);
+    default: return launch_cycle<4>(A, shape, wide, rank, s);
     }
 }
 

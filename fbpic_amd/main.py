@@ -194,6 +194,11 @@ class Simulation(object):
         # re-sort every few steps only, where the conditions of _one_pass_ok hold; else the
         # two-pass sequence (gather + push + rank | deposit J + push + sort + deposit rho).
         self.one_pass_cycle = os.environ.get('FBPIC_AMD_ONE_PASS', '1') != '0'
+        # ... for the cubic shape too (round 6: k_cycle_cubic) - built, pinned, and OFF by default: at C5 (2048 x 512,
+        # Nm = 4, 64 ppc) the pass takes 15.5 ms where the two passes take 5.3 + 5.5 (its stencil sums are
+        # lane-by-lane LDS reads - 393 KB per 64 particles - where the two-pass gather runs on the matrix
+        # cores, and 256 VGPRs + 18 KB of LDS leave 2 waves per SIMD): profiles/r06_c5_onepass_vs_twopass.txt
+        self.one_pass_cubic = False
         self._eb_pending = None
         self._comm_stream = None
 
@@ -377,7 +382,9 @@ class Simulation(object):
         supported by the kernel."""
         fld, comm = self.fld, self.comm
         if not (self.one_pass_cycle and not self.reference_sequence and not cross
-                and not self.use_galilean and self.particle_shape == 'linear'):
+                and not self.use_galilean):
+            return False
+        if self.particle_shape != 'linear' and not self.one_pass_cubic:
             return False
         if comm.size > 1 and ((correct_currents is False) or (use_true_rho is True)):
             return False             # those deposits exchange their guard cells on the interpolation grid
@@ -416,12 +423,16 @@ class Simulation(object):
         fld = self.fld
         self._wait_eb()
         self._flush_J_transform()
-        fld.erase_source_records()
+        records = self.particle_shape == 'linear'
+        if records:
+            fld.erase_source_records()
+        else:
+            fld.erase('J+rho')       # cubic shape: the J | rho fields of the interpolation slab
         for species in self.ptcl:
             species.cycle(fld, self.comm, self.dt, store_fields=store_fields, wrap_z=wrap_z)
             species.keep_fields_sorted = False
-        fld.interp2spect_J_and_rho_next(fuse_filter=self.filter_currents, from_records=True,
-                                        defer_hankel=self._hankel_deferral())
+        fld.interp2spect_J_and_rho_next(fuse_filter=self.filter_currents, from_records=records,
+                                        defer_hankel=self._hankel_deferral() if records else False)
         # (what deposit() records: single domain only when these are True, see _one_pass_ok)
         fld.exchanged_source['J'] = (correct_currents is False)
         fld.exchanged_source['rho_next'] = (use_true_rho is True)

@@ -491,7 +491,7 @@ class Particles(object):
             if part == 'inside':
                 return                      # the book-keeping below belongs to the completed pass
         elif ranked and self._home_valid and rank_next == (dt_x, 1., 1., 1.) \
-                and self._home_shift(g0) is not None \
+                and self._home_shift(g0) is not None and self.particle_shape == 'linear' \
                 and _capi.lib().fb_gather_push_deposit_supported(_SHAPE[self.particle_shape], Nm):
             # arrays sorted some steps ago (a sorting iteration of the one-pass cycle): segments
             # from the home cells, which a stale order does not fragment
@@ -645,9 +645,18 @@ class Particles(object):
             views += [grid[m].Er, grid[m].Et, grid[m].Ez, grid[m].Br, grid[m].Bt, grid[m].Bz]
         eb = [p(getattr(self, k)) if store_fields else None for k in _FIELDS]
         wz = (0., 0.) if wrap_z is None else (float(wrap_z[0]), float(wrap_z[1]))
-        jv, rv = fld.record_views('J'), fld.record_views('rho')
-        ruy0 = grid[0].d_ruyten_linear_coef
-        ruyh = grid[1 if Nm > 1 else 0].d_ruyten_linear_coef
+        if self.particle_shape == 'linear':
+            # the node-major records (one cache line per node: a linear flush is one atomic instruction)
+            jv, rv = fld.record_views('J'), fld.record_views('rho')
+        else:
+            # cubic shape: the J | rho fields of the interpolation slab (16 nodes per cell either way)
+            jv = []
+            for m in range(Nm):
+                jv += [grid[m].Jr, grid[m].Jt, grid[m].Jz]
+            rv = [grid[m].rho for m in range(Nm)]
+        suffix = 'linear' if self.particle_shape == 'linear' else 'cubic'
+        ruy0 = getattr(grid[0], 'd_ruyten_%s_coef' % suffix)
+        ruyh = getattr(grid[1 if Nm > 1 else 0], 'd_ruyten_%s_coef' % suffix)
         stats = self._cycle_stats
         # (the counters are cumulative - the pass adds to them; one small copy per pass, no memset)
         self._cycle_poll()

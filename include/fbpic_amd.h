@@ -42,9 +42,20 @@ const char *fb_last_error(void);
 /* target architecture and the effective compiler options of the build (incl. whether hipcc accepted the
  * tuned scheduling options of the one-pass particle kernel); bench.py logs it next to its numbers */
 const char *fb_build_info(void);
+/* same text as fb_last_error (the name SURVEY.md 8b lists) */
+const char *fb_last_error_string(void);
 /* utils/cuda.py:261-299 (GPU selection) -> explicit device binding per process */
 int fb_set_device(int device);
 int fb_sync(void *stream);
+/* Device arrays for a host application that has no array library of its own (the reference wraps
+ * numba.cuda device arrays: utils/cuda.py:101-137 `cuda.to_device` / `copy_to_host`; fbpic_amd itself hands
+ * in PyTorch-ROCm tensors and never calls these).  The caller still owns every buffer: the library frees
+ * nothing on its own.  fb_h2d / fb_d2h are asynchronous on `stream` (host memory that is not page-locked
+ * makes the runtime stage the copy; fb_sync(stream) before the host buffer is reused or read). */
+int fb_malloc(size_t nbytes, void **device_ptr);
+int fb_free(void *device_ptr);
+int fb_h2d(void *device_dst, const void *host_src, size_t nbytes, void *stream);
+int fb_d2h(void *host_dst, const void *device_src, size_t nbytes, void *stream);
 
 /* ---- transport between the z-slabs of neighbouring ranks (one rank per GPU) ----------------
  * Replaces BoundaryCommunicator.exchange_domains, fbpic/boundaries/boundary_communicator.py:

@@ -120,8 +120,8 @@ def test_c2_full_size_vs_oracle(oracle, correct):
           '%d sorts' % (nstep, correct, {k: '%.1e' % v for k, v in wf.items()}, wp, s.cycle_passes, s.cycle_sorts))
 
 
-@pytest.mark.parametrize('correct,nstep', [(True, 3), (False, 2)])
-def test_c5_full_grid_vs_oracle(oracle, correct, nstep):
+@pytest.mark.parametrize('correct,nstep,one_pass', [(True, 3, False), (False, 2, False), (False, 2, True)])
+def test_c5_full_grid_vs_oracle(oracle, correct, nstep, one_pass):
     """BASELINE configs[4] on its full 2048 x 512 grid, Nm = 4, cubic; 16 macroparticles per cell
     (p_nz = p_nr = 1, p_nt = 16) instead of 64 so that the oracle steps it in seconds.  E and J with the
     current correction: 2e-10 (measured 1e-11 / 4e-11: Nz = 2048 doubles the amplification named in the
@@ -131,11 +131,75 @@ def test_c5_full_grid_vs_oracle(oracle, correct, nstep):
     assert sim.ptcl[0].Ntot == 2048 * 512 * 16
     _tag_weights(sim)
     orc = helpers.oracle_from_sim(oracle, sim, nthreads=16)
+    # one_pass: the cubic one-pass kernel (k_cycle_cubic, opt-in) instead of the two passes bench.py times
+    sim.one_pass_cubic = one_pass
     with GpuMemoryManager(sim):
         sim.step(nstep, correct_currents=correct)
+    assert (sim.ptcl[0].cycle_passes > 0) == one_pass
     orc.step(nstep, correct_currents=correct)
     ej = 2e-10 if correct else 1e-13
     wf = _compare_fields(sim, orc, 4, {'E': ej, 'J': ej, 'B': 1e-13, 'r': 1e-13}, 'vs oracle s%d' % nstep)
     wp = _compare_particles(oracle, sim, orc, 1e-13, 'particles vs oracle s%d' % nstep)
     print('C5 full grid (16 ppc), %d steps, correction %s: fields %s, particles %.2e vs the oracle'
           % (nstep, correct, {k: '%.1e' % v for k, v in wf.items()}, wp))
+
+
+def test_c3_full_grid_vs_reference_golden():
+    """BASELINE configs[2] on its OWN grid - 4096 x 256, Nm = 2, open z with damping, moving window at c,
+    a0 = 4 Gaussian pulse (docs/source/example_input/lwfa_script.py) - against the REAL reference
+    (tests/golden/c3_thin_slab.npz, oracle/capture_golden.py:cap_c3_thin: the interpreted reference needs
+    ~40 min for it): a plasma slab of two cells inside the pulse (7360 macroparticles, 2 x 2 x 4 per cell),
+    3 steps.  Compared: every particle array of the final state, 48 z rows of every grid (20 around the
+    slab, 28 over the whole local grid incl. guard and damping cells), and sum / sum of squares / maximum
+    of EVERY grid over all 4416 x 256 cells (what the stored rows do not see).  The small-grid trajectory
+    with injection and hand-overs is tests/test_gpu_lwfa.py."""
+    from scipy.constants import c
+    from conftest import golden
+    from fbpic_amd.main import Simulation
+    from fbpic_amd.lpa_utils.laser import add_laser_pulse, GaussianLaser
+    g = golden('c3_thin_slab')
+    Nz, Nr, Nm = int(g['Nz']), int(g['Nr']), int(g['Nm'])
+    assert (Nz, Nr, Nm) == (4096, 256, 2)
+    zmin, zmax, rmax, dt, z_slab = (float(g[k]) for k in ('zmin', 'zmax', 'rmax', 'dt', 'z_slab'))
+    dz = (zmax - zmin) / Nz
+    np.random.seed(0)
+    sim = Simulation(Nz, zmax, Nr, rmax, Nm, dt, zmin=zmin, p_zmin=z_slab, p_zmax=z_slab + 2 * dz,
+                     p_rmin=0., p_rmax=18.e-6, p_nz=2, p_nr=2, p_nt=4, n_e=4.e24,
+                     n_order=-1, particle_shape='linear', boundaries={'z': 'open', 'r': 'reflective'})
+    add_laser_pulse(sim, GaussianLaser(a0=4., waist=5.e-6, tau=16.e-15, z0=15.e-6))
+    sim.set_moving_window(v=c)
+    assert sim.fld.Nz == int(g['Nz_local']) and sim.comm.n_guard == int(g['n_guard'])
+    assert sim.comm.nz_damp == int(g['nz_damp']) and sim.comm.n_inject == int(g['n_inject'])
+    s = sim.ptcl[0]
+    ref0 = g['s0_ptcl0']
+    assert s.Ntot == ref0.shape[1]
+    for j, k in enumerate(PTCL[:8]):
+        assert np.array_equal(np.asarray(getattr(s, k)), ref0[j]), k          # same lattice, bit for bit
+    for _ in range(int(g['nstep'])):
+        sim.step(1)                                # (as the capture: one call per step)
+    assert sim.fld.interp[0].zmin == float(g['s3_zmin'])                       # same window motion
+    rows = g['s3_rows']
+    ref_rows, ref_sum, ref_sum2, ref_max = g['s3_interp_rows'], g['s3_interp_sum'], g['s3_interp_sum2'], g['s3_interp_max']
+    for m in range(Nm):
+        for i, k in enumerate(INTERP):
+            grp = [j for j, kk in enumerate(INTERP) if kk[0] == k[0]]
+            scale = ref_max[:, grp].max()
+            if scale == 0:
+                continue
+            F = np.asarray(getattr(sim.fld.interp[m], k))
+            what = {'E': 'E', 'B': 'B', 'J': 'J', 'r': 'rho'}[k[0]]
+            achieved(None, np.abs(F[rows] - ref_rows[m, i]).max() / scale, 1e-11, 'rows ' + what)
+            ncell = F.size
+            achieved(None, abs(F.sum() - ref_sum[m, i]) / (scale * ncell), 1e-13, 'mean ' + what)
+            s2 = ref_sum2[:, grp].max()
+            achieved(None, abs((np.abs(F)**2).sum() - ref_sum2[m, i]) / s2, 1e-11, 'sum of squares ' + what)
+            achieved(None, abs(np.abs(F).max() - ref_max[m, i]) / scale, 1e-11, 'maximum ' + what)
+    ref = g['s3_ptcl0']
+    assert s.Ntot == ref.shape[1]
+    got = np.array([np.asarray(getattr(s, k)) for k in PTCL[:8]])
+    o1 = np.lexsort((ref[2], ref[1], ref[0], ref[7]))
+    o2 = np.lexsort((got[2], got[1], got[0], got[7]))
+    for j, k in enumerate(PTCL[:8]):
+        sc = np.abs(ref[j]).max()
+        if sc > 0:
+            achieved(None, np.abs(got[j][o2] - ref[j][o1]).max() / sc, 1e-11, 'particles')

@@ -59,6 +59,42 @@ def test_push_bit_exact(hip, oracle, n):
         assert np.array_equal(host(d[k]), g[gk][:n]), k   # bit-exact vs the reference itself
 
 
+def test_array_wrapper_family(hip, oracle):
+    """fb_malloc / fb_h2d / fb_d2h / fb_free / fb_last_error_string (the reference's
+    `cuda.to_device` / `copy_to_host`, utils/cuda.py:101-137): a position push on arrays that never were
+    PyTorch tensors, bit-exact against the oracle on the golden inputs (tests/golden/push.npz)."""
+    import ctypes
+    lib = hip.lib()
+    g = golden('push')
+    n = 4096
+    names = ('x', 'y', 'z', 'ux', 'uy', 'uz', 'inv_gamma')
+    h = {k: np.ascontiguousarray(g['in_' + k][:n]) for k in names}
+    d = {}
+    for k in names:
+        ptr = ctypes.c_void_p()
+        hip.check(lib.fb_malloc(8 * n, ctypes.byref(ptr)), 'fb_malloc')
+        assert ptr.value
+        hip.check(lib.fb_h2d(ptr, h[k].ctypes.data_as(ctypes.c_void_p), 8 * n, hip.stream()), 'fb_h2d')
+        d[k] = ptr
+    hip.check(lib.fb_push_x(n, d['x'], d['y'], d['z'], d['ux'], d['uy'], d['uz'], d['inv_gamma'], c,
+                            0.5 * float(g['dt']), 1., 1., 1., hip.stream()), 'fb_push_x')
+    out = {k: np.empty(n) for k in ('x', 'y', 'z')}
+    for k in out:
+        hip.check(lib.fb_d2h(out[k].ctypes.data_as(ctypes.c_void_p), d[k], 8 * n, hip.stream()), 'fb_d2h')
+    hip.check(lib.fb_sync(hip.stream()), 'fb_sync')
+    ref = {k: h[k].copy() for k in ('x', 'y', 'z')}
+    oracle.push_x(ref['x'], ref['y'], ref['z'], h['ux'], h['uy'], h['uz'], h['inv_gamma'], 0.5 * float(g['dt']), 1., 1., 1.)
+    for k in ('x', 'y', 'z'):
+        assert np.array_equal(out[k], ref[k]), k
+    for k in names:
+        hip.check(lib.fb_free(d[k]), 'fb_free')
+    # zero bytes and NULL are accepted; a failing call leaves its text in both error getters
+    z = ctypes.c_void_p(1)
+    assert lib.fb_malloc(0, ctypes.byref(z)) == 0 and not z.value and lib.fb_free(None) == 0
+    assert lib.fb_malloc(8, None) != 0
+    assert lib.fb_last_error_string() == lib.fb_last_error() and b'fb_malloc' in lib.fb_last_error_string()
+
+
 def test_shift_periodic(hip, oracle):
     rng = np.random.default_rng(5)
     z = rng.uniform(-3., 4., 10001)

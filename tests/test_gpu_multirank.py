@@ -37,7 +37,7 @@ def _global_particles(shape):
     return np.array([getattr(s, k) for k in helpers.PTCL])
 
 
-def _run(rank, world, port, shape, outdir, correct, fuse=True, tag=''):
+def _run(rank, world, port, shape, outdir, correct, fuse=True, tag='', n_guard=N_GUARD):
     import torch
     import torch.distributed as dist
     import helpers
@@ -47,7 +47,7 @@ def _run(rank, world, port, shape, outdir, correct, fuse=True, tag=''):
         dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank,
                                 world_size=world)
     zmax = NZ * DZ
-    sim = Simulation(NZ, zmax, NR, NR * DZ, NM, DZ / c, n_order=N_ORDER, n_guard=N_GUARD,
+    sim = Simulation(NZ, zmax, NR, NR * DZ, NM, DZ / c, n_order=N_ORDER, n_guard=n_guard,
                      particle_shape=shape)
     zlo, zhi = sim.comm.get_zmin_zmax(local=True, with_damp=False, with_guard=False, rank=rank)
     sel = (P[2] >= zlo) & (P[2] < zhi)
@@ -77,9 +77,9 @@ def _run(rank, world, port, shape, outdir, correct, fuse=True, tag=''):
         dist.destroy_process_group()
 
 
-def _worker(rank, world, port, shape, outdir, correct, q, fuse=True, tag=''):
+def _worker(rank, world, port, shape, outdir, correct, q, fuse=True, tag='', n_guard=N_GUARD):
     try:
-        _run(rank, world, port, shape, outdir, correct, fuse, tag)
+        _run(rank, world, port, shape, outdir, correct, fuse, tag, n_guard)
         q.put((rank, 'ok'))
     except Exception:  # pragma: no cover
         import traceback
@@ -263,7 +263,8 @@ def test_decomposed_correction_deferral_equals_separate_launches():
     for fuse, tag in ((True, '_fused'), (False, '_sep')):
         port = _free_port()
         q = ctx.Queue()
-        procs = [ctx.Process(target=_worker, args=(r, world, port, 'linear', outdir, True, q, fuse, tag))
+        # (n_guard = 64: 128 + 2 x 64 = 256 local rows, a length of the LDS z-FFT - the fused launch needs it)
+        procs = [ctx.Process(target=_worker, args=(r, world, port, 'linear', outdir, True, q, fuse, tag, 64))
                  for r in range(world)]
         for p in procs:
             p.start()
