@@ -18,6 +18,7 @@ host tensors -> the same movements as tensor operations (the second branch of `_
 `_recv_counts`, `_pack_rest`, `_compact`, `_append`), which exist for the gloo tests of the
 transport logic on CPU (tests/test_multirank_cpu.py) and nothing else.
 """
+from scipy.constants import c
 from .. import _capi
 
 _STATE = ('x', 'y', 'z', 'ux', 'uy', 'uz', 'inv_gamma', 'w')     # reference buffer order
@@ -38,6 +39,8 @@ def _resized(t, a, n_keep, n_new):
 
 
 HEADER = 8          # FB_HANDOVER_HEADER (include/fbpic_amd.h)
+# one-pass iterations since the sort up to which the hand-over scans home rows only (see the device path)
+HOME_SCAN_MAX_AGE = 8
 _CAP0 = 16384       # initial capacity (particles) of a hand-over message: 1 MiB; grows on demand
 
 
@@ -191,12 +194,24 @@ def exchange_particles_between_ranks(comm, species, fld, time):
     use_prefix = bool(dev.type == 'cuda' and getattr(species, 'sorted', False)
                       and getattr(species, '_prefix_valid', False)
                       and getattr(species, 'use_bin_sort', False) and n > 0)
+    # Round 6: after one-pass iterations the arrays are in HOME order (the order of the last sort, whose
+    # prefix sum still describes it: a one-pass iteration permutes nothing), not in cell order - the scan
+    # used to fall back to all of z there (150 us per hand-over at C2).  A particle moves less than one
+    # cell per step (c dt <= dz), so `since` iterations after the sort every leaver still sits in a home
+    # row within `since` + 1 rows of the rows compared for a fresh sort.
+    margin = 0
+    if (not use_prefix) and dev.type == 'cuda' and n > 0 and getattr(species, '_home_valid', False) \
+            and getattr(species, '_prefix_valid', False) and getattr(species, 'use_bin_sort', False) \
+            and getattr(species, '_cycle_since_sort', None) is not None \
+            and species._cycle_since_sort <= HOME_SCAN_MAX_AGE and comm.dz >= c * abs(getattr(species, 'dt', 0.)) * 0.999:
+        use_prefix = True
+        margin = int(species._cycle_since_sort) + 1
     cuts = (-1, -1, -1, -1)
     if use_prefix:
         Nz, Nr = fld.Nz, fld.Nr
         shift = getattr(species, 'prefix_sum_shift', 0)      # window moves since the sort
-        rows = [min(max(r, 0), Nz) for r in (ng + shift - 1, ng + shift + 2,
-                                              Nz - ng + shift - 1, Nz - ng + shift + 2)]
+        rows = [min(max(r, 0), Nz) for r in (ng + shift - 1 - margin, ng + shift + 2 + margin,
+                                              Nz - ng + shift - 1 - margin, Nz - ng + shift + 2 + margin)]
         cuts = tuple(r * (Nr + 1) - 1 for r in rows)      # -1 = offset 0
     _select_pack(t, n, species.z, species.prefix_sum if use_prefix else None, cuts, zbox_min, zbox_max,
                  arrs, L, R, st['idx'], st['counts'])

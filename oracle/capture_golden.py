@@ -650,20 +650,45 @@ def cap_uniform_rho():
     # The assertions are analytic (rho = -n e inside the plasma); no fixture needed.
 
 
-def c3_thin_rows(Nz_local, iz_slab):
-    """z rows of the local grid stored by the C3 fixture: 20 around the plasma slab, 28 spread over
-    the grid (guard and damping cells at both ends included)."""
+def c3_rows(Nz_local, iz_slab):
+    """z rows of the local grid stored by the C3 fixture: 20 around the left edge of the plasma, 28
+    spread over the grid (guard and damping cells at both ends included)."""
     near = np.arange(iz_slab - 10, iz_slab + 10)
     far = np.linspace(0, Nz_local - 1, 28).astype(int)
     return np.unique(np.clip(np.concatenate([near, far]), 0, Nz_local - 1))
 
 
-def cap_c3_thin():
+def c3_particle_sample(P, every=300):
+    """Order-independent reduction of the (8, N) particle arrays of the C3 fixture: every 300th particle
+    of the lexicographic order (w, x, y, z) - unperturbed lattice particles tie exactly in (w, x, y) and
+    differ in z by half a cell, perturbed ones by physical amounts - plus sum and sum of squares of every
+    attribute over ALL particles."""
+    o = np.lexsort((P[2], P[1], P[0], P[7]))
+    return P[:, o[::every]], P.sum(axis=1), (P**2).sum(axis=1)
+
+
+def c3_reduce(res, full, P, g0_zmin, dz, z_slab, Nz_local):
+    iz_slab = int(round((z_slab - g0_zmin) / dz))
+    rows = c3_rows(Nz_local, iz_slab)
+    res['sf_rows'] = rows
+    res['sf_interp_rows'] = full[:, :, rows, :]
+    res['sf_interp_sum'] = full.sum(axis=(2, 3))
+    res['sf_interp_sum2'] = (np.abs(full)**2).sum(axis=(2, 3))
+    res['sf_interp_max'] = np.abs(full).max(axis=(2, 3))
+    res['sf_zmin'] = g0_zmin
+    res['sf_ntot'] = P.shape[1]
+    res['sf_ptcl_sample'], res['sf_ptcl_sum'], res['sf_ptcl_sum2'] = c3_particle_sample(P)
+
+
+def cap_c3_full_grid():
     """BASELINE configs[2] on its OWN grid (4096 x 256, Nm = 2, open z, moving window at c, a0 = 4
-    Gaussian pulse: docs/source/example_input/lwfa_script.py) with a plasma slab of two cells inside
-    the pulse (2 x 2 x 4 macroparticles per cell, 7360 in all), 3 steps.  The interpreted reference
-    needs ~1 h for this; stored: every particle array of the final state, 48 z rows of every grid
-    (s3_rows) and, for the rows that are not stored, sum and sum of squares of every grid."""
+    Gaussian pulse: docs/source/example_input/lwfa_script.py).  The plasma is loaded as a slab of two
+    cells inside the pulse (7360 macroparticles, 2 x 2 x 4 per cell); the reference's continuous
+    injection then fills the window to the right of it at the first particle exchange (uniform
+    density: 5.95 M macroparticles), so the two steps run the laser through a window full of plasma.
+    The interpreted reference needs ~20 min for this; stored: 48 z rows of every grid (sf_rows), sum /
+    sum of squares / maximum of every grid over all cells, every 300th particle of the (w, x, y, z)
+    order and sum / sum of squares of every particle attribute."""
     import time
     from fbpic.main import Simulation
     from fbpic.lpa_utils.laser import add_laser_pulse, GaussianLaser
@@ -681,7 +706,7 @@ def cap_c3_thin():
     add_laser_pulse(sim, GaussianLaser(a0=4., waist=5.e-6, tau=16.e-15, z0=15.e-6))
     sim.set_moving_window(v=c)
     print('built', time.time() - t0, 'Ntot', sim.ptcl[0].Ntot, 'local Nz', sim.fld.Nz, flush=True)
-    nstep = 3
+    nstep = 2
     res = dict(Nz=Nz, Nr=Nr, Nm=Nm, zmin=zmin, zmax=zmax, rmax=rmax, dt=dt, z_slab=z_slab, nstep=nstep,
                Nz_local=sim.fld.Nz, n_guard=sim.comm.n_guard, n_inject=sim.comm.n_inject,
                nz_damp=sim.comm.nz_damp)
@@ -689,25 +714,18 @@ def cap_c3_thin():
     for it in range(nstep):
         t0 = time.time()
         sim.step(1, show_progress=False)
-        print('step', it, time.time() - t0, flush=True)
+        print('step', it, time.time() - t0, 'Ntot', sim.ptcl[0].Ntot, flush=True)
     g0 = sim.fld.interp[0]
-    iz_slab = int(round((z_slab - g0.zmin) / dz))
-    rows = c3_thin_rows(sim.fld.Nz, iz_slab)
     full = np.array([[getattr(sim.fld.interp[m], k) for k in INTERP] for m in range(Nm)])
-    res['s3_rows'] = rows
-    res['s3_interp_rows'] = full[:, :, rows, :]
-    res['s3_interp_sum'] = full.sum(axis=(2, 3))
-    res['s3_interp_sum2'] = (np.abs(full)**2).sum(axis=(2, 3))
-    res['s3_interp_max'] = np.abs(full).max(axis=(2, 3))
-    res['s3_zmin'] = g0.zmin
-    res['s3_ptcl0'] = np.array([getattr(sim.ptcl[0], k) for k in PTCL[:8]])
-    save('c3_thin_slab', **res)
+    P = np.array([getattr(sim.ptcl[0], k) for k in PTCL[:8]])
+    c3_reduce(res, full, P, g0.zmin, dz, z_slab, sim.fld.Nz)
+    save('c3_full_grid', **res)
 
 
 ALL = dict(push=cap_push, gather=cap_gather, deposit=cap_deposit, grid_setup=cap_grid_setup,
            spectral=cap_spectral, cycle=cap_cycle, bunch=cap_bunch, lwfa=cap_lwfa,
            galilean=cap_galilean, crossdep=cap_crossdep,
-           laser_profiles=cap_laser_profiles, c3_thin=cap_c3_thin)
+           laser_profiles=cap_laser_profiles, c3_full_grid=cap_c3_full_grid)
 
 if __name__ == '__main__':
     names = sys.argv[1:] or list(ALL)

@@ -9,8 +9,8 @@ charge conservation, round trips) and the one-pass / fused-spectral step to the 
       offsets, sort policy), the next sorting iteration, the fused spectral launch every time;
   C5  the full 2048 x 512 grid, Nm = 4, cubic, with 1 x 1 x 16 = 16 ppc (16.8 M macroparticles:
       what the oracle steps in ~15 s per iteration), 3 iterations;
-  C3  the 4096 x 256 moving-window laser-wakefield grid with a thin plasma slab (reference
-      fixture, see test_c3_full_grid_vs_reference_golden).
+  C3  the 4096 x 256 moving-window laser-wakefield grid with the window full of plasma (5.95 M
+      macroparticles; reference fixture, see test_c3_full_grid_vs_reference_golden).
 
 Bars: B and rho <= 1e-13 of the largest component of their group (the reference's own CPU <-> GPU bar
 for one deposition, /root/reference/tests/test_cpu_gpu_deposition.py:96), particles <= 1e-13 matched
@@ -147,17 +147,18 @@ def test_c5_full_grid_vs_oracle(oracle, correct, nstep, one_pass):
 def test_c3_full_grid_vs_reference_golden():
     """BASELINE configs[2] on its OWN grid - 4096 x 256, Nm = 2, open z with damping, moving window at c,
     a0 = 4 Gaussian pulse (docs/source/example_input/lwfa_script.py) - against the REAL reference
-    (tests/golden/c3_thin_slab.npz, oracle/capture_golden.py:cap_c3_thin: the interpreted reference needs
-    ~40 min for it): a plasma slab of two cells inside the pulse (7360 macroparticles, 2 x 2 x 4 per cell),
-    3 steps.  Compared: every particle array of the final state, 48 z rows of every grid (20 around the
-    slab, 28 over the whole local grid incl. guard and damping cells), and sum / sum of squares / maximum
-    of EVERY grid over all 4416 x 256 cells (what the stored rows do not see).  The small-grid trajectory
-    with injection and hand-overs is tests/test_gpu_lwfa.py."""
+    (tests/golden/c3_full_grid.npz, oracle/capture_golden.py:cap_c3_full_grid: the interpreted reference
+    needs ~20 min for it).  The plasma is loaded as two cells inside the pulse; the continuous injection of
+    the first particle exchange then fills the window to the right of it (5.95 M macroparticles, same
+    count here), and two steps run the pulse through it.  Compared: 48 z rows of every grid (20 around
+    the plasma edge, 28 over the whole local grid incl. guard and damping cells), sum / sum of squares /
+    maximum of EVERY grid over all 4416 x 256 cells, every 300th particle of the (w, x, y, z) order and
+    sum / sum of squares of every particle attribute over all particles."""
     from scipy.constants import c
     from conftest import golden
     from fbpic_amd.main import Simulation
     from fbpic_amd.lpa_utils.laser import add_laser_pulse, GaussianLaser
-    g = golden('c3_thin_slab')
+    g = golden('c3_full_grid')
     Nz, Nr, Nm = int(g['Nz']), int(g['Nr']), int(g['Nm'])
     assert (Nz, Nr, Nm) == (4096, 256, 2)
     zmin, zmax, rmax, dt, z_slab = (float(g[k]) for k in ('zmin', 'zmax', 'rmax', 'dt', 'z_slab'))
@@ -177,9 +178,10 @@ def test_c3_full_grid_vs_reference_golden():
         assert np.array_equal(np.asarray(getattr(s, k)), ref0[j]), k          # same lattice, bit for bit
     for _ in range(int(g['nstep'])):
         sim.step(1)                                # (as the capture: one call per step)
-    assert sim.fld.interp[0].zmin == float(g['s3_zmin'])                       # same window motion
-    rows = g['s3_rows']
-    ref_rows, ref_sum, ref_sum2, ref_max = g['s3_interp_rows'], g['s3_interp_sum'], g['s3_interp_sum2'], g['s3_interp_max']
+    assert sim.fld.interp[0].zmin == float(g['sf_zmin'])                       # same window motion
+    assert s.Ntot == int(g['sf_ntot'])                                         # same injection
+    rows = g['sf_rows']
+    ref_rows, ref_sum, ref_sum2, ref_max = g['sf_interp_rows'], g['sf_interp_sum'], g['sf_interp_sum2'], g['sf_interp_max']
     for m in range(Nm):
         for i, k in enumerate(INTERP):
             grp = [j for j, kk in enumerate(INTERP) if kk[0] == k[0]]
@@ -189,17 +191,20 @@ def test_c3_full_grid_vs_reference_golden():
             F = np.asarray(getattr(sim.fld.interp[m], k))
             what = {'E': 'E', 'B': 'B', 'J': 'J', 'r': 'rho'}[k[0]]
             achieved(None, np.abs(F[rows] - ref_rows[m, i]).max() / scale, 1e-11, 'rows ' + what)
-            ncell = F.size
-            achieved(None, abs(F.sum() - ref_sum[m, i]) / (scale * ncell), 1e-13, 'mean ' + what)
-            s2 = ref_sum2[:, grp].max()
-            achieved(None, abs((np.abs(F)**2).sum() - ref_sum2[m, i]) / s2, 1e-11, 'sum of squares ' + what)
+            achieved(None, abs(F.sum() - ref_sum[m, i]) / (scale * F.size), 1e-13, 'mean ' + what)
+            achieved(None, abs((np.abs(F)**2).sum() - ref_sum2[m, i]) / ref_sum2[:, grp].max(), 1e-11,
+                     'sum of squares ' + what)
             achieved(None, abs(np.abs(F).max() - ref_max[m, i]) / scale, 1e-11, 'maximum ' + what)
-    ref = g['s3_ptcl0']
-    assert s.Ntot == ref.shape[1]
     got = np.array([np.asarray(getattr(s, k)) for k in PTCL[:8]])
-    o1 = np.lexsort((ref[2], ref[1], ref[0], ref[7]))
-    o2 = np.lexsort((got[2], got[1], got[0], got[7]))
+    o = np.lexsort((got[2], got[1], got[0], got[7]))
+    sample = got[:, o[::300]]
+    ref = g['sf_ptcl_sample']
+    assert sample.shape == ref.shape
+    assert np.array_equal(sample[7], ref[7])                                   # the same macroparticles
     for j, k in enumerate(PTCL[:8]):
         sc = np.abs(ref[j]).max()
         if sc > 0:
-            achieved(None, np.abs(got[j][o2] - ref[j][o1]).max() / sc, 1e-11, 'particles')
+            achieved(None, np.abs(sample[j] - ref[j]).max() / sc, 1e-11, 'particle sample')
+        achieved(None, abs(got[j].sum() - g['sf_ptcl_sum'][j]) / max(np.abs(got[j]).sum(), 1e-300), 1e-11, 'particle sums')
+        achieved(None, abs((got[j]**2).sum() - g['sf_ptcl_sum2'][j]) / max(g['sf_ptcl_sum2'][j], 1e-300), 1e-11,
+                 'particle sums of squares')

@@ -100,7 +100,14 @@ def test_one_pass_equals_the_four_entry_points(hip, oracle, Nm, records, stale, 
     state = [hx, hy, hz] + [host(a).copy() for a in dst[3:]]          # x y z ux uy uz w ig
     # field grids: six per mode, views of one slab (what the 32-bit addressing needs; separately
     # allocated arrays may lie anywhere)
-    gslab = dev(hip, (rng.normal(size=(Nz, 6 * Nm, Nr)) + 1j * rng.normal(size=(Nz, 6 * Nm, Nr))) * 1e9)
+    hslab = (rng.normal(size=(Nz, 6 * Nm, Nr)) + 1j * rng.normal(size=(Nz, 6 * Nm, Nr))) * 1e9
+    if shape != 1:
+        # cubic: the sequence's gather sums on the matrix cores (Nm = 4) / in another loop order (Nm = 1), so
+        # E, B agree to the last bits only (4e-16, both against the oracle, below) - with |B| ~ 1e9 T the Vay
+        # push turns by 1e5 rad per step and amplifies that to 5e-8 in the momenta.  B ~ E / c here.
+        for mm in range(Nm):
+            hslab[:, 6 * mm + 3:6 * mm + 6, :] /= c
+    gslab = dev(hip, hslab)
     views = [gslab[:, j, :] for j in range(6 * Nm)]
     ruy0 = dev(hip, rng.uniform(-0.05, 0.05, Nr + 1))
     ruyh = dev(hip, rng.uniform(-0.05, 0.05, Nr + 1))
@@ -146,6 +153,18 @@ def test_one_pass_equals_the_four_entry_points(hip, oracle, Nm, records, stale, 
     hip.check(hip.lib().fb_deposit_rho(shape, Nm, n, p(b[0]), p(b[1]), p(b[2]), p(b[6]), q, *geom,
                                        hip.ptr_array(rv2), rv2[0].stride(0), rv2[0].stride(1), None,
                                        p(ruy0), p(ruyh), None, hip.stream()), 'deposit_rho')
+    # ---- the gathered E, B of both paths against the oracle's gather of the same (wrapped) positions
+    gx, gy, gz = state[0].copy(), state[1].copy(), state[2].copy()
+    oracle.shift_periodic(gz, zlo, zhi)
+    hgrids = [[host(views[6 * mm + k]).copy() for k in range(6)] for mm in range(Nm)]
+    Fo = [np.zeros(n) for _ in range(6)]
+    oracle.gather('linear' if shape == 1 else 'cubic', Nm == 2, gx, gy, gz, rmax_gather, *geom, hgrids, *Fo)
+    for lo, nm_ in ((0, 'E'), (3, 'B')):
+        scF = max(np.abs(f).max() for f in Fo[lo:lo + 3])
+        achieved(None, max(np.abs(host(u) - f).max() for u, f in zip(F[lo:lo + 3], Fo[lo:lo + 3])) / scF, 1e-13,
+                 nm_ + ' one pass vs oracle')
+        achieved(None, max(np.abs(host(u) - f).max() for u, f in zip(F2[lo:lo + 3], Fo[lo:lo + 3])) / scF, 1e-13,
+                 nm_ + ' sequence vs oracle')
     for k, (u, v) in enumerate(zip(a + F, b + F2)):
         if shape == 1:
             assert np.array_equal(host(u), host(v)), k
