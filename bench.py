@@ -34,10 +34,18 @@ import os
 import sys
 import time
 
-# The CPU baseline's OpenMP threads are bound to cores (SURVEY.md 8d recipe; docs/source/overview/
-# parallelisation.rst:47-53 of the reference): read by libgomp when it is first loaded, so set here.
-os.environ.setdefault('OMP_PROC_BIND', 'close')
-os.environ.setdefault('OMP_PLACES', 'cores')
+# The CPU baseline runs in a process of its own (`--cpu-baseline-only`, started by the default run): its
+# OpenMP threads are bound to cores (SURVEY.md 8d recipe; docs/source/overview/parallelisation.rst:47-53 of
+# the reference) - libgomp reads the two variables when it is first loaded (with `import torch`), and it
+# pins the INITIAL thread as well, so in the GPU process they would cut `available_cores()` to one core and
+# put NumPy's and scipy's thread pools on it (a first version of this did: `cores: 2`, transforms slower on
+# n threads than on one).
+_CPU_LEG = '--cpu-baseline-only' in sys.argv
+_AFFINITY_AT_START = os.sched_getaffinity(0)
+if _CPU_LEG:
+    os.environ.setdefault('OMP_PROC_BIND', 'close')
+    os.environ.setdefault('OMP_PLACES', 'cores')
+    os.environ.setdefault('OMP_WAIT_POLICY', 'passive')     # (the team sleeps through the NumPy phases)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -205,6 +213,8 @@ def parse():
     ap.add_argument('--shape', default='linear')
     ap.add_argument('--ppc', default='2,4,4')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-only', action='store_true',
+                    help='(internal) build the workload, time the CPU oracle on it, print its JSON object')
     ap.add_argument('--cpu-steps', type=int, default=10)   # ~10 s of CPU work on 16 cores
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-side-legs', action='store_true',
@@ -243,8 +253,27 @@ def config_name(args, ppc, world):
     return name
 
 
+def cpu_baseline_in_subprocess(args):
+    """The cpu_baseline object of the line, measured by `bench.py --cpu-baseline-only` in a process of its
+    own (bound OpenMP threads, no GPU runtime in it) on the same workload."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-only', '--Nz', str(args.Nz), '--Nr', str(args.Nr),
+           '--Nm', str(args.Nm), '--shape', args.shape, '--ppc', args.ppc, '--cpu-steps', str(args.cpu_steps)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        return json.loads(r.stdout.strip().split('\n')[-1])
+    except Exception as exc:            # the GPU line stands on its own
+        return {'error': repr(exc)[:300]}
+
+
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        import helpers
+        ppc = tuple(int(v) for v in args.ppc.split(','))
+        sm = helpers.uniform_plasma_sim(args.Nz, args.Nr, args.Nm, ppc, args.shape, seed=0, n_order=-1)
+        print(json.dumps(cpu_baseline(sm, args)))
+        return
     import numpy as np
     import torch
     import helpers
@@ -311,7 +340,7 @@ def main():
     sim, Nz_global, n_total = build(args.scaling)
     cpu_base = None
     if rank == 0 and not args.no_cpu_baseline and world == 1:
-        cpu_base = cpu_baseline(sim, args)
+        cpu_base = cpu_baseline_in_subprocess(args)
 
     # decomposed run: the warm-up also covers the first particle hand-over between the ranks
     # (every `exchange_period` steps; its first execution pays one-time start-up costs, ~3 ms)
@@ -759,10 +788,25 @@ def cpu_baseline(sim, args):
     (-O3 -march=native, oracle.build_native), the z-FFT on a thread pool as the reference plans
     FFTW with threads = nthreads (fourier.py:59-96), np.dot on the BLAS threads NumPy brings."""
     from oracle import oracle as orc
+    mask = _AFFINITY_AT_START
+    try:
+        os.sched_setaffinity(0, mask)      # (whatever an import has pinned the initial thread to)
+    except OSError:
+        pass
     native = orc.build_native()
     if native:
         orc.use_library(native)
     nthreads = min(orc.max_threads(), available_cores())
+    # libgomp pins the INITIAL thread too when it binds its team (first parallel region): every thread
+    # pool created later by that thread - NumPy's BLAS, scipy.fft's workers - would inherit a one-core
+    # mask and the transforms would run slower on n threads than on one (measured: 0.40 against 0.19 s
+    # per step).  Start the team now, then give the initial thread its mask back; the workers stay pinned.
+    orc.set_threads(nthreads)
+    orc.push_x(*[__import__('numpy').zeros(4096) for _ in range(7)], 0.)
+    try:
+        os.sched_setaffinity(0, mask)
+    except OSError:
+        pass
     orc.FFT_WORKERS = nthreads
     o = orc.from_sim(sim, nthreads=nthreads)
     o.step(1)                       # warm-up (thread pools, FFT plans)
@@ -790,7 +834,7 @@ def cpu_baseline(sim, args):
             'seconds': dt,
             'build': ('gcc -O3 -march=native -ffp-contract=off -fopenmp (built on this host)' if native
                       else 'checker build (oracle/Makefile flags): no compiler on this host'),
-            'omp': {k: os.environ.get(k) for k in ('OMP_PROC_BIND', 'OMP_PLACES')},
+            'omp': {k: os.environ.get(k) for k in ('OMP_PROC_BIND', 'OMP_PLACES', 'OMP_WAIT_POLICY')},
             'fft_threads': nthreads,
             'phase_seconds': phases, 'phase_seconds_single_thread_step': phases1,
             'note': 'phases: particle kernels = gather, push, deposit (thread-private grids), reduce (their '
