@@ -141,6 +141,7 @@ def bench_c3(args, torch, world, rank):
                      boundaries={'z': 'open', 'r': 'reflective'})
     add_laser_pulse(sim, GaussianLaser(a0=4., waist=5.e-6, tau=16.e-15, z0=15.e-6))
     sim.set_moving_window(v=c)
+    apply_policy(sim, args.policy)
     # the warm-up covers the first particle hand-over / injection (every `exchange_period` steps):
     # its buffers grow once (allocations), which is start-up cost, not the steady state
     warm = max(args.warmup, sim.comm.exchange_period + 2)
@@ -226,6 +227,9 @@ def parse():
                     help='BASELINE.json configuration: C2 = configs[1] (the one the metric is quoted '
                          'on), C5 = configs[4] (2048x512 Nm=4 cubic 64 ppc), C3 = configs[2] (laser-'
                          'wakefield 4096x256, moving window, window filled with plasma)')
+    ap.add_argument('--policy', default='',
+                    help='sort-policy attributes of every species, e.g. bad=2.0,stray=0.5,period=3,suspend=0 '
+                         '(cycle_bad_limit, cycle_stray_limit, cycle_sort_period, cycle_suspend_iterations)')
     ap.add_argument('--reference-sequence', action='store_true',
                     help="the reference's launch sequence: no fusion, rho_prev re-deposited every step")
     return ap.parse_args()
@@ -240,6 +244,15 @@ def set_reference_sequence(sm, on):
     sm.reference_sequence = bool(on)
     for sp in sm.ptcl:
         sp.fuse_sort_deposit_rho = not on
+
+
+def apply_policy(sm, spec):
+    names = {'bad': 'cycle_bad_limit', 'stray': 'cycle_stray_limit', 'period': 'cycle_sort_period',
+             'suspend': 'cycle_suspend_iterations'}
+    for item in filter(None, spec.split(',')):
+        k, v = item.split('=')
+        for sp in sm.ptcl:
+            setattr(sp, names[k], int(v) if k in ('period', 'suspend') else float(v))
 
 
 def config_name(args, ppc, world):
@@ -317,6 +330,7 @@ def main():
                                         n_order=n_order, n_guard=(None if world == 1 else 64))
         if args.reference_sequence:
             set_reference_sequence(sm, True)
+        apply_policy(sm, args.policy)
         if args.resort_fragmentation is not None:
             for sp in sm.ptcl:
                 sp.resort_fragmentation = args.resort_fragmentation

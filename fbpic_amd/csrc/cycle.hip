@@ -42,6 +42,7 @@ struct CycleArgs {
     double *ux, *uy, *uz, *ig;
     const double *w;
     int home_shift;                            // ... minus this: (cells the grid has moved since) x (Nr+1)
+    int regroup_at;                            // chunks with more J-strays than this are regrouped in the wave
     double *Ex, *Ey, *Ez, *Bx, *By, *Bz;       // optional: gathered fields stored
     double invdz, zmin;
     int Nz;
@@ -184,6 +185,11 @@ __device__ __forceinline__ void fb_wait_vm()
 // the normal chunk (every stray is a gather segment and a scatter of its own): counted for the host's
 // sort policy (a laser wake turns whole regions into such chunks, and their waves are the kernel's tail)
 #define FB_CYCLE_BAD_CHUNK 16
+// strays of the J deposition per 64 particles from which a chunk is regrouped inside the wave (see the
+// deposition part of the chunk loop)
+#ifndef FB_CYCLE_REGROUP_AT
+#define FB_CYCLE_REGROUP_AT 12
+#endif
 
 // Front half of a chunk: what can be done as soon as the positions are there - the keys of the
 // home runs, the stencil origin of every particle, which particles are strays, the segment of
@@ -346,6 +352,26 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
         // segment of this lane: its run, or - a stray - one of its own behind the runs
         f.myseg = g_home ? __popcll(g_runs & le) - 1 : ngruns + __popcll(straym & lt);
         f.rem_r = g_runs; f.rem_s = straym;
+#ifndef FB_CYCLE_NO_REGROUP
+        if (__popcll(straym) > A.regroup_at) {
+            // many strays: one segment per DISTINCT stencil among them (in a wake most of them have moved
+            // on to the same two or three neighbouring cells), not one per particle
+            unsigned long long rem = straym, leaders = 0ull;
+            int ns = 0, mine = 0;
+            while (rem) {
+                const int l = __builtin_ctzll(rem);
+                const int z_ = __builtin_amdgcn_readlane(kz, l), r_ = __builtin_amdgcn_readlane(kr, l);
+                const unsigned long long m_ = __ballot(inside && !g_home && kz == z_ && kr == r_);
+                if ((m_ >> lane) & 1ull) mine = ns;
+                leaders |= 1ull << l;
+                ns++;
+                rem &= ~m_;
+            }
+            f.nseg = ngruns + ns;
+            if (!g_home) f.myseg = ngruns + mine;
+            f.rem_s = leaders;
+        }
+#endif
 #ifndef FB_KNOCK_NODES            // (timing experiment: no node loads for the next chunk)
         if (ask) request(f, min(NSEG, f.nseg));
 #endif
@@ -636,6 +662,51 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
             nbad += (__popcll(smJ) > FB_CYCLE_BAD_CHUNK) ? 1u : 0u;
             wave_lds_release();
         FB_MARK("M_SCATTER");
+#ifndef FB_CYCLE_NO_REGROUP
+            // A chunk full of particles that have left their home cells (a laser wake moves a quarter of the
+            // electrons to the next cell within a step): one scatter per stray costs several times the run
+            // reduction.  Such a chunk is REGROUPED inside the wave: its staged columns are sorted by the cell
+            // of the J deposition (ranks from one ballot per distinct cell), the runs of the reduction are
+            // those of the sorted order - every particle takes part in one - and only the particles whose rho
+            // cell differs from their J cell (those that cross a boundary in the second half push) remain
+            // strays, of the rho engine alone.  The particle arrays themselves keep their order.
+            if (__popcll(smJ) > A.regroup_at) {
+                const unsigned long long actm = __ballot(act);
+                int pos = cnt + __popcll(~actm & lt);                 // lanes without a particle: behind
+                {
+                    unsigned long long rem = actm;
+                    int nbefore = 0;
+                    while (rem) {
+                        const int l = __builtin_ctzll(rem);
+                        const int z_ = __builtin_amdgcn_readlane(dkz, l), r_ = __builtin_amdgcn_readlane(dkr, l);
+                        const int n_ = __builtin_amdgcn_readlane(dnb, l);
+                        const unsigned long long m_ = __ballot(act && dkz == z_ && dkr == r_ && dnb == n_);
+                        if ((m_ >> lane) & 1ull) pos = nbefore + __popcll(m_ & lt);
+                        nbefore += __popcll(m_);
+                        rem &= ~m_;
+                    }
+                }
+                ed.permute_columns(pos);
+                // the keys at the sorted positions (lane i sends to lane pos(i))
+                const int jz = __builtin_amdgcn_ds_permute(4 * pos, dkz), jr = __builtin_amdgcn_ds_permute(4 * pos, dkr);
+                const int jn = __builtin_amdgcn_ds_permute(4 * pos, dnb);
+                const int rz = __builtin_amdgcn_ds_permute(4 * pos, rkz), rr = __builtin_amdgcn_ds_permute(4 * pos, rkr);
+                const int rn = __builtin_amdgcn_ds_permute(4 * pos, rnb);
+                const bool in = lane < cnt;
+                const int pz = __shfl_up(jz, 1), pr = __shfl_up(jr, 1), pn = __shfl_up(jn, 1);
+                const unsigned long long starts = __ballot(in && (lane == 0 || jz != pz || jr != pr || jn != pn));
+                const bool sameR = in && rz == jz && rr == jr && rn == jn;
+                const unsigned long long strayR = __ballot(in && !sameR);
+                wave_lds_release();
+                if (strayR) {
+                    ed.scatter_strays(0ull, strayR, jz, jr, jn, rz, rr, rn);
+                    ed.zero_amplitudes(false, !sameR);
+                    wave_lds_release();
+                }
+                ed.reduce(cnt, starts, cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull), jz, jr, jn);
+                wave_lds_acquire();
+            } else
+#endif
             if (smJ | smR) {
                 // strays first (they read their staged amplitudes), then their amplitudes are zeroed:
                 // the products below need no per-particle mask
@@ -644,8 +715,13 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
                 wave_lds_release();
             }
         FB_MARK("M_REDUCE");
-            ed.reduce(cnt, runstarts, hmJ | hmR, hkz, hkr, hnb);
-            wave_lds_acquire();
+#ifndef FB_CYCLE_NO_REGROUP
+            if (!(__popcll(smJ) > A.regroup_at))
+#endif
+            {
+                ed.reduce(cnt, runstarts, hmJ | hmR, hkz, hkr, hnb);
+                wave_lds_acquire();
+            }
         }
         FB_MARK("M_END");
         if (!more) break;
@@ -774,6 +850,11 @@ static int cycle_entry(const char *who, bool rank, int shape, int Nm, long n,
     A.x = x; A.y = y; A.z = z; A.ux = ux; A.uy = uy; A.uz = uz; A.ig = inv_gamma; A.w = w;
     A.home = home_cell;
     A.home_shift = home_cell_shift;
+    {
+        // (FBPIC_AMD_CYCLE_REGROUP: developer override of the threshold; 64 = never)
+        static const int env_at = getenv("FBPIC_AMD_CYCLE_REGROUP") ? atoi(getenv("FBPIC_AMD_CYCLE_REGROUP")) : -1;
+        A.regroup_at = env_at >= 0 ? env_at : FB_CYCLE_REGROUP_AT;
+    }
     A.Ex = Ex; A.Ey = Ey; A.Ez = Ez; A.Bx = Bx; A.By = By; A.Bz = Bz;
     A.invdz = invdz; A.zmin = zmin; A.Nz = Nz; A.invdr = invdr; A.rmin = rmin; A.Nr = Nr;
     A.inv_ncol = 1. / (double)(Nr + 1);

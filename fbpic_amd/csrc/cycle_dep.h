@@ -249,6 +249,23 @@ struct CycleDep {
         if (notR) Pd[L::ROW_AR * PAD + lane] = 0.;
     }
 
+    // ---- move the staged column of particle `lane` to column `pos` (a permutation of 0 .. 63), every row but
+    // the row of ones: the chunk's particles re-ordered inside the panel (cycle.hip, regrouped chunks).  LDS
+    // operations of a wave execute in issue order, so the reads of a batch return the old columns before its
+    // writes land.
+    __device__ __forceinline__ void permute_columns(int pos)
+    {
+        double *Pd = (double *)P;
+#pragma unroll
+        for (int r0 = 1; r0 < L::NROWS; r0 += 4) {
+            double v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (r0 + k < L::NROWS) v[k] = Pd[(r0 + k) * PAD + lane];
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (r0 + k < L::NROWS) Pd[(r0 + k) * PAD + pos] = v[k];
+        }
+    }
+
     // ---- flush of the current cell: one atomic instruction per tile.  keep_upper: only its lower
     // node column (the upper one carries on as the lower column of the next cell)
     __device__ __forceinline__ void flush(bool keep_upper)

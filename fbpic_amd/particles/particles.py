@@ -137,15 +137,23 @@ class Particles(object):
         self._home_valid = False
         self.record_home_in_sort_pass = False     # set by Simulation.step for its sorting iterations
         self.cycle_sort_period = int(os.environ.get('FBPIC_AMD_SORT_PERIOD', '3'))
-        self.cycle_stray_limit = float(os.environ.get('FBPIC_AMD_STRAY_LIMIT', '0.12'))
-        # ... or when more than `cycle_bad_limit` of the 64-particle chunks hold > 16 such particles (a
-        # laser wake: the strays are not spread out but fill whole regions, whose waves then are the
-        # tail of the launch - C3: 1.9 ms per pass against 1.5 for the two passes of a sorting
-        # iteration).  If already the FIRST pass after a sort reports that, the one-pass form does not
-        # fit the plasma as it is now: the next `cycle_suspend_iterations` iterations are two-pass
-        # (sorting) ones, then one pass probes again.
-        self.cycle_bad_limit = 0.01
+        # (round 6: 0.5 instead of 0.12 - the kernel regroups a chunk with more than 12 strays inside the
+        # wave, csrc/cycle.hip, so a quarter of the particles changing cell per step, as in a laser wake, no
+        # longer makes the pass slower than the two passes of a sorting iteration: C3 0.88 against 0.39 + 0.72
+        # ms; the period governs thermal plasmas either way)
+        self.cycle_stray_limit = float(os.environ.get('FBPIC_AMD_STRAY_LIMIT', '0.5'))
+        # ... or when more than `cycle_bad_limit` of the 64-particle chunks hold > 16 such particles.  If
+        # already the FIRST pass after a sort reports that, the next `cycle_suspend_iterations` iterations
+        # are two-pass (sorting) ones, then one pass probes again.  Round 5 needed this rule (a wake
+        # filled whole regions with strays, every one a gather segment and a scatter of its own: C3 1.3 -
+        # 1.9 ms per pass); with the regrouped chunks of round 6 it is OFF by default (limit 2.0) and
+        # kept for plasmas whose strays scatter over many cells.
+        self.cycle_bad_limit = 2.0
         self.cycle_suspend_iterations = 16
+        # The sorting second pass (fb_push_x_sort_deposit_J_rho) runs its two depositions one after the
+        # other instead of merged when more than this share of the chunks is full of cell changers (C3:
+        # 0.70 against 0.77 - 0.90 ms)
+        self.cycle_two_engine_limit = 0.01
         self._cycle_suspended = 0
         self.cycle_bad_fraction = None
         self._cycle_since_sort = 0
@@ -808,7 +816,7 @@ class Particles(object):
                 views[0].stride(0), views[0].stride(1), p(ruy0), p(ruyh),
                 # (a plasma that has just turned the one-pass form off - whole chunks of particles that
                 # change cell every step - also wants the two depositions of this pass one after the other)
-                1 if (self._cycle_suspended > 0 or (self.cycle_bad_fraction or 0.) > self.cycle_bad_limit) else 0,
+                1 if (self._cycle_suspended > 0 or (self.cycle_bad_fraction or 0.) > self.cycle_two_engine_limit) else 0,
                 st)
             _capi.check(rc, 'fb_push_x_sort_deposit_J_rho')
         else:
