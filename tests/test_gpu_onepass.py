@@ -375,3 +375,22 @@ def test_gather_push_rank_next_home_equals_gather_push_rank_next(hip, oracle, Nm
     o2 = np.lexsort((ob[2], ob[1], ob[0], cib))
     for u, v in zip(oa, ob):
         assert np.array_equal(u[o1], v[o2])
+
+
+def test_every_chunk_regrouped_in_a_process_of_its_own():
+    """The in-wave regrouping of chunks full of strays (cycle.hip, threshold FB_CYCLE_REGROUP_AT = 12 J-strays per 64
+    particles) with the threshold forced to 0 - every chunk with a single stray takes the path, in the kernel
+    tests above and in the moving-window laser-wakefield trajectory against the reference.  The threshold is a
+    developer override read once per process (FBPIC_AMD_CYCLE_REGROUP), hence the subprocess."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FBPIC_AMD_CYCLE_REGROUP='0')
+    cmd = [sys.executable, '-m', 'pytest', '-q', '-x', '-p', 'no:cacheprovider',
+           os.path.join(root, 'tests', 'test_gpu_onepass.py'), os.path.join(root, 'tests', 'test_gpu_lwfa.py'),
+           '-k', '(test_one_pass_equals_the_four_entry_points and 100003-1) or test_step_one_pass_equals_two_pass '
+                 'or test_lwfa_moving_window_vs_reference']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert ' passed' in r.stdout and 'failed' not in r.stdout
