@@ -389,7 +389,10 @@ int fb_push_x_sort_deposit_J_rho(long n, int ncell, const double *x, const doubl
  * `home_cell_shift` is subtracted from every home cell before use: n_move (Nr + 1) when the grid
  * has advanced by n_move cells since the sort (moving window, boundaries/moving_window.py:60-239 -
  * the cell of a particle that stays where it is moves n_move rows down), 0 otherwise.
- * Linear shape, Nm <= 4 (fb_gather_push_deposit_supported). */
+ * A chunk of 64 particles of which more than 12 have left their home cells (a laser wake) is regrouped inside
+ * the wave - runs of its particles' CURRENT cells instead of one scatter per particle; same result.
+ * Linear or cubic shape (round 6: cubic = the same pass with the 4 x 4 stencil, slower than the two passes
+ * at 2048 x 512, Nm = 4 - the caller decides), Nm <= 4 (fb_gather_push_deposit_supported). */
 int fb_gather_push_deposit_supported(int shape, int Nm);
 int fb_gather_push_deposit_J_rho(int shape, int Nm, long n,
                                  double *x, double *y, double *z, double *ux, double *uy,
