@@ -101,4 +101,5 @@ def test_bench_roofline_object_is_stable_between_tied_kernels():
     roof, _ = bench.roofline({'fb_gather_push': [(0.127, a)] * 3})
     # 112 B per particle when E, B stay in registers (a[19] is None)
     assert abs(roof['achieved'] - 112 * 4194304 / 0.127e-3 / 1e9) < 1e-6
-    assert roof['traffic'] is None or roof['traffic'] > 4e8
+    # (the newest PMC pass may hold the plain gather of the reference-sequence leg: 72 B per particle = 3.0e8)
+    assert roof['traffic'] is None or roof['traffic'] > 2.5e8

@@ -7,7 +7,7 @@ PASSES="stats fetch write mfma mfmautil"
 if [ "$1" = "--traffic-only" ]; then PASSES="stats fetch write"; shift; fi
 mkdir -p gpurun_out/$TAG
 cd /tmp && export TMPDIR=/tmp
-CMD="python /root/repo/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing $@"
+CMD="python /root/repo/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-side-legs $@"
 for d in $PASSES; do
   case $d in
     stats) OPT="--kernel-trace --stats";;
