@@ -248,11 +248,11 @@ def set_reference_sequence(sm, on):
 
 def apply_policy(sm, spec):
     names = {'bad': 'cycle_bad_limit', 'stray': 'cycle_stray_limit', 'period': 'cycle_sort_period',
-             'suspend': 'cycle_suspend_iterations'}
+             'suspend': 'cycle_suspend_iterations', 'homesort': 'record_home_in_rho_sort'}
     for item in filter(None, spec.split(',')):
         k, v = item.split('=')
         for sp in sm.ptcl:
-            setattr(sp, names[k], int(v) if k in ('period', 'suspend') else float(v))
+            setattr(sp, names[k], int(v) if k in ('period', 'suspend', 'homesort') else float(v))
 
 
 def config_name(args, ppc, world):
@@ -426,7 +426,9 @@ def main():
             sim.carry_state_between_calls = True
     dt_wall = max_over_ranks(dt_wall)
     passes = {'one_pass': sum(s_.cycle_passes for s_ in sim.ptcl),
-              'sorting_two_pass': sum(s_.cycle_sorts for s_ in sim.ptcl),
+              # sorts that record home cells: the sorting (two-pass) iterations + the sort in front of a call's
+              # / hand-over's rho_prev deposition
+              'sorts': sum(s_.cycle_sorts for s_ in sim.ptcl),
               'sort_period': sim.ptcl[0].cycle_sort_period if sim.ptcl else None,
               'last_stray_fraction': max((s_.cycle_last_stray_fraction or 0.) for s_ in sim.ptcl)
               if sim.ptcl else None}

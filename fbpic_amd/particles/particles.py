@@ -136,6 +136,7 @@ class Particles(object):
         self._ext_gen = 0
         self._home_valid = False
         self.record_home_in_sort_pass = False     # set by Simulation.step for its sorting iterations
+        self.record_home_in_rho_sort = True       # ... and the sort in front of a rho_prev deposition records them too
         self.cycle_sort_period = int(os.environ.get('FBPIC_AMD_SORT_PERIOD', '3'))
         # (round 6: 0.5 instead of 0.12 - the kernel regroups a chunk with more than 12 strays inside the
         # wave, csrc/cycle.hip, so a quarter of the particles changing cell per step, as in a laser wake, no
@@ -928,10 +929,16 @@ class Particles(object):
         if fieldtype == 'rho':
             self.flush_pending_J()
         if not self.sorted and self._needs_sort():
-            self.sort_particles(fld=fld)
+            # (inside step() the sort also records the home cells of the one-pass cycle: the rho_prev
+            # deposition that follows a particle hand-over then leaves a FRESH order behind, and the
+            # iteration runs one pass instead of a second, sorting pair - C3: 0.86 against 1.13 ms)
+            home = bool(self._in_step and self.use_bin_sort and fieldtype == 'rho' and self.record_home_in_rho_sort)
+            self.sort_particles(fld=fld, record_home=home)
             self.sorted = True
             self._deposits_since_sort = 0
             self._runs_latest = None
+            if home and self._home_valid:
+                self._after_home_sort()
         self.flush_pending_push()
         grid = fld.interp
         Nm = len(grid)

@@ -272,13 +272,17 @@ def test_step_one_pass_equals_two_pass_and_oracle(hip, oracle, Nm, period, limit
         s = sim.ptcl[0]
         assert (s.cycle_passes > 0) == one
         if one:
-            # every call starts with a sorting (two-pass) iteration: the arrays come from the host;
-            # `period` one-pass iterations follow each of them
+            # every call starts with the sort in front of its rho_prev deposition (the arrays come from the
+            # host), which records the home cells (round 6): `period` one-pass iterations follow it, then a
+            # sorting two-pass iteration, and so on - cycle_sorts counts both kinds of sort.  4 + 3 steps:
+            #   period 3: sort, 3 passes, sorting iteration | sort, 3 passes          -> 3 sorts, 6 passes
+            #   period 1: sort, pass, sorting, pass, sorting | sort, pass, sorting, pass -> 5 sorts, 4 passes
+            #   period 50: sort, 4 passes | sort, 3 passes                               -> 2 sorts, 7 passes
             if limit is None:
-                assert (s.cycle_sorts, s.cycle_passes) == {3: (2, 5), 1: (4, 3), 50: (2, 5)}[period]
+                assert (s.cycle_sorts, s.cycle_passes) == {3: (3, 6), 1: (5, 4), 50: (2, 7)}[period]
             else:
                 # u_th = 0.1: more than 5 % of the particles leave their cell within a step or two
-                assert s.cycle_sorts > 2 and s.cycle_sorts + s.cycle_passes == 7
+                assert s.cycle_sorts > 2 and s.cycle_passes >= 3
                 assert s.cycle_last_stray_fraction is not None
         res.append(sim)
     ref.step(7)
