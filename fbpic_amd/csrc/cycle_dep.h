@@ -393,6 +393,48 @@ struct CycleDep {
         }
     }
 
+    // ---- a chunk regrouped by (J cell, rho cell) PAIRS (cycle.hip): every run of the sorted order holds
+    // particles with one J stencil and one rho stencil - which may differ (a particle that crosses a cell
+    // boundary within the second half push) -, so every particle takes part in a run of BOTH engines and
+    // nothing is scattered one by one.  Each run is flushed on its own (no sliding columns: the two
+    // engines' cells need not move together), the J tiles to the J cell, the rho tiles to the rho cell;
+    // guard folding and axis signs per lane as in flush().
+    __device__ __forceinline__ void flush_pair(int zJ, int rJ, int nJ, int zR, int rR, int nR)
+    {
+        const int cz = engR ? zR : zJ, cr = engR ? rR : rJ, nb = engR ? nR : nJ;
+#pragma unroll
+        for (int t = 0; t < NTL; t++) {
+            double v = acc[t];
+            if (!((valid >> t) & 1u) || v == 0.) continue;
+            int gz = cz + jzD, gr = cr + jrD;
+            fold_node(gz, gr, Nz, Nr);
+            if (jrD < nb && ((neg >> t) & 1u)) v = -v;
+            const unsigned voff = f_off[t] + (unsigned)((gz - jzD) * rsB + gr * csB);
+            atomicAdd((double *)(gbase + voff), v);
+        }
+    }
+    __device__ __forceinline__ void reduce_pairs(int cnt, unsigned long long starts, int jz, int jr, int jn,
+                                                 int rz, int rr, int rn)
+    {
+        flush(false);                        // the run that was open when the chunk began
+        cur_z = DEP_NOKEY; cur_r = DEP_NOKEY; cur_nb = 0;
+        int p = 0;
+        while (p < cnt) {
+            const unsigned long long rest = (p + 1 < 64) ? (starts >> (p + 1)) : 0ull;
+            int e = rest ? p + 1 + __builtin_ctzll(rest) : cnt;
+            if (e > cnt) e = cnt;
+#pragma unroll
+            for (int t = 0; t < NTL; t++) acc[t] = 0.;
+            product(p, e);
+            flush_pair(__builtin_amdgcn_readlane(jz, p), __builtin_amdgcn_readlane(jr, p),
+                       __builtin_amdgcn_readlane(jn, p), __builtin_amdgcn_readlane(rz, p),
+                       __builtin_amdgcn_readlane(rr, p), __builtin_amdgcn_readlane(rn, p));
+            p = e;
+        }
+#pragma unroll
+        for (int t = 0; t < NTL; t++) acc[t] = 0.;
+    }
+
     // ---- a chunk in which the stencils of the two engines differ for MANY particles (a laser wake:
     // fast particles change cell within the half push between the two depositions): two traversals,
     // each engine on the runs of ITS OWN keys, the other engine's mode-0 amplitudes zero meanwhile -

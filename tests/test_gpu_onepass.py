@@ -390,11 +390,13 @@ def test_every_chunk_regrouped_in_a_process_of_its_own():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, FBPIC_AMD_CYCLE_REGROUP='0')
     cmd = [sys.executable, '-m', 'pytest', '-q', '-x', '-p', 'no:cacheprovider',
            os.path.join(root, 'tests', 'test_gpu_onepass.py'), os.path.join(root, 'tests', 'test_gpu_lwfa.py'),
            '-k', '(test_one_pass_equals_the_four_entry_points and 100003-1) or test_step_one_pass_equals_two_pass '
                  'or test_lwfa_moving_window_vs_reference']
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
-    assert ' passed' in r.stdout and 'failed' not in r.stdout
+    # both forms of the regrouping: by (J cell, rho cell) pairs (the default) and by the J cell alone
+    for pairs in ('1', '0'):
+        env = dict(os.environ, FBPIC_AMD_CYCLE_REGROUP='0', FBPIC_AMD_CYCLE_PAIRS=pairs)
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, 'pairs = %s\n' % pairs + r.stdout[-3000:] + r.stderr[-1000:]
+        assert ' passed' in r.stdout and 'failed' not in r.stdout
