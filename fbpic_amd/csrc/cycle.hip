@@ -777,7 +777,10 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
 }
 
 template <int NM, bool WIDE, bool RANK>
-__global__ __launch_bounds__(256) void k_cycle_linear(CycleArgs A) { cycle_linear_body<FB_SHAPE_LINEAR, NM, WIDE, RANK>(A); }
+#ifndef FB_CYCLE_ATTR
+#define FB_CYCLE_ATTR
+#endif
+__global__ __launch_bounds__(256) FB_CYCLE_ATTR void k_cycle_linear(CycleArgs A) { cycle_linear_body<FB_SHAPE_LINEAR, NM, WIDE, RANK>(A); }
 // cubic shape (round 6): the same pass with the 4 x 4 stencil - lane-by-lane stencil sums from the staged
 // node values, the two cubic DepEngines on the home runs
 template <int NM, bool WIDE>

@@ -20,6 +20,7 @@
 // Fragment layouts (cdna_hip_programming.md section 3, f64 row formula):
 //   A: lane l -> A[i = l & 15][k = l >> 4]      B: lane l -> B[k = l >> 4][j = l & 15]
 //   D: reg r of lane l -> D[i = (l >> 4) + 4 r][j = l & 15]
+#include <cstdlib>
 #include "fb_common.h"
 
 namespace fb {
@@ -91,7 +92,7 @@ template <int WC, int WN, int WZ> struct H2Cfg {
     static constexpr size_t LDS_BYTES = (size_t)2 * (ABUF + BBUF) * 8;
 };
 
-template <bool SCALED, bool PAIRED, bool DUAL, int WC, int WN, int WZ, int WPE>
+template <bool SCALED, bool PAIRED, bool DUAL, int WC, int WN, int WZ, int WPE, bool FULL>
 __global__ __launch_bounds__(64 * WZ * WN) __attribute__((amdgpu_waves_per_eu(WPE, 4))) void k_hankel(HankelJobs J, HankelScales Sc, HankelPairs Pr,
                                                          long irs, long ors, double alpha, int Nz, int Nr)
 {
@@ -135,8 +136,47 @@ __global__ __launch_bounds__(64 * WZ * WN) __attribute__((amdgpu_waves_per_eu(WP
     // single resident workgroup per CU keeps two chunks of global traffic in flight
     double2 ra0[NA], ra1[NA];
     double2 rb0[NB], rb1[NB];
+    // FULL: the partner (PAIRED) and the column scale (SCALED) of a stage, combined when the stage goes to LDS
+    double2 rw0[(FULL && PAIRED) ? NA : 1], rw1[(FULL && PAIRED) ? NA : 1];
+    double rs0[(FULL && SCALED) ? NA : 1], rs1[(FULL && SCALED) ? NA : 1];
     const int nchunks = (Nr + H2_KC - 1) / H2_KC;
-    auto gload = [&](int c, double2 *ra, double2 *rb) {
+    const int ntot = (DUAL && in2) ? 2 * nchunks : nchunks;
+    // FULL (Nr a multiple of two K chunks and of the tile width, every SCALED job with its column scale): the
+    // loads of a chunk are STRAIGHT-LINE code - rows beyond Nz and chunks beyond the last one read a clamped
+    // address (their sums are never stored / they are never written to LDS) -, so the compiler knows how many
+    // loads are in flight at every point and the wait in front of the LDS writes of chunk c + 1 is
+    // s_waitcnt vmcnt(loads of the younger chunk).  With a branch around a load (the general path
+    // below) that wait is vmcnt(0): it also waits for the chunk requested a moment ago, and the register
+    // stages hide nothing (round 6: MFMA pipe 59 % busy at 4416 x 256 whatever the workgroup shape).
+    const cplx *__restrict__ pin2 = (PAIRED && in2) ? in2 : in;
+    const double phalf = (PAIRED && in2) ? 0.5 : 1.0, psg = (PAIRED && in2) ? psgn : 0.;
+    auto gload = [&](int c, double2 *ra, double2 *rb, double2 *rw, double *rs) {
+        if constexpr (FULL) {
+            const int cl = min(c, ntot - 1);
+            const bool second = DUAL && cl >= nchunks;
+            const int k0 = (second ? cl - nchunks : cl) * H2_KC;
+            const cplx *__restrict__ src = second ? in2 : in;
+            const double *__restrict__ mm = second ? mat2 : mat;
+#pragma unroll
+            for (int j = 0; j < NA; j++) {
+                const int idx = j * NTHR + tid;
+                const int row = idx >> 4, kk = idx & 15;
+                const long o = (long)min(zb + row, Nz - 1) * irs + (k0 + kk);
+                // (raw values: the combination below needs them, i.e. would wait for them here)
+                ra[j] = *(const double2 *)(src + o);
+                if (PAIRED) rw[j] = *(const double2 *)(pin2 + o);
+                if (SCALED) rs[j] = sk[k0 + kk];
+            }
+#pragma unroll
+            for (int j = 0; j < NB; j++) {
+                const int idx = j * NTHR + tid;
+                const int kr = idx / (TN / 2), nn = 2 * (idx % (TN / 2));
+                const double *mrow = mm + (long)min(k0 + kr, Nr - 1) * Nr + (n0 + nn);
+                const double2 v = *(const double2 *)mrow;
+                rb[j] = v;
+            }
+            return;
+        }
         const bool second = DUAL && c >= nchunks;
         const int k0 = (second ? c - nchunks : c) * H2_KC;
         const cplx *__restrict__ src = second ? in2 : in;
@@ -173,14 +213,24 @@ __global__ __launch_bounds__(64 * WZ * WN) __attribute__((amdgpu_waves_per_eu(WP
             rb[j] = v;
         }
     };
-    auto lstore = [&](int buf, const double2 *ra, const double2 *rb) {
+    auto lstore = [&](int buf, const double2 *ra, const double2 *rb, const double2 *rw, const double *rs) {
         double *A = hk_lds + buf * (C::ABUF + C::BBUF);
         double *B = A + C::ABUF;
 #pragma unroll
         for (int j = 0; j < NA; j++) {
             const int idx = j * NTHR + tid;
+            double2 v = ra[j];
+            if constexpr (FULL) {
+                if (PAIRED) {
+                    // numba_rt_to_pm: p = 0.5 (r - i t), m = 0.5 (r + i t); a job without a partner: 1.0 (v - 0 w)
+                    const double2 w_ = rw[j];
+                    v.x = phalf * (v.x - psg * w_.y);
+                    v.y = phalf * (v.y + psg * w_.x);
+                }
+                if (SCALED) { const double s_ = rs[j]; v.x *= s_; v.y *= s_; }
+            }
             if (NAE % NTHR == 0 || idx < NAE)
-                *(double2 *)(A + (idx >> 4) * H2_RSA + 2 * (idx & 15)) = ra[j];
+                *(double2 *)(A + (idx >> 4) * H2_RSA + 2 * (idx & 15)) = v;
         }
 #pragma unroll
         for (int j = 0; j < NB; j++) {
@@ -189,8 +239,7 @@ __global__ __launch_bounds__(64 * WZ * WN) __attribute__((amdgpu_waves_per_eu(WP
                 *(double2 *)(B + (idx / (TN / 2)) * H2_RSB + 2 * (idx % (TN / 2))) = rb[j];
         }
     };
-    const int ntot = (DUAL && in2) ? 2 * nchunks : nchunks;
-    auto compute = [&](int c) {
+        auto compute = [&](int c) {
         const int cur = c & 1;
         const double *A = hk_lds + cur * (C::ABUF + C::BBUF) + (wrow * 16 + li) * H2_RSA;
         const double *B = hk_lds + cur * (C::ABUF + C::BBUF) + C::ABUF + wcol + li;
@@ -212,20 +261,46 @@ __global__ __launch_bounds__(64 * WZ * WN) __attribute__((amdgpu_waves_per_eu(WP
         if (DUAL && c >= nchunks) mma_chunk(acc2_re, acc2_im);
         else mma_chunk(acc_re, acc_im);
     };
-    gload(0, ra0, rb0);
-    lstore(0, ra0, rb0);
-    if (ntot > 1) gload(1, ra1, rb1);
-    __syncthreads();
-    for (int c = 0; c < ntot; c += 2) {
-        if (c + 2 < ntot) gload(c + 2, ra0, rb0);
-        compute(c);
-        if (c + 1 < ntot) lstore(1, ra1, rb1);
+    // Two register stages: chunk c + 2 is requested in front of the MFMAs of chunk c; chunk c + 1 - requested one
+    // chunk of MFMA work earlier - goes to the other LDS buffer behind them; one barrier per chunk.
+    gload(0, ra0, rb0, rw0, rs0);
+    lstore(0, ra0, rb0, rw0, rs0);
+    if constexpr (FULL) {
+        // an even number of chunks, no branch in the loop: the requests beyond the last chunk re-read it, the
+        // last LDS write lands in the buffer nobody reads any more
+        gload(1, ra1, rb1, rw1, rs1);
         __syncthreads();
-        if (c + 1 >= ntot) break;
-        if (c + 3 < ntot) gload(c + 3, ra1, rb1);
-        compute(c + 1);
-        if (c + 2 < ntot) lstore(0, ra0, rb0);
+        // (sched_barrier: the requests stay in front of the MFMAs and the LDS writes behind them - left alone
+        // the scheduler writes chunk c + 1 to LDS early in chunk c, i.e. waits for it half a chunk after its
+        // request)
+        for (int c = 0; c < ntot; c += 2) {
+            gload(c + 2, ra0, rb0, rw0, rs0);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(c);
+            __builtin_amdgcn_sched_barrier(0);
+            lstore(1, ra1, rb1, rw1, rs1);
+            __syncthreads();
+            gload(c + 3, ra1, rb1, rw1, rs1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(c + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            lstore(0, ra0, rb0, rw0, rs0);
+            __syncthreads();
+        }
+    } else {
+        if (ntot > 1) gload(1, ra1, rb1, rw1, rs1);
         __syncthreads();
+        for (int c = 0; c < ntot; c += 2) {
+            if (c + 2 < ntot) gload(c + 2, ra0, rb0, rw0, rs0);
+            compute(c);
+            if (c + 1 < ntot) lstore(1, ra1, rb1, rw1, rs1);
+            __syncthreads();
+            if (c + 1 >= ntot) break;
+            if (c + 3 < ntot) gload(c + 3, ra1, rb1, rw1, rs1);
+            compute(c + 1);
+            if (c + 2 < ntot) lstore(0, ra0, rb0, rw0, rs0);
+            __syncthreads();
+        }
     }
     const bool pair = DUAL && in2;
     const int z0 = zb + wrow * 16;
@@ -257,12 +332,12 @@ __global__ __launch_bounds__(64 * WZ * WN) __attribute__((amdgpu_waves_per_eu(WP
     }
 }
 
-template <bool SCALED, bool PAIRED, bool DUAL, int WC, int WN, int WZ, int WPE>
-static int launch_tile(const HankelJobs &J, const HankelScales &Sc, const HankelPairs &Pr, int nj, long irs,
+template <bool SCALED, bool PAIRED, bool DUAL, int WC, int WN, int WZ, int WPE, bool FULL>
+static int launch_tile_(const HankelJobs &J, const HankelScales &Sc, const HankelPairs &Pr, int nj, long irs,
                    long ors, double alpha, int Nz, int Nr, hipStream_t s)
 {
     using C = H2Cfg<WC, WN, WZ>;
-    auto kern = k_hankel<SCALED, PAIRED, DUAL, WC, WN, WZ, WPE>;
+    auto kern = k_hankel<SCALED, PAIRED, DUAL, WC, WN, WZ, WPE, FULL>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e1 = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -273,6 +348,22 @@ static int launch_tile(const HankelJobs &J, const HankelScales &Sc, const Hankel
     dim3 grid((Nz + C::TZ - 1) / C::TZ, (Nr + C::TN - 1) / C::TN, nj);
     hipLaunchKernelGGL(kern, grid, dim3(C::NTHR), C::LDS_BYTES, s, J, Sc, Pr, irs, ors, alpha, Nz, Nr);
     return check(hipGetLastError(), "fb_hankel");
+}
+
+// straight-line loads (FULL) where the sizes allow it, see gload
+template <bool SCALED, bool PAIRED, bool DUAL, int WC, int WN, int WZ, int WPE>
+static int launch_tile(const HankelJobs &J, const HankelScales &Sc, const HankelPairs &Pr, int nj, long irs,
+                   long ors, double alpha, int Nz, int Nr, hipStream_t s)
+{
+    bool full = (Nr % (2 * H2_KC) == 0) && (Nr % (WC * WN) == 0) && Nz >= 1;
+    if (SCALED)
+        for (int j = 0; j < nj; j++) full = full && Sc.sk[j] != nullptr;
+#ifdef FB_HANKEL_TILE_PROBE
+    static const int nofull = getenv("FBPIC_AMD_HANKEL_NOFULL") ? atoi(getenv("FBPIC_AMD_HANKEL_NOFULL")) : 0;
+    if (nofull) full = false;
+#endif
+    if (full) return launch_tile_<SCALED, PAIRED, DUAL, WC, WN, WZ, WPE, true>(J, Sc, Pr, nj, irs, ors, alpha, Nz, Nr, s);
+    return launch_tile_<SCALED, PAIRED, DUAL, WC, WN, WZ, WPE, false>(J, Sc, Pr, nj, irs, ors, alpha, Nz, Nr, s);
 }
 
 static int launch(int njobs, const void *const *in, long irs, void *const *out, long ors,
@@ -311,7 +402,38 @@ static int launch(int njobs, const void *const *in, long irs, void *const *out, 
         const long wg_big = (long)((Nz + 63) / 64) * ((Nr + 127) / 128) * nj;
         const bool big = wg_big >= 2 * 256;
 #define H2(SC, PA, DU, WN_, WZ_, WP) launch_tile<SC, PA, DU, 32, WN_, WZ_, WP>(J, Sc, Pr, nj, irs, ors, alpha, Nz, Nr, s)
-#define H2V(SC, PA) (big ? H2(SC, PA, false, 4, 4, 4) : H2(SC, PA, false, 2, 2, 3))
+        // (round 6, with the straight-line loads: 32 x 128 with 8 waves beats 64 x 128 at Nr = 256 - 195 against
+        // 213 us for the 8 forward transforms of 4416 x 256, 308 against 315 for 12 -, equal at Nr = 512)
+        const bool mid = big && Nr < 512;
+#define H2V(SC, PA) (mid ? H2(SC, PA, false, 4, 2, 2) : big ? H2(SC, PA, false, 4, 4, 4) : H2(SC, PA, false, 2, 2, 3))
+#ifdef FB_HANKEL_TILE_PROBE
+        // developer A/B builds (tools/variant.sh ... -DFB_HANKEL_TILE_PROBE): other workgroup shapes by environment
+        static const int probe = getenv("FBPIC_AMD_HANKEL_TILE") ? atoi(getenv("FBPIC_AMD_HANKEL_TILE")) : 0;
+#define H2W(SC, PA, DU, WC_, WN_, WZ_, WP) launch_tile<SC, PA, DU, WC_, WN_, WZ_, WP>(J, Sc, Pr, nj, irs, ors, alpha, Nz, Nr, s)
+        if (probe && !dual && !paired && !scaled) {
+            switch (probe) {
+            case 1: return H2W(false, false, false, 64, 2, 4, 2);      // 64 x 128, 8 waves, wave tile 16 x 64
+            case 2: return H2W(false, false, false, 64, 4, 4, 4);      // 64 x 256, 16 waves
+            case 3: return H2W(false, false, false, 64, 4, 2, 2);      // 32 x 256, 8 waves
+            case 4: return H2W(false, false, false, 32, 4, 2, 2);      // 32 x 128, 8 waves
+            case 5: return H2W(false, false, false, 32, 4, 4, 4);      // 64 x 128, 16 waves (the big default)
+            case 6: return H2W(false, false, false, 32, 2, 2, 3);      // 32 x 64, 4 waves (the small default)
+            case 7: return H2W(false, false, false, 32, 8, 2, 4);      // 32 x 256, 16 waves
+            case 8: return H2W(false, false, false, 64, 4, 1, 1);      // 16 x 256, 4 waves
+            }
+        }
+        if (probe && dual) {
+            switch (probe) {
+            case 1: return H2W(false, false, true, 32, 4, 2, 2);       // 32 x 128, 8 waves
+            case 2: return H2W(false, false, true, 32, 2, 4, 2);       // 64 x 64, 8 waves
+            case 3: return H2W(false, false, true, 32, 8, 1, 2);       // 16 x 256, 8 waves
+            case 4: return H2W(false, false, true, 32, 8, 2, 4);       // 32 x 256, 16 waves
+            case 5: return H2W(false, false, true, 32, 4, 4, 4);       // 64 x 128, 16 waves (spills)
+            case 6: return H2W(false, false, true, 32, 2, 2, 2);       // default
+            }
+        }
+#undef H2W
+#endif
         if (dual) r = H2(false, false, true, 2, 2, 2);
         else if (paired) r = H2V(true, true);
         else if (scaled) r = H2V(true, false);

@@ -251,8 +251,13 @@ def test_decomposed_correction_deferral_equals_separate_launches():
     -> 'correct', fb_spect_cycle_standard with correct_currents = 2).  The full-size C4 test cannot see
     a wrong fused launch (Nr = 256 > 128: it does not run there; its bounds are percent-level anyway).
     Here, with Nr = 32: the same two ranks with the deferral and with the separate launches
-    (Fields.fuse_spectral_cycle = False), whole local grids incl. guard cells and every particle, 1e-13;
-    reference order that must hold: fbpic/main.py:530-557."""
+    (Fields.fuse_spectral_cycle = False), whole local grids incl. guard cells and every particle;
+    reference order that must hold: fbpic/main.py:530-557.
+    Bound of the fields: 5e-13.  The two runs differ by the summation order of the Hankel products AND by the
+    order of their own deposition atomics (not reproducible run to run); the curl-free correction multiplies
+    that rounding by ~Nz / 2 pi x n e c / |J|.  Measured over six executions on
+    five boxes: 4.3e-14, 9.0e-14, 9.0e-14, 9.9e-14, 9.9e-14, 1.35e-13 - a bound of 1e-13 sat inside the spread.
+    A wrong fused launch (a swapped matrix, a missing filter factor) shows at 1e-3 or worse."""
     import helpers
     outdir = tempfile.mkdtemp()
     import atexit
@@ -283,7 +288,7 @@ def test_decomposed_correction_deferral_equals_separate_launches():
                 grp = [kk for kk in helpers.INTERP if kk[0] == k[0]]
                 scale = max(np.abs(b['%s_%d' % (kk, mm)]).max() for kk in grp for mm in range(NM))
                 if scale > 0:
-                    achieved(None, np.abs(a[key] - b[key]).max() / scale, 1e-13, 'fields, whole local grid')
+                    achieved(None, np.abs(a[key] - b[key]).max() / scale, 5e-13, 'fields, whole local grid')
         pa = np.array([a['p_' + k] for k in helpers.PTCL[:8]])
         pb = np.array([b['p_' + k] for k in helpers.PTCL[:8]])
         assert pa.shape == pb.shape
