@@ -273,19 +273,22 @@ __global__ __launch_bounds__(64 * WZ * WN) __attribute__((amdgpu_waves_per_eu(WP
         // (sched_barrier: the requests stay in front of the MFMAs and the LDS writes behind them - left alone
         // the scheduler writes chunk c + 1 to LDS early in chunk c, i.e. waits for it half a chunk after its
         // request)
+#ifndef HK_KNOCK
+#define HK_KNOCK 0             // timing experiments (tools/variant.sh): 1 no requests in the loop, 2 nor LDS writes, 3 nor barriers
+#endif
         for (int c = 0; c < ntot; c += 2) {
-            gload(c + 2, ra0, rb0, rw0, rs0);
+            if (HK_KNOCK < 1) gload(c + 2, ra0, rb0, rw0, rs0);
             __builtin_amdgcn_sched_barrier(0);
             compute(c);
             __builtin_amdgcn_sched_barrier(0);
-            lstore(1, ra1, rb1, rw1, rs1);
-            __syncthreads();
-            gload(c + 3, ra1, rb1, rw1, rs1);
+            if (HK_KNOCK < 2) lstore(1, ra1, rb1, rw1, rs1);
+            if (HK_KNOCK < 3) __syncthreads();
+            if (HK_KNOCK < 1) gload(c + 3, ra1, rb1, rw1, rs1);
             __builtin_amdgcn_sched_barrier(0);
             compute(c + 1);
             __builtin_amdgcn_sched_barrier(0);
-            lstore(0, ra0, rb0, rw0, rs0);
-            __syncthreads();
+            if (HK_KNOCK < 2) lstore(0, ra0, rb0, rw0, rs0);
+            if (HK_KNOCK < 3) __syncthreads();
         }
     } else {
         if (ntot > 1) gload(1, ra1, rb1, rw1, rs1);

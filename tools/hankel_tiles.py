@@ -8,7 +8,9 @@ usage: hankel_tiles.py                 the whole scan (spawns itself)
 import os, sys, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-VARIANT = os.path.join(ROOT, 'fbpic_amd', 'csrc', 'variants', 'libfbpic_amd_hkprobe.so')
+VARIANT = os.path.join(ROOT, 'fbpic_amd', 'csrc', 'variants', 'libfbpic_amd_%s.so' % os.environ.get('FBPIC_AMD_HK_VARIANT', 'hkprobe'))
+if os.environ.get('FBPIC_AMD_HK_VARIANT') == 'default':
+    VARIANT = os.path.join(ROOT, 'fbpic_amd', 'csrc', 'libfbpic_amd.so')
 
 
 def one(kind, Nz, Nr, njobs, reps=20):
@@ -62,8 +64,8 @@ def one(kind, Nz, Nr, njobs, reps=20):
         p_ = a[:64, 0, :] @ mats[0].to(torch.complex128)
         m_ = a[:64, 1, :] @ mats[1].to(torch.complex128)
         err = float(max((b[:64, 0, :] - (p_ + m_)).abs().max(), (b[:64, 1, :] - 1j * (p_ - m_)).abs().max()) / p_.abs().max())
-    print('%-5s Nz=%d Nr=%d jobs=%2d tile=%s : %8.1f us  %5.1f TFLOP/s  err %.1e'
-          % (kind, Nz, Nr, njobs, os.environ.get('FBPIC_AMD_HANKEL_TILE', '0'), us, flop / (us * 1e-6) / 1e12, err), flush=True)
+    print('%-5s Nz=%d Nr=%d jobs=%2d tile=%s lib=%s : %8.1f us  %5.1f TFLOP/s  err %.1e'
+          % (kind, Nz, Nr, njobs, os.environ.get('FBPIC_AMD_HANKEL_TILE', '0'), os.environ.get('FBPIC_AMD_HK_VARIANT', 'hkprobe'), us, flop / (us * 1e-6) / 1e12, err), flush=True)
 
 
 if '--one' in sys.argv:
