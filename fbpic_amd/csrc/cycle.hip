@@ -173,14 +173,6 @@ __device__ unsigned long long cycle_trace_buf[16];
 #else
 #define FB_MARK(x)
 #endif
-// s_waitcnt vmcnt(0) as an INSTRUCTION the compiler sees (an asm statement would leave its wait-count
-// bookkeeping believing the loads - also those into LDS - are still pending: it then waits again,
-// with vmcnt(0), in front of the first use, i.e. for whatever stores and atomics were issued since)
-__device__ __forceinline__ void fb_wait_vm()
-{
-    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0), expcnt and lgkmcnt untouched (gfx9 encoding)
-    asm volatile("" ::: "memory");
-}
 #define KP(T, field) karg_ptr<T>((int)__builtin_offsetof(CycleArgs, field))
 // a chunk of 64 particles of which more than this many have left their home cell costs several times
 // the normal chunk (every stray is a gather segment and a scatter of its own): counted for the host's

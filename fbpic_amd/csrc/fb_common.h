@@ -103,6 +103,24 @@ struct PushX {
     double chdt, px, py, pz;
 };
 
+// s_waitcnt vmcnt(0) as an INSTRUCTION the compiler sees (an asm statement would leave its wait-count
+// bookkeeping believing the loads - also those into LDS - are still pending: it then waits again,
+// with vmcnt(0), in front of the first use, i.e. for whatever stores and atomics were issued since)
+#ifdef __HIPCC__
+__device__ __forceinline__ void fb_wait_vm()
+{
+    // (compiler barriers on both sides: without the first one a load requested just in front of the wait may
+    // be scheduled behind it - seen in the prologue of k_perm_deposit_J_rho, whose loop then waited at its top)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0), expcnt and lgkmcnt untouched (gfx9 encoding)
+    asm volatile("" ::: "memory");
+}
+// "this value is needed HERE": the compiler waits for the load that produces it in front of this point (loads
+// through const __restrict__ pointers are invariant to it and move freely across fb_wait_vm's barriers - a
+// prologue that ends with fb_wait_vm may still leave its loads in flight, and the loop then waits at its top)
+template <class T> __device__ __forceinline__ void fb_consume(T &v) { asm volatile("" : "+v"(v)); }
+#endif
+
 // Optional by-product of a kernel that holds x, y, z, u, inv_gamma of every particle in
 // registers (fb_deposit_J_rank_next, fb_gather_push_rank_next): Simulation.step pushes the
 // positions by another half step and then re-sorts them (main.py:519-528).  The kernel also
