@@ -61,7 +61,10 @@ constexpr int SC_PANEL = 16 * SC_RS;
 // (4 / 8 / 16 / 32 steps: 50.8 / 51.4 / 52.8 / 61.3 us when the launch is repeated back to back,
 // tools/sc_time.py - but INSIDE a step, where the particle kernels have flushed the matrices out
 // of L2: 64.8 / 57.9 / 56.7 / 65.7 us.  The depth is chosen in the bench, not in the loop.)
-constexpr int SC_PF = 16;            // matrix row groups requested ahead of the MFMA that uses them
+#ifndef SC_PF_STEPS
+#define SC_PF_STEPS 16
+#endif
+constexpr int SC_PF = SC_PF_STEPS;   // matrix row groups requested ahead of the MFMA that uses them
 
 struct SpectCycleArgs {
     // per mode m: src[4m..] = Jr, Jt, Jz, rho after the forward z-FFT (un-normalised)
