@@ -198,7 +198,114 @@ def cap_lwfa(name, nranks, shape, nsteps, G=LWFA_2R):
     save(name, **res)
 
 
+# ---- BASELINE config C4 on its own grid: 4096 x 256, Nm = 2, n_order = 32, n_guard = 64, 8 slabs
+C4 = dict(Nz=4096, Nr=256, zmin=-10.e-6, zmax=30.e-6, rmax=20.e-6, n_order=32, n_guard=64, nranks=8,
+          nslab=2)          # plasma slabs of `nslab` cells, one cell to the right of every slab boundary
+
+
+def c4_dens_func(G):
+    """Plasma only in thin slabs just right of the 7 inner slab boundaries (the window moves one cell per
+    step: every slab crosses its boundary within four steps and is handed to the left neighbour at the first
+    particle exchange; the slab of boundary 5 sits at the centre of the laser pulse).  Everywhere else the
+    density is 0, so the continuous injection adds nothing and the interpreted reference stays affordable."""
+    dz = (G['zmax'] - G['zmin']) / G['Nz']
+    per = G['Nz'] // G['nranks']
+    edges = [G['zmin'] + r * per * dz for r in range(1, G['nranks'])]
+
+    def dens(z, r):
+        n = np.zeros_like(z)
+        for b in edges:
+            n = np.where((z >= b + dz) & (z < b + (1 + G['nslab']) * dz), 1., n)
+        return n
+    return dens
+
+
+def c4_rows(Nz_local, ng):
+    """z rows of a rank's local grid kept by the C4 fixture: two in each guard region, two inside."""
+    return np.array([ng // 2, ng + 1, ng + 3, Nz_local // 2, Nz_local - ng - 2, Nz_local - ng // 2 - 1])
+
+
+def c4_sim(G):
+    from fbpic.main import Simulation
+    dt = (G['zmax'] - G['zmin']) / G['Nz'] / c
+    np.random.seed(0)
+    return Simulation(G['Nz'], G['zmax'], G['Nr'], G['rmax'], 2, dt, zmin=G['zmin'],
+                      p_zmin=G['zmin'], p_zmax=G['zmax'], p_rmin=0., p_rmax=18.e-6, p_nz=2, p_nr=2, p_nt=4,
+                      n_e=4.e24, dens_func=c4_dens_func(G), n_order=G['n_order'], n_guard=G['n_guard'],
+                      particle_shape='linear', verbose_level=0, boundaries={'z': 'open', 'r': 'reflective'},
+                      use_cuda=False)
+
+
+def cap_c4_full_grid(name='c4_full_grid', G=C4):
+    """The laser-wakefield window of BASELINE config 4 at its own size on 8 slabs, run by the REAL reference
+    (every rank its own Simulation.step: guard exchanges of E, B and of the corrected J, particle hand-over at
+    the first exchange, moving window, damping at the two open ends, a0 = 4 pulse), exchange_period + 2
+    steps.  Stored per rank: 6 z rows of every grid, sum / sum of squares / maximum of every grid over
+    the whole local grid, every third particle of the (w, x, y, z) order and the moments of every particle
+    attribute."""
+    import time
+    from fbpic.lpa_utils.laser import add_laser_pulse, GaussianLaser
+    from mpi4py import MPI
+    nranks = G['nranks']
+    MPI.set_world(nranks)
+    sims = [None] * nranks
+    errs = []
+    turn = [threading.Semaphore(0) for _ in range(nranks + 1)]
+    turn[0].release()
+
+    def build(r):
+        MPI.set_rank(r)
+        try:
+            turn[r].acquire()
+            sims[r] = c4_sim(G)
+            turn[r + 1].release()
+            MPI.COMM_WORLD.barrier()
+            add_laser_pulse(sims[r], GaussianLaser(a0=4., waist=5.e-6, tau=16.e-15, z0=15.e-6))
+            sims[r].set_moving_window(v=c)
+        except Exception:   # pragma: no cover
+            errs.append((r, traceback.format_exc()))
+            turn[r + 1].release()
+    t0 = time.time()
+    th = [threading.Thread(target=build, args=(r,)) for r in range(nranks)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if errs:
+        raise RuntimeError('rank %d failed in setup:\n%s' % errs[0])
+    s0 = sims[0]
+    nstep = int(s0.comm.exchange_period) + 2
+    print('built', time.time() - t0, 'exchange_period', s0.comm.exchange_period, 'local Nz',
+          [s.fld.Nz for s in sims], 'Ntot', [s.ptcl[0].Ntot for s in sims], flush=True)
+    res = dict(Nz=G['Nz'], Nr=G['Nr'], Nm=2, zmin=G['zmin'], zmax=G['zmax'], rmax=G['rmax'], dt=s0.dt,
+               n_order=G['n_order'], n_guard=s0.comm.n_guard, nz_damp=s0.comm.nz_damp, n_inject=s0.comm.n_inject,
+               nranks=nranks, nslab=G['nslab'], nstep=nstep, exchange_period=s0.comm.exchange_period,
+               Nz_local=np.array([s.fld.Nz for s in sims]),
+               n0=np.array([s.ptcl[0].Ntot for s in sims]))
+    for it in range(nstep):
+        t0 = time.time()
+        run_ranks(sims, 1)
+        print('step', it, time.time() - t0, 'Ntot', [s.ptcl[0].Ntot for s in sims], flush=True)
+    for r, sim in enumerate(sims):
+        full = np.array([[getattr(sim.fld.interp[m], k) for k in INTERP] for m in range(2)])
+        rows = c4_rows(sim.fld.Nz, sim.comm.n_guard)
+        res['r%d_rows' % r] = rows
+        res['r%d_interp_rows' % r] = full[:, :, rows, :]
+        res['r%d_interp_sum' % r] = full.sum(axis=(2, 3))
+        res['r%d_interp_sum2' % r] = (np.abs(full)**2).sum(axis=(2, 3))
+        res['r%d_interp_max' % r] = np.abs(full).max(axis=(2, 3))
+        res['r%d_zmin' % r] = sim.fld.interp[0].zmin
+        P = np.array([getattr(sim.ptcl[0], k) for k in PTCL])
+        res['r%d_ntot' % r] = P.shape[1]
+        o = np.lexsort((P[2], P[1], P[0], P[7]))
+        res['r%d_ptcl_sample' % r] = P[:, o[::3]]
+        res['r%d_ptcl_sum' % r] = P.sum(axis=1)
+        res['r%d_ptcl_sum2' % r] = (P**2).sum(axis=1)
+    save(name, **res)
+
+
 CASES = {
+    'c4_full_grid': cap_c4_full_grid,
     # 48 physical + 2 x 12 guard cells per rank; exchange_period = int((12/2 - 3) / 2) = 1
     'mr_periodic_lin_2r': lambda: cap_periodic('mr_periodic_lin_2r', 2, 'linear', 96, 8, 8, 12,
                                                (1, 2, 4), True, (1, 5)),
