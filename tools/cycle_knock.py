@@ -24,7 +24,7 @@ res = {n: {} for n, _ in libs}
 RS = tuple(int(v) for v in os.environ.get('KNOCK_R', '1,2,3').split(','))
 REPS = int(os.environ.get('KNOCK_REPS', '10'))
 with GpuMemoryManager(sim):
-    sim.step(24)
+    sim.step(int(os.environ.get("KNOCK_AGE", "24")))
     fld, comm = sim.fld, sim.comm
     for _ in range(8):
         if all(r in res['default'] for r in RS):
