@@ -388,6 +388,7 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
     double xq = 0., yq = 0., zq = 0.;  // ... of the one after it
     int hq = 0;
     double mux, muy, muz, mig;         // momenta, 1/gamma of the next chunk
+    double mw = 0.;                    // ... and its weights (read by the first half of the staging, in front of the wait)
     auto load_pos = [&](long b, double &x_, double &y_, double &z_, int &h_) {
         const long i = min(b + lane, n - 1);
         const KPtrs<4> q = karg_ptrs4(KOFF(x));            // x, y, z, home
@@ -399,6 +400,7 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
         const KPtrs<4> q = karg_ptrs4(KOFF(ux));           // ux, uy, uz, ig
         mux = ((const double *)q.p[0])[i]; muy = ((const double *)q.p[1])[i]; muz = ((const double *)q.p[2])[i];
         mig = ((const double *)q.p[3])[i];
+        if constexpr (!RANK) mw = KP(const double, w)[i];
     };
     load_pos(base, xn, yn, zn, hn);
     load_mom(base);
@@ -422,11 +424,10 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
         FB_MARK("M_TOP");
         const long nbase = base + 64;
         const bool more = (ch + 1 < A.chunks_per_wave) && nbase < n;
-        // momenta of this chunk (requested a chunk ago); its weights (first read behind the wait), the
-        // momenta of the next chunk and the positions of the one after it leave now
+        // momenta and weights of this chunk (requested a chunk ago); the momenta and weights of the next chunk
+        // and the positions of the one after it leave now
         double pux = mux, puy = muy, puz = muz, pig = mig;
-        double pw = 0.;
-        if constexpr (!RANK) pw = KP(const double, w)[i];
+        const double pw = mw;
         if (more) {
             load_mom(nbase);
             if (ch + 2 < A.chunks_per_wave) load_pos(nbase + 64, xq, yq, zq, hq);
@@ -620,7 +621,7 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
         const double bJ0 = ((const double *)bq.p[0])[irJ], bJh = ((const double *)bq.p[1])[irJ];
         const double bR0 = ((const double *)bq.p[0])[irR], bRh = ((const double *)bq.p[1])[irR];
 #endif
-        wait_and_store();
+        if constexpr (!P::MERGED) wait_and_store();
         if constexpr (!P::MERGED) {
             ej.stage_with(true, xh, yh, zh, wj, pux, puy, puz, pig, A.c_light, geom, bJ0, bJh, dkz, dkr, dnb);
             {
@@ -644,9 +645,22 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
             }
         } else {
             int rkz, rkr, rnb;
+            // (the chunk's one wait for vector memory sits INSIDE the staging, in front of the radial shape
+            // factors: the Ruyten coefficients requested above travel during the rest of it)
+#ifndef FB_CYCLE_WAIT_FIRST
+            double rcJ, rcR;
+            ed.template stage_pre<0>(xh, yh, zh, wj, pux, puy, puz, pig, A.c_light, geom, dkz, dkr, dnb, rcJ);
+        FB_MARK("M_RSTAGE");
+            ed.template stage_pre<1>(x1, y1, z1, wj, 0., 0., 0., 0., 0., geom, rkz, rkr, rnb, rcR);
+            wait_and_store();
+            ed.template stage_post<0>(rcJ, bJ0, bJh);
+            ed.template stage_post<1>(rcR, bR0, bRh);
+#else
+            wait_and_store();
             ed.template stage<0>(xh, yh, zh, wj, pux, puy, puz, pig, A.c_light, geom, bJ0, bJh, dkz, dkr, dnb);
         FB_MARK("M_RSTAGE");
             ed.template stage<1>(x1, y1, z1, wj, 0., 0., 0., 0., 0., geom, bR0, bRh, rkz, rkr, rnb);
+#endif
             const bool homeJ = act && dkz == hkz && dkr == hkr && dnb == hnb;
             const bool homeR = act && rkz == hkz && rkr == hkr && rnb == hnb;
             const unsigned long long hmJ = __ballot(homeJ), smJ = __ballot(act && !homeJ);

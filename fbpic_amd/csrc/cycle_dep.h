@@ -187,10 +187,11 @@ struct CycleDep {
 
     // ---- phase 1, lane = particle: amplitudes, first shape factors, stencil key of engine E
     // (0: J, 1: rho) - the arithmetic of DepEngine::stage_with.  u, ig, c_light only for J.
+    // stage_pre: everything that does not read the Ruyten coefficients
     template <int E>
-    __device__ __forceinline__ void stage(double xj, double yj, double zj, double wj,
+    __device__ __forceinline__ void stage_pre(double xj, double yj, double zj, double wj,
             double ux, double uy, double uz, double ig, double c_light, const DepGeom &g,
-            double beta0_v, double betah_v, int &my_kz, int &my_kr, int &my_nb)
+            int &my_kz, int &my_kr, int &my_nb, double &r_cell_out)
     {
         constexpr int NC = (E == 0) ? 3 : 1;
         constexpr int R0 = (E == 0) ? L::ROW_AJ : L::ROW_AR;           // mode-0 amplitudes (real)
@@ -226,16 +227,36 @@ struct CycleDep {
         const int icr = (int)ceil(r_cell), icz = (int)ceil(z_cell);
         my_kr = min(icr - 1, Nr); my_kz = icz - 1;
         my_nb = 1 - icr;
-        double Sz[2], Sr0[2], Srh[2];
+        double Sz[2];
         shape_z<FB_SHAPE_LINEAR>(z_cell, Sz);
-        shape_r<FB_SHAPE_LINEAR>(r_cell, beta0_v, Sr0);
-        constexpr int RS = (E == 0) ? L::ROW_SJ : L::ROW_SR, RT = (E == 0) ? L::ROW_TJ : L::ROW_TR;
+        constexpr int RS = (E == 0) ? L::ROW_SJ : L::ROW_SR;
         Pd[RS * PAD + lane] = Sz[0];
+        r_cell_out = r_cell;
+    }
+    // ... and the part that reads the Ruyten coefficients (the radial shape factors of mode 0 and of the modes
+    // >= 1): the one-pass kernel requests the coefficients in front of stage_pre and waits for vector memory
+    // between the two parts, so that the request travels during the rest of the staging (round 6)
+    template <int E>
+    __device__ __forceinline__ void stage_post(double r_cell, double beta0_v, double betah_v)
+    {
+        double *Pd = (double *)P;
+        double Sr0[2], Srh[2];
+        constexpr int RT = (E == 0) ? L::ROW_TJ : L::ROW_TR;
+        shape_r<FB_SHAPE_LINEAR>(r_cell, beta0_v, Sr0);
         Pd[RT * PAD + lane] = Sr0[0];
         if constexpr (NM > 1) {
             shape_r<FB_SHAPE_LINEAR>(r_cell, betah_v, Srh);
             Pd[(RT + 1) * PAD + lane] = Srh[0];
         }
+    }
+    template <int E>
+    __device__ __forceinline__ void stage(double xj, double yj, double zj, double wj,
+            double ux, double uy, double uz, double ig, double c_light, const DepGeom &g,
+            double beta0_v, double betah_v, int &my_kz, int &my_kr, int &my_nb)
+    {
+        double r_cell;
+        stage_pre<E>(xj, yj, zj, wj, ux, uy, uz, ig, c_light, g, my_kz, my_kr, my_nb, r_cell);
+        stage_post<E>(r_cell, beta0_v, betah_v);
     }
 
     // zero the amplitudes of the lanes (= particles) that take no part in the runs of an engine
