@@ -423,6 +423,9 @@ static int launch(int njobs, const void *const *in, long irs, void *const *out, 
             case 6: return H2W(false, false, false, 32, 2, 2, 3);      // 32 x 64, 4 waves (the small default)
             case 7: return H2W(false, false, false, 32, 8, 2, 4);      // 32 x 256, 16 waves
             case 8: return H2W(false, false, false, 64, 4, 1, 1);      // 16 x 256, 4 waves
+            case 9: return H2W(false, false, false, 32, 4, 3, 3);      // 48 x 128, 12 waves
+            case 11: return H2W(false, false, false, 32, 2, 3, 3);     // 48 x 64, 6 waves
+            case 12: return H2W(false, false, false, 32, 2, 4, 2);     // 64 x 64, 8 waves
             }
         }
         if (probe && dual) {
