@@ -812,6 +812,11 @@ static int launch_cycle_linear(const CycleArgs &A0, hipStream_t s)
     // and its node lines leave the XCD's L2)
     const long target_waves = 256L * 64;
     int cpw = (int)((nchunks + target_waves - 1) / target_waves);
+    {
+        // (FBPIC_AMD_CYCLE_CPW: developer override of the chunks per wave, for the scans of tools/)
+        static const int env_cpw = getenv("FBPIC_AMD_CYCLE_CPW") ? atoi(getenv("FBPIC_AMD_CYCLE_CPW")) : 0;
+        if (env_cpw > 0) cpw = env_cpw;
+    }
     if (cpw < 1) cpw = 1;
     if (cpw > 64) cpw = 64;
     A.chunks_per_wave = cpw;
