@@ -392,15 +392,15 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
     auto load_pos = [&](long b, double &x_, double &y_, double &z_, int &h_) {
         const long i = min(b + lane, n - 1);
         const KPtrs<4> q = karg_ptrs4(KOFF(x));            // x, y, z, home
-        x_ = ((const double *)q.p[0])[i]; y_ = ((const double *)q.p[1])[i]; z_ = ((const double *)q.p[2])[i];
-        h_ = ((const int *)q.p[3])[i];
+        x_ = FB_NT_LD(((const double *)q.p[0]) + i); y_ = FB_NT_LD(((const double *)q.p[1]) + i); z_ = FB_NT_LD(((const double *)q.p[2]) + i);
+        h_ = FB_NT_LD(((const int *)q.p[3]) + i);
     };
     auto load_mom = [&](long b) {
         const long i = min(b + lane, n - 1);
         const KPtrs<4> q = karg_ptrs4(KOFF(ux));           // ux, uy, uz, ig
-        mux = ((const double *)q.p[0])[i]; muy = ((const double *)q.p[1])[i]; muz = ((const double *)q.p[2])[i];
-        mig = ((const double *)q.p[3])[i];
-        if constexpr (!RANK) mw = KP(const double, w)[i];
+        mux = FB_NT_LD(((const double *)q.p[0]) + i); muy = FB_NT_LD(((const double *)q.p[1]) + i); muz = FB_NT_LD(((const double *)q.p[2]) + i);
+        mig = FB_NT_LD(((const double *)q.p[3]) + i);
+        if constexpr (!RANK) mw = FB_NT_LD(KP(const double, w) + i);
     };
     load_pos(base, xn, yn, zn, hn);
     load_mom(base);
@@ -555,14 +555,14 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
                     ((double *)e4.p[3])[i] = bx; ((double *)b2.p[0])[i] = by; ((double *)b2.p[1])[i] = bz;
                 }
                 const KPtrs<8> q = karg_ptrs8(KOFF(x));            // x, y, z, home, ux, uy, uz, ig
-                ((double *)q.p[4])[i] = pux; ((double *)q.p[5])[i] = puy; ((double *)q.p[6])[i] = puz;
-                ((double *)q.p[7])[i] = pig;
+                FB_NT_ST(pux, ((double *)q.p[4]) + i); FB_NT_ST(puy, ((double *)q.p[5]) + i); FB_NT_ST(puz, ((double *)q.p[6]) + i);
+                FB_NT_ST(pig, ((double *)q.p[7]) + i);
                 if constexpr (RANK) {
                     // the second half push belongs to the sort pass that follows (which deposits J
                     // from x(n+1/2) first): the position is left at x(n+1/2)
-                    ((double *)q.p[0])[i] = xh; ((double *)q.p[1])[i] = yh; ((double *)q.p[2])[i] = zh;
+                    FB_NT_ST(xh, ((double *)q.p[0]) + i); FB_NT_ST(yh, ((double *)q.p[1]) + i); FB_NT_ST(zh, ((double *)q.p[2]) + i);
                 } else {
-                    ((double *)q.p[0])[i] = x1; ((double *)q.p[1])[i] = y1; ((double *)q.p[2])[i] = z1;
+                    FB_NT_ST(x1, ((double *)q.p[0]) + i); FB_NT_ST(y1, ((double *)q.p[1]) + i); FB_NT_ST(z1, ((double *)q.p[2]) + i);
                 }
             }
         };
@@ -573,7 +573,7 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
             // one chunk later, when the atomic's value has long arrived
             {
                 const int b_ = __shfl(pd_base, pd_run0);
-                if (pd_i >= 0) { A.rk_cell[pd_i] = pd_cell; A.rk_rank[pd_i] = b_ + (lane - pd_run0); }
+                if (pd_i >= 0) { FB_NT_ST(pd_cell, A.rk_cell + pd_i); FB_NT_ST(b_ + (lane - pd_run0), A.rk_rank + pd_i); }
             }
             int rk_c = -1;
             if (act) {
@@ -760,7 +760,7 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
     }
     if constexpr (RANK) {
         const int b_ = __shfl(pd_base, pd_run0);
-        if (pd_i >= 0) { A.rk_cell[pd_i] = pd_cell; A.rk_rank[pd_i] = b_ + (lane - pd_run0); }
+        if (pd_i >= 0) { FB_NT_ST(pd_cell, A.rk_cell + pd_i); FB_NT_ST(b_ + (lane - pd_run0), A.rk_rank + pd_i); }
         return;
     }
     if constexpr (!P::MERGED) {

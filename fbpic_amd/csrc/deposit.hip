@@ -67,21 +67,21 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
         if (ip < n) {
             if constexpr (PERM) {
 #pragma unroll
-                for (int k = 0; k < 8; k++) pn[k] = PM.src.p[k][idx_n];
+                for (int k = 0; k < 8; k++) pn[k] = FB_NT_LDG(PM.src.p[k] + idx_n);
             } else {
-                pn[0] = x[ip]; pn[1] = y[ip]; pn[2] = z[ip]; pn[3] = w[ip];
-                if constexpr (NCOMP == 3) { pn[4] = ux[ip]; pn[5] = uy[ip]; pn[6] = uz[ip]; pn[7] = inv_gamma[ip]; }
+                pn[0] = FB_NT_LD(x + ip); pn[1] = FB_NT_LD(y + ip); pn[2] = FB_NT_LD(z + ip); pn[3] = FB_NT_LD(w + ip);
+                if constexpr (NCOMP == 3) { pn[4] = FB_NT_LD(ux + ip); pn[5] = FB_NT_LD(uy + ip); pn[6] = FB_NT_LD(uz + ip); pn[7] = FB_NT_LD(inv_gamma + ip); }
             }
         }
     };
     // PERM: two-stage pipeline - the index of chunk ch+2 is requested while the attributes
     // of chunk ch+1 (through the index requested one iteration earlier) are in flight
-    if constexpr (PERM) { if (chunk0 * 64 + lane < n) idx_n = PM.sidx[chunk0 * 64 + lane]; }
+    if constexpr (PERM) { if (chunk0 * 64 + lane < n) idx_n = FB_NT_LD(PM.sidx + (chunk0 * 64 + lane)); }
     prefetch(chunk0 * 64 + lane);
     int idx_nn = 0;
     if constexpr (PERM) {
         idx_c = idx_n;
-        if (chunks_per_wave > 1 && (chunk0 + 1) * 64 + lane < n) idx_nn = PM.sidx[(chunk0 + 1) * 64 + lane];
+        if (chunks_per_wave > 1 && (chunk0 + 1) * 64 + lane < n) idx_nn = FB_NT_LD(PM.sidx + ((chunk0 + 1) * 64 + lane));
     }
     for (int ch = 0; ch < chunks_per_wave; ch++) {
         const long base = (chunk0 + ch) * 64;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
         }
         if (ch + 1 < chunks_per_wave) prefetch(ip + 64);
         if constexpr (PERM) {
-            if (ch + 2 < chunks_per_wave && ip + 128 < n) idx_nn = PM.sidx[ip + 128];
+            if (ch + 2 < chunks_per_wave && ip + 128 < n) idx_nn = FB_NT_LD(PM.sidx + (ip + 128));
         }
         double xj = pc[0], yj = pc[1], zj = pc[2];
         if constexpr (PERM) {
@@ -110,11 +110,11 @@ __global__ __launch_bounds__(256) void k_deposit(long n,
                 xj = pc[0] + PM.chdt * g * PM.px * pc[3];
                 yj = pc[1] + PM.chdt * g * PM.py * pc[4];
                 zj = pc[2] + PM.chdt * g * PM.pz * pc[5];
-                PM.dst.p[0][ip] = xj; PM.dst.p[1][ip] = yj; PM.dst.p[2][ip] = zj;
-                PM.dst.p[3][ip] = pc[3]; PM.dst.p[4][ip] = pc[4]; PM.dst.p[5][ip] = pc[5];
-                PM.dst.p[6][ip] = pc[6]; PM.dst.p[7][ip] = g;
+                FB_NT_ST(xj, PM.dst.p[0] + ip); FB_NT_ST(yj, PM.dst.p[1] + ip); FB_NT_ST(zj, PM.dst.p[2] + ip);
+                FB_NT_ST(pc[3], PM.dst.p[3] + ip); FB_NT_ST(pc[4], PM.dst.p[4] + ip); FB_NT_ST(pc[5], PM.dst.p[5] + ip);
+                FB_NT_ST(pc[6], PM.dst.p[6] + ip); FB_NT_ST(g, PM.dst.p[7] + ip);
                 for (int k = 8; k < PM.nattr; k++) PM.dst.p[k][ip] = PM.src.p[k][idx_c];
-                if (PM.cell_sorted) PM.cell_sorted[ip] = PM.cell[idx_c];
+                if (PM.cell_sorted) FB_NT_ST(FB_NT_LDG(PM.cell + idx_c), PM.cell_sorted + ip);
             }
         }
         const double wj = q * pc[PERM ? 6 : 3];
@@ -213,13 +213,13 @@ __global__ __launch_bounds__(256) void k_perm_deposit_J_rho(long n, double q, do
     auto prefetch = [&](long ip) {
         if (ip < n) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) pn[k] = PM.src.p[k][idx_n];
+            for (int k = 0; k < 8; k++) pn[k] = FB_NT_LDG(PM.src.p[k] + idx_n);
         }
     };
-    if (chunk0 * 64 + lane < n) idx_n = PM.sidx[chunk0 * 64 + lane];
+    if (chunk0 * 64 + lane < n) idx_n = FB_NT_LD(PM.sidx + (chunk0 * 64 + lane));
     prefetch(chunk0 * 64 + lane);
     idx_c = idx_n;
-    if (chunks_per_wave > 1 && (chunk0 + 1) * 64 + lane < n) idx_nn = PM.sidx[(chunk0 + 1) * 64 + lane];
+    if (chunks_per_wave > 1 && (chunk0 + 1) * 64 + lane < n) idx_nn = FB_NT_LD(PM.sidx + ((chunk0 + 1) * 64 + lane));
     for (int ch = 0; ch < chunks_per_wave; ch++) {
         const long base = (chunk0 + ch) * 64;
         if (base >= n) break;
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void k_perm_deposit_J_rho(long n, double q, do
         if (ch > 0) idx_c = idx_n;
         idx_n = idx_nn;
         if (ch + 1 < chunks_per_wave) prefetch(ip + 64);
-        if (ch + 2 < chunks_per_wave && ip + 128 < n) idx_nn = PM.sidx[ip + 128];
+        if (ch + 2 < chunks_per_wave && ip + 128 < n) idx_nn = FB_NT_LD(PM.sidx + (ip + 128));
         const double wj = q * pc[6];
         int kz, kr, nb;
         // ---- J from the position before the push
@@ -248,11 +248,11 @@ __global__ __launch_bounds__(256) void k_perm_deposit_J_rho(long n, double q, do
             xj = pc[0] + PM.chdt * g * PM.px * pc[3];
             yj = pc[1] + PM.chdt * g * PM.py * pc[4];
             zj = pc[2] + PM.chdt * g * PM.pz * pc[5];
-            PM.dst.p[0][ip] = xj; PM.dst.p[1][ip] = yj; PM.dst.p[2][ip] = zj;
-            PM.dst.p[3][ip] = pc[3]; PM.dst.p[4][ip] = pc[4]; PM.dst.p[5][ip] = pc[5];
-            PM.dst.p[6][ip] = pc[6]; PM.dst.p[7][ip] = g;
+            FB_NT_ST(xj, PM.dst.p[0] + ip); FB_NT_ST(yj, PM.dst.p[1] + ip); FB_NT_ST(zj, PM.dst.p[2] + ip);
+            FB_NT_ST(pc[3], PM.dst.p[3] + ip); FB_NT_ST(pc[4], PM.dst.p[4] + ip); FB_NT_ST(pc[5], PM.dst.p[5] + ip);
+            FB_NT_ST(pc[6], PM.dst.p[6] + ip); FB_NT_ST(g, PM.dst.p[7] + ip);
             for (int k = 8; k < PM.nattr; k++) PM.dst.p[k][ip] = PM.src.p[k][idx_c];
-            if (PM.cell_sorted) PM.cell_sorted[ip] = PM.cell[idx_c];
+            if (PM.cell_sorted) FB_NT_ST(FB_NT_LDG(PM.cell + idx_c), PM.cell_sorted + ip);
         }
         // ---- rho from the pushed position
         er.stage(act, xj, yj, zj, wj, 0., 0., 0., 0., 0., gR, beta0, betah, kz, kr, nb);
@@ -296,13 +296,13 @@ __global__ __launch_bounds__(256) void k_perm_deposit_J_rho_merged(long n, doubl
     auto prefetch = [&](long ip) {
         if (ip < n) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) pn[k] = PM.src.p[k][idx_n];
+            for (int k = 0; k < 8; k++) pn[k] = FB_NT_LDG(PM.src.p[k] + idx_n);
         }
     };
-    if (chunk0 * 64 + lane < n) idx_n = PM.sidx[chunk0 * 64 + lane];
+    if (chunk0 * 64 + lane < n) idx_n = FB_NT_LD(PM.sidx + (chunk0 * 64 + lane));
     prefetch(chunk0 * 64 + lane);
     idx_c = idx_n;
-    if (chunks_per_wave > 1 && (chunk0 + 1) * 64 + lane < n) idx_nn = PM.sidx[(chunk0 + 1) * 64 + lane];
+    if (chunks_per_wave > 1 && (chunk0 + 1) * 64 + lane < n) idx_nn = FB_NT_LD(PM.sidx + ((chunk0 + 1) * 64 + lane));
     for (int ch = 0; ch < chunks_per_wave; ch++) {
         const long base = (chunk0 + ch) * 64;
         if (base >= n) break;
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void k_perm_deposit_J_rho_merged(long n, doubl
         if (ch > 0) idx_c = idx_n;
         idx_n = idx_nn;
         if (ch + 1 < chunks_per_wave) prefetch(ip + 64);
-        if (ch + 2 < chunks_per_wave && ip + 128 < n) idx_nn = PM.sidx[ip + 128];
+        if (ch + 2 < chunks_per_wave && ip + 128 < n) idx_nn = FB_NT_LD(PM.sidx + (ip + 128));
         const double wj = act ? q * pc[6] : 0.;
         // pending push_x (expression of k_push_x), attributes written at the sorted slot
         const double gi = pc[7];
@@ -328,14 +328,14 @@ __global__ __launch_bounds__(256) void k_perm_deposit_J_rho_merged(long n, doubl
         const int irR = min((int)ceil(g.invdr * (r1 - g.rmin) - 0.5), g.Nr);
         const double bJ0 = beta0[irJ], bJh = betah[irJ], bR0 = beta0[irR], bRh = betah[irR];
         if (act) {
-            PM.dst.p[0][ip] = xj; PM.dst.p[1][ip] = yj; PM.dst.p[2][ip] = zj;
-            PM.dst.p[3][ip] = pc[3]; PM.dst.p[4][ip] = pc[4]; PM.dst.p[5][ip] = pc[5];
-            PM.dst.p[6][ip] = pc[6]; PM.dst.p[7][ip] = gi;
+            FB_NT_ST(xj, PM.dst.p[0] + ip); FB_NT_ST(yj, PM.dst.p[1] + ip); FB_NT_ST(zj, PM.dst.p[2] + ip);
+            FB_NT_ST(pc[3], PM.dst.p[3] + ip); FB_NT_ST(pc[4], PM.dst.p[4] + ip); FB_NT_ST(pc[5], PM.dst.p[5] + ip);
+            FB_NT_ST(pc[6], PM.dst.p[6] + ip); FB_NT_ST(gi, PM.dst.p[7] + ip);
             // (static indices: a run-time index into the by-value pointer tables sends them to scratch)
 #pragma unroll
             for (int k = 8; k < 16; k++)
                 if (k < PM.nattr) PM.dst.p[k][ip] = PM.src.p[k][idx_c];
-            if (PM.cell_sorted) PM.cell_sorted[ip] = PM.cell[idx_c];
+            if (PM.cell_sorted) FB_NT_ST(FB_NT_LDG(PM.cell + idx_c), PM.cell_sorted + ip);
         }
         int jkz, jkr, jnb, rkz, rkr, rnb;
         ed.template stage<0>(pc[0], pc[1], pc[2], wj, pc[3], pc[4], pc[5], gi, c_light, g, bJ0, bJh, jkz, jkr, jnb);

@@ -103,6 +103,26 @@ struct PushX {
     double chdt, px, py, pz;
 };
 
+// Particle streams (positions, momenta, weights, home cells, permutation indices: read once and written once per
+// pass, 500 MB per step at the headline size) are NON-TEMPORAL: global_load / global_store ... nt.  What the grid
+// kernels of the step re-read - interpolation grids, deposition records, the 46 MB spectral slab, the solver's tables
+// (~105 MB together) - then survives in L2 / the 256 MB Infinity Cache between the particle passes.  Round 6, C2: fused
+// spectral launch 49.6 -> 44.5 us, step 0.384 -> 0.373 ms (profiles/r06_nontemporal_streams.txt).  -DFB_NO_NT: plain
+// accesses, for A/B builds.
+// (FB_NT_LDG: the permuted gathers of the sorting pass - a line is shared by the lanes of neighbouring particles)
+#if !defined(FB_NO_NT) && !defined(FB_NO_NT_GATHER)
+#define FB_NT_LDG(p) __builtin_nontemporal_load(p)
+#else
+#define FB_NT_LDG(p) (*(p))
+#endif
+#ifndef FB_NO_NT
+#define FB_NT_LD(p) __builtin_nontemporal_load(p)
+#define FB_NT_ST(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define FB_NT_LD(p) (*(p))
+#define FB_NT_ST(v, p) (*(p) = (v))
+#endif
+
 // s_waitcnt vmcnt(0) as an INSTRUCTION the compiler sees (an asm statement would leave its wait-count
 // bookkeeping believing the loads - also those into LDS - are still pending: it then waits again,
 // with vmcnt(0), in front of the first use, i.e. for whatever stores and atomics were issued since)

@@ -148,8 +148,8 @@ __device__ __forceinline__ void rank_commit(RankPending &pd, int lane, const Pus
     if (!PA.RK.count) return;
     const int b = __shfl(pd.base, pd.run0);
     if (pd.i >= 0) {
-        PA.RK.cell[pd.i] = pd.cell;
-        PA.RK.rank[pd.i] = b + (lane - pd.run0);
+        FB_NT_ST(pd.cell, PA.RK.cell + pd.i);
+        FB_NT_ST(b + (lane - pd.run0), PA.RK.rank + pd.i);
     }
     pd.i = -1;
 }
@@ -167,21 +167,21 @@ __device__ __forceinline__ void gather_finish(bool act, long i, int lane, double
     if (act) {
         const double ex = cs * F[0] - sn * F[1], ey = sn * F[0] + cs * F[1], ez = F[2];
         const double bx = cs * F[3] - sn * F[4], by = sn * F[3] + cs * F[4], bz = F[5];
-        if (Ex) { Ex[i] = ex; Ey[i] = ey; Ez[i] = ez; Bx[i] = bx; By[i] = by; Bz[i] = bz; }
+        if (Ex) { FB_NT_ST(ex, Ex + i); FB_NT_ST(ey, Ey + i); FB_NT_ST(ez, Ez + i); FB_NT_ST(bx, Bx + i); FB_NT_ST(by, By + i); FB_NT_ST(bz, Bz + i); }
         if (PA.ux) {
             // momenta are loaded here, not at the top of the chunk: 8 VGPRs less across the
             // stencil phase; the other waves of the SIMD cover the latency (measured: -3 %)
             double pux, puy, puz, pig;
             if (pre) { pux = pre[0]; puy = pre[1]; puz = pre[2]; pig = pre[3]; }
-            else { pux = PA.ux[i]; puy = PA.uy[i]; puz = PA.uz[i]; pig = PA.ig[i]; }
+            else { pux = FB_NT_LD(PA.ux + i); puy = FB_NT_LD(PA.uy + i); puz = FB_NT_LD(PA.uz + i); pig = FB_NT_LD(PA.ig + i); }
             vay(pux, puy, puz, pig, ex, ey, ez, bx, by, bz, PA.econst, PA.bconst);
-            PA.ux[i] = pux; PA.uy[i] = puy; PA.uz[i] = puz; PA.ig[i] = pig;
+            FB_NT_ST(pux, PA.ux + i); FB_NT_ST(puy, PA.uy + i); FB_NT_ST(puz, PA.uz + i); FB_NT_ST(pig, PA.ig + i);
             if (PA.chdt != 0.) {
                 // numba_methods.py:28-30 with push_x = push_y = push_z = 1
                 const double xp = xj + PA.chdt * pig * 1. * pux;
                 const double yp = yj + PA.chdt * pig * 1. * puy;
                 const double zp = zj + PA.chdt * pig * 1. * puz;
-                PA.x[i] = xp; PA.y[i] = yp; PA.z[i] = zp;
+                FB_NT_ST(xp, PA.x + i); FB_NT_ST(yp, PA.y + i); FB_NT_ST(zp, PA.z + i);
                 if (PA.RK.count) {
                     // position after the coming push_x, cell as in k_cell_index / k_bin_rank
                     const double xq = xp + PA.RK.chdt * pig * PA.RK.px * pux;
@@ -223,8 +223,8 @@ __device__ __forceinline__ void gather_finish(bool act, long i, int lane, double
         } else {
             rk_base = __shfl(rk_base, rk_run0);
             if (act) {
-                PA.RK.cell[i] = rk_c;
-                PA.RK.rank[i] = rk_base + (lane - rk_run0);
+                FB_NT_ST(rk_c, PA.RK.cell + i);
+                FB_NT_ST(rk_base + (lane - rk_run0), PA.RK.rank + i);
             }
         }
     }
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void k_gather(int Nm_arg, long n,
     // software pipeline: the particle coordinates of chunk ch+1 are requested before the
     // work on chunk ch starts, so their HBM latency hides behind staging + stencil math
     double xn = 0., yn = 0., zn = 0.;
-    if (chunk0 * 64 + lane < n) { xn = x[chunk0 * 64 + lane]; yn = y[chunk0 * 64 + lane]; zn = z[chunk0 * 64 + lane]; }
+    if (chunk0 * 64 + lane < n) { xn = FB_NT_LD(x + (chunk0 * 64 + lane)); yn = FB_NT_LD(y + (chunk0 * 64 + lane)); zn = FB_NT_LD(z + (chunk0 * 64 + lane)); }
     RankPending pend = {-1, 0, 0, 0};
     bool have_next = true;        // xn, yn, zn hold the coordinates of the chunk about to start
     long r_lo = 0, r_hi = n;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void k_gather(int Nm_arg, long n,
             const bool none = PA.range_mode == 1 ? (base + 64 <= r_lo || base >= r_hi)
                                                  : (base >= r_lo && base + 64 <= r_hi);
             if (none) { have_next = false; continue; }      // (nothing is loaded for it)
-            if (!have_next && i < n) { xn = x[i]; yn = y[i]; zn = z[i]; }
+            if (!have_next && i < n) { xn = FB_NT_LD(x + i); yn = FB_NT_LD(y + i); zn = FB_NT_LD(z + i); }
             have_next = true;
         }
         double cs = 1., sn = 0., Sz[S], Sr[S];
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void k_gather(int Nm_arg, long n,
             while (zj >= PA.wzmax) zj -= l_box;
             while (zj < PA.wzmin) zj += l_box;
         }
-        if (ch + 1 < chunks_per_wave && i + 64 < n) { xn = x[i + 64]; yn = y[i + 64]; zn = z[i + 64]; }
+        if (ch + 1 < chunks_per_wave && i + 64 < n) { xn = FB_NT_LD(x + (i + 64)); yn = FB_NT_LD(y + (i + 64)); zn = FB_NT_LD(z + (i + 64)); }
         rank_commit(pend, lane, PA);            // ranks of the previous chunk
         double rj = 0.;
         if (act) {
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
 
     const long chunk0 = (xcd_block_id() * nwaves + wave) * chunks_per_wave;
     double xn = 0., yn = 0., zn = 0.;
-    if (chunk0 * 64 + lane < n) { xn = x[chunk0 * 64 + lane]; yn = y[chunk0 * 64 + lane]; zn = z[chunk0 * 64 + lane]; }
+    if (chunk0 * 64 + lane < n) { xn = FB_NT_LD(x + (chunk0 * 64 + lane)); yn = FB_NT_LD(y + (chunk0 * 64 + lane)); zn = FB_NT_LD(z + (chunk0 * 64 + lane)); }
     RankPending pend = {-1, 0, 0, 0};
     for (int ch = 0; ch < chunks_per_wave; ch++) {
         const long base = (chunk0 + ch) * 64;
@@ -660,11 +660,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
             while (zj >= PA.wzmax) zj -= l_box;
             while (zj < PA.wzmin) zj += l_box;
         }
-        if (ch + 1 < chunks_per_wave && i + 64 < n) { xn = x[i + 64]; yn = y[i + 64]; zn = z[i + 64]; }
+        if (ch + 1 < chunks_per_wave && i + 64 < n) { xn = FB_NT_LD(x + (i + 64)); yn = FB_NT_LD(y + (i + 64)); zn = FB_NT_LD(z + (i + 64)); }
         // momenta of the chunk: requested now, used by the push at the end (this kernel's
         // occupancy is set by its LDS panels, the 8 registers are free)
         double mom[4] = {0., 0., 0., 0.};
-        if (PA.ux && act) { mom[0] = PA.ux[i]; mom[1] = PA.uy[i]; mom[2] = PA.uz[i]; mom[3] = PA.ig[i]; }
+        if (PA.ux && act) { mom[0] = FB_NT_LD(PA.ux + i); mom[1] = FB_NT_LD(PA.uy + i); mom[2] = FB_NT_LD(PA.uz + i); mom[3] = FB_NT_LD(PA.ig + i); }
         double rj = 0., r_cell = 0., z_cell = 0.;
         if (act) {
             rj = sqrt(xj * xj + yj * yj);

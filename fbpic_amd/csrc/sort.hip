@@ -212,8 +212,8 @@ __global__ __launch_bounds__(256) void k_build_sidx(long n, const int *__restric
     long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < ncell; i += stride) count[i] = 0;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const int c = cell[i];
-        sidx[(c > 0 ? prefix[c - 1] : 0) + rank[i]] = (int)i;
+        const int c = FB_NT_LD(cell + i);
+        FB_NT_ST((int)i, sidx + ((c > 0 ? prefix[c - 1] : 0) + FB_NT_LD(rank + i)));
     }
 }
 
