@@ -28,6 +28,18 @@
 namespace fb {
 
 typedef double2 cx;
+// non-temporal load of a complex value (the big-grid transforms read every element once: what they WRITE is what
+// the next launch reads, and only that should stay in the 256 MB Infinity Cache - fb_common.h, FB_NT_LD)
+typedef double zf_v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cx zf_ld_nt(const cx *p)
+{
+#ifndef FB_NO_NT
+    const zf_v2d v = __builtin_nontemporal_load((const zf_v2d *)p);
+    return make_double2(v.x, v.y);
+#else
+    return *p;
+#endif
+}
 
 __device__ __forceinline__ cx cadd(cx a, cx b) { return make_double2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ cx csub(cx a, cx b) { return make_double2(a.x - b.x, a.y - b.y); }
@@ -208,7 +220,7 @@ typedef ZCfg<2304, 2, 192, 6, 6, 8, 8, 1> ZC2304;
 // pm: 0 = plain load; 1 = this column is an r slot, r = p + m with m one field (gin2) to the
 // right; 2 = a t slot, t = i (p - m) with p one field to the left (numba_pm_to_rt,
 // spectral_transformer.py:140-142, folded into the first pass of the backward transform)
-template <class Z, int R, int NS, bool FWD, bool FIRST, bool LAST>
+template <class Z, int R, int NS, bool FWD, bool FIRST, bool LAST, bool NTIN = false>
 __device__ __forceinline__ void zf_pass(cx *lds, const cx *__restrict__ tw,
         const cx *gin, long in_stride, cx *gout, long out_stride,
         int c, int jj0, bool col_ok, double scale, int pm = 0, const cx *gin2 = nullptr,
@@ -226,7 +238,7 @@ __device__ __forceinline__ void zf_pass(cx *lds, const cx *__restrict__ tw,
         for (int t = 0; t < R; t++) {
             const int row = jj + t * NR;
             if (FIRST) {
-                cx a = col_ok ? gin[(long)row * in_stride] : make_double2(0., 0.);
+                cx a = col_ok ? (NTIN ? zf_ld_nt(gin + (long)row * in_stride) : gin[(long)row * in_stride]) : make_double2(0., 0.);
                 // consume-and-clear (fb_zfft_from_records_consume): every element of the record
                 // array is read by exactly one lane of one workgroup
                 if (gclear && col_ok) gclear[(long)row * in_stride] = make_double2(0., 0.);
@@ -331,7 +343,7 @@ __global__ __launch_bounds__(Z::NTHR) void k_zfft(long ncols, const cx *in, long
     constexpr int R0 = Z::R0, R1 = Z::R1, R2 = Z::R2, R3 = Z::R3, R4 = Z::R4;
     constexpr int NPASS = (R1 == 1) ? 1 : (R2 == 1) ? 2 : (R3 == 1) ? 3 : (R4 == 1) ? 4 : 5;
 #define ZF_ARGS zf_lds, tw, gin, in_stride, gout, out_stride, c, jj0, col_ok, scale
-    zf_pass<Z, R0, 1, FWD, true, NPASS == 1>(ZF_ARGS, pm, gin2,
+    zf_pass<Z, R0, 1, FWD, true, NPASS == 1, SUB>(ZF_ARGS, pm, gin2,
                                              (aos_clear && aos_Nr > 0) ? const_cast<cx *>(gin) : nullptr);
     if constexpr (NPASS >= 2) zf_pass<Z, R1, R0, FWD, false, NPASS == 2>(ZF_ARGS);
     if constexpr (NPASS >= 3) zf_pass<Z, R2, R0 * R1, FWD, false, NPASS == 3>(ZF_ARGS);
@@ -524,7 +536,7 @@ __global__ __launch_bounds__(256) void k_fft_pass(int N, int NS, long ncols, con
         cx v[R];
 #pragma unroll
         for (int t = 0; t < R; t++) {
-            v[t] = in[(long)(jj + t * NR) * is + col];
+            v[t] = zf_ld_nt(in + ((long)(jj + t * NR) * is + col));
             if (t > 0 && NS > 1) {
                 cx w = tw[t * k * tstep];
                 if (!FWD) w.y = -w.y;
