@@ -12,6 +12,24 @@ __device__ __forceinline__ cplx rmul(double s, cplx a) { return {s * a.re, s * a
 __device__ __forceinline__ cplx imul(cplx a) { return {-a.im, a.re}; }   // i * a
 __device__ __forceinline__ cplx ld(const cplx *p) { double2 v = *(const double2 *)p; return {v.x, v.y}; }
 __device__ __forceinline__ void st(cplx *p, cplx v) { *(double2 *)p = make_double2(v.re, v.im); }
+// Non-temporal loads for the solver step of a BIG grid (its slab + tables exceed the 256 MB Infinity Cache: every
+// operand is read once per step, and what the step WRITES - the new E, B - is what the next launch reads; see
+// FB_NT_LD in fb_common.h).  Small grids keep plain loads: their tables and fields live in the cache from step to step.
+typedef double fld_v2d __attribute__((ext_vector_type(2)));
+template <bool NT> __device__ __forceinline__ cplx ldx(const cplx *p)
+{
+#ifndef FB_NO_NT
+    if constexpr (NT) { const fld_v2d v = __builtin_nontemporal_load((const fld_v2d *)p); return {v.x, v.y}; }
+#endif
+    return ld(p);
+}
+template <bool NT> __device__ __forceinline__ double ldx(const double *p)
+{
+#ifndef FB_NO_NT
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+#endif
+    return *p;
+}
 
 #define FB_GRID_LOOP(idx, iz, ir)                                                     \
     const long ncell_ = (long)Nz * Nr;                                                \
@@ -173,6 +191,7 @@ struct PsatdModes {
 // (fb_shift_spect: E, B, rho_prev and J times shift[iz]^n_move, moving_window.py:176-239) is
 // applied to the values this kernel writes anyway - one sweep over the spectral slab less per
 // step of a moving-window run.
+template <bool NT>
 __global__ __launch_bounds__(256) void k_psatd_step(PsatdModes M, long rs, double dt, double inv_dt,
         int correct, int use_true_rho, double c2, double eps0, double mu0, int Nz, int Nr,
         const cplx *__restrict__ shift, int n_move)
@@ -194,17 +213,17 @@ __global__ __launch_bounds__(256) void k_psatd_step(PsatdModes M, long rs, doubl
             if (moving) a = {a.re * pw.re - a.im * pw.im, a.re * pw.im + a.im * pw.re};
             st(p, a);
         };
-        const double rpc = t[0][idx], rnc = t[1][idx], jc = t[2][idx], Cc = t[3][idx], Sw = t[4][idx];
-        const double krr = t[5][idx], kzz = t[6][idx];
-        const cplx ep = ld(f[0] + o), em = ld(f[1] + o), ez = ld(f[2] + o);
-        const cplx bp = ld(f[3] + o), bm = ld(f[4] + o), bz = ld(f[5] + o);
-        cplx jp = ld(f[6] + o), jm = ld(f[7] + o), jz = ld(f[8] + o);
-        const cplx rp = ld(f[9] + o), rn = ld(f[10] + o);
+        const double rpc = ldx<NT>(t[0] + idx), rnc = ldx<NT>(t[1] + idx), jc = ldx<NT>(t[2] + idx), Cc = ldx<NT>(t[3] + idx), Sw = ldx<NT>(t[4] + idx);
+        const double krr = ldx<NT>(t[5] + idx), kzz = ldx<NT>(t[6] + idx);
+        const cplx ep = ldx<NT>(f[0] + o), em = ldx<NT>(f[1] + o), ez = ldx<NT>(f[2] + o);
+        const cplx bp = ldx<NT>(f[3] + o), bm = ldx<NT>(f[4] + o), bz = ldx<NT>(f[5] + o);
+        cplx jp = ldx<NT>(f[6] + o), jm = ldx<NT>(f[7] + o), jz = ldx<NT>(f[8] + o);
+        const cplx rp = ldx<NT>(f[9] + o), rn = ldx<NT>(f[10] + o);
         if (correct) {
             cplx t1 = rmul(inv_dt, csub(rn, rp));
             cplx t2 = rmul(kzz, imul(jz));
             cplx t3 = rmul(krr, csub(jp, jm));
-            cplx F = rmul(-t[7][idx], cadd(cadd(t1, t2), t3));
+            cplx F = rmul(-ldx<NT>(t[7] + idx), cadd(cadd(t1, t2), t3));
             jp = cadd(jp, rmul(0.5 * krr, F));
             jm = cadd(jm, rmul(-0.5 * krr, F));
             jz = cadd(jz, rmul(kzz, imul(rmul(-1., F))));
@@ -585,9 +604,16 @@ extern "C" int fb_psatd_step_standard_shift(int Nm, void *const *fields, long rs
     for (int i = 0; i < 11 * FB_MAX_MODES; i++) M.f[i] = i < 11 * Nm ? (cplx *)fields[i] : nullptr;
     for (int i = 0; i < 8 * FB_MAX_MODES; i++) M.t[i] = i < 8 * Nm ? tables[i] : nullptr;
     dim3 grid(stream_grid((long)Nz * Nr, 256, 256 * 4), Nm);
-    hipLaunchKernelGGL(k_psatd_step, grid, dim3(256), 0, (hipStream_t)stream, M, rs, dt, 1. / dt,
-                       correct_currents, use_true_rho, c * c, epsilon_0, mu_0, Nz, Nr,
-                       (const cplx *)shift, n_move);
+    // (240 B of operands per cell and mode: beyond ~3/4 of the Infinity Cache they are read non-temporally)
+    const bool big = 240. * (double)Nz * (double)Nr * (double)Nm > 192. * 1048576.;
+    if (big)
+        hipLaunchKernelGGL(k_psatd_step<true>, grid, dim3(256), 0, (hipStream_t)stream, M, rs, dt, 1. / dt,
+                           correct_currents, use_true_rho, c * c, epsilon_0, mu_0, Nz, Nr,
+                           (const cplx *)shift, n_move);
+    else
+        hipLaunchKernelGGL(k_psatd_step<false>, grid, dim3(256), 0, (hipStream_t)stream, M, rs, dt, 1. / dt,
+                           correct_currents, use_true_rho, c * c, epsilon_0, mu_0, Nz, Nr,
+                           (const cplx *)shift, n_move);
     FB_CHECK_LAUNCH("fb_psatd_step_standard");
 }
 
