@@ -596,5 +596,21 @@ class BoundaryCommunicator(object):
             self.exchange_particles_aperiodic_subdomain(species, fld, time)
 
     def exchange_particles_aperiodic_subdomain(self, species, fld, time):
-        from .particle_buffer_handling import exchange_particles_between_ranks
+        from .particle_buffer_handling import exchange_particles_between_ranks, finish_particle_handover
+        begun = species.__dict__.pop('_handover_begun', None)
+        if begun is not None:           # the first half is already in the stream (begin_exchange_particles)
+            finish_particle_handover(self, species, fld, time, begun)
+            return
         exchange_particles_between_ranks(self, species, fld, time)
+
+    def begin_exchange_particles(self, species, fld):
+        """First half of the hand-over of a decomposed domain, posted ahead of its place in the step
+        (Simulation._step_loop: behind the particle pass of the iteration before): selection, packing,
+        the two messages and the request of the host read; `exchange_particles` then completes it.  All
+        ranks post it at the same point of the step, so the order of the point-to-point operations is the
+        same on both ends of every link."""
+        from .particle_buffer_handling import begin_particle_handover
+        species._touch()
+        species.flush_pending_push()
+        species._prerank = None
+        species._handover_begun = begin_particle_handover(self, species, fld)

@@ -172,6 +172,16 @@ def _append(t, out, buf, stride, cnt, first, shift_attr, shift):
 
 def exchange_particles_between_ranks(comm, species, fld, time):
     """One hand-over of `species` with the two z neighbours; see the module docstring."""
+    finish_particle_handover(comm, species, fld, time, begin_particle_handover(comm, species, fld))
+
+
+def begin_particle_handover(comm, species, fld):
+    """First half of a hand-over: selection + packing, the exchange of the two fixed-size messages and the
+    REQUEST of the one host read (the four counts; an event marks it in the stream).  Reads the particle
+    arrays, changes none of them.  Simulation.step posts it right behind the particle pass of the iteration
+    BEFORE a hand-over iteration: the host then waits for that event only, and prepares compaction and append
+    (~300 us of host work, during which the stream used to be empty) while the field kernels of that
+    iteration are still queued.  Returns the context `finish_particle_handover` needs."""
     t = _capi.torch()
     dev = species.z.device
     st = _device_state(t, species, comm, dev)
@@ -221,8 +231,29 @@ def exchange_particles_between_ranks(comm, species, fld, time):
     comm._handover_caps = None
     _recv_counts(t, L, R, st['counts'])
     st['counts_host'].copy_(st['counts'], non_blocking=True)
+    ev = None
     if dev.type == 'cuda':
-        t.cuda.current_stream().synchronize()         # the one host read of a hand-over
+        ev = st.get('event')
+        if ev is None:
+            ev = st['event'] = t.cuda.Event()
+        ev.record(t.cuda.current_stream())
+    return {'st': st, 'n': n, 'arrs': arrs, 'idx_cap': idx_cap, 'dev': dev, 'event': ev,
+            'z_ptr': species.z.data_ptr()}
+
+
+def finish_particle_handover(comm, species, fld, time, ctx):
+    """Second half: the host read of the counts, then compaction, append and the bookkeeping of the
+    species.  `ctx`: what `begin_particle_handover` returned for the same species - whose arrays must not
+    have changed since."""
+    t = _capi.torch()
+    st, n, arrs, idx_cap, dev = ctx['st'], ctx['n'], ctx['arrs'], ctx['idx_cap'], ctx['dev']
+    if species.Ntot != n or species.z.data_ptr() != ctx['z_ptr']:
+        raise _capi.BackendError('particle hand-over: the particle arrays changed between the two halves '
+                                 'of a hand-over (the messages of the first half are already exchanged)')
+    L, R = st['left'], st['right']
+    nattr = len(_STATE)
+    if ctx['event'] is not None:
+        ctx['event'].synchronize()                    # the one host read of a hand-over
     n_sl, n_sr, n_rl, n_rr = [int(v) for v in st['counts_host'][:4].tolist()]
     if max(n_sl, n_sr) > idx_cap:
         raise _capi.BackendError('particle hand-over: %d / %d particles leave the slab of rank %d at '

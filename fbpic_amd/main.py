@@ -190,6 +190,9 @@ class Simulation(object):
         # (xGMI, RCCL) exceeds ~60 us; it is kept selectable for that measurement
         # (FBPIC_AMD_OVERLAP) and pinned by tests/test_gpu_multirank_golden.py.
         self.overlap_guard_exchange = os.environ.get('FBPIC_AMD_OVERLAP', 'off')
+        # the first half of a particle hand-over (selection, messages, request of the host read) is posted
+        # behind the particle pass of the iteration before (see _handover_can_start_early)
+        self.early_handover = os.environ.get('FBPIC_AMD_EARLY_HANDOVER', '1') != '0'
         # The particle work of an iteration as ONE pass (Particles.cycle, csrc/cycle.hip) with a
         # re-sort every few steps only, where the conditions of _one_pass_ok hold; else the
         # two-pass sequence (gather + push + rank | deposit J + push + sort + deposit rho).
@@ -326,6 +329,13 @@ class Simulation(object):
                 else:
                     self._gather_push_reference_order(move_momenta, move_positions)
                 self._deposit_push_deposit(correct_currents, use_true_rho, move_positions, cross)
+            if self._handover_can_start_early(i_step, N):
+                # the next iteration hands particles over: selection, messages and the request of the
+                # host read go into the stream HERE, behind the particle pass (the positions are
+                # final); the host read then waits for that point of the stream only, and the host's
+                # part of the hand-over overlaps the field kernels queued below
+                for species in ptcl:
+                    self.comm.begin_exchange_particles(species, fld)
             shifted_by = self._field_update(correct_currents, use_true_rho, cross)
             if self.comm.moving_win is not None:
                 self.comm.move_grids(fld, ptcl, dt, self.time, spect_shifted_by=shifted_by)
@@ -372,6 +382,19 @@ class Simulation(object):
             # is due at this iteration (or the reference launch sequence is asked for).
             self.deposit('J', exchange=True)
         return wrap_z
+
+    def _handover_can_start_early(self, i_step, N):
+        """The hand-over of the NEXT iteration may be begun behind this iteration's particle pass: a
+        decomposed domain whose box does not move in between (no moving window: the ownership rule
+        compares z with the box edges of the iteration it belongs to), the next iteration inside this
+        call (between calls the user may change the particles), one exchange at a time on the
+        communicator (no E, B tail on the second stream)."""
+        comm = self.comm
+        return bool(self.early_handover and comm.size > 1 and comm.n_guard != 0
+                    and comm.moving_win is None and i_step + 1 < N
+                    and (self.iteration + 1) % comm.exchange_period == 0
+                    and self.overlap_guard_exchange == 'off' and self._eb_pending is None
+                    and all(getattr(sp.z, 'is_cuda', False) for sp in self.ptcl))
 
     def _one_pass_ok(self, correct_currents, use_true_rho, cross):
         """Whether the particle work of this iteration can be the single pass of
