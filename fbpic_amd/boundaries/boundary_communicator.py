@@ -614,3 +614,4 @@ class BoundaryCommunicator(object):
         species.flush_pending_push()
         species._prerank = None
         species._handover_begun = begin_particle_handover(self, species, fld)
+        self.early_handovers = getattr(self, 'early_handovers', 0) + 1      # (diagnostics / tests)

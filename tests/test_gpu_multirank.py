@@ -57,6 +57,8 @@ def _run(rank, world, port, shape, outdir, correct, fuse=True, tag='', n_guard=N
         # the forward Hankel transform of J, rho and the curl-free correction as separate launches
         # (default on a decomposed domain: ONE launch, fb_spect_cycle_standard with correct_currents = 2)
         sim.fld.fuse_spectral_cycle = False
+    if tag == '_late':
+        sim.early_handover = False      # the whole hand-over at its place in the iteration
     sim.step(NSTEP, correct_currents=correct)
     ng = sim.comm.n_guard
     sl = slice(ng, sim.fld.Nz - ng) if ng else slice(None)
@@ -71,6 +73,9 @@ def _run(rank, world, port, shape, outdir, correct, fuse=True, tag='', n_guard=N
         out['p_' + k] = getattr(sp, k)
     if tag:
         out['launches'] = out_launches
+    # hand-overs whose first half was posted behind the particle pass of the iteration before
+    # (Simulation.early_handover: on by default; FBPIC_AMD_EARLY_HANDOVER=0 in the environment of a rank)
+    out['early_handovers'] = getattr(sim.comm, 'early_handovers', 0)
     np.savez(os.path.join(outdir, 'w%d_r%d%s.npz' % (world, rank, tag)), **out)
     if world > 1:
         dist.barrier()
@@ -118,6 +123,8 @@ def test_two_ranks_reproduce_single_domain(shape, correct, tol, nranks):
             assert msg == 'ok', 'world %d rank %d:\n%s' % (world, rank, msg)
     one = np.load(os.path.join(outdir, 'w1_r0.npz'))
     two = [np.load(os.path.join(outdir, 'w%d_r%d.npz' % (nranks, r))) for r in range(nranks)]
+    # the hand-over inside the call (iteration 6 of 9) took the early form on every rank, none on one rank
+    assert int(one['early_handovers']) == 0 and all(int(t['early_handovers']) == 1 for t in two)
     for m in range(NM):
         for k in helpers.INTERP:
             key = '%s_%d' % (k, m)
@@ -296,3 +303,49 @@ def test_decomposed_correction_deferral_equals_separate_launches():
         o2 = np.lexsort((pb[2], pb[1], pb[0], pb[7]))
         for j, k in enumerate(helpers.PTCL[:8]):
             achieved(None, np.abs(pa[j][o1] - pb[j][o2]).max() / max(np.abs(pb[j]).max(), 1e-300), 1e-13, 'particles')
+
+
+def test_early_handover_equals_handover_in_place():
+    """The first half of a particle hand-over (selection, packing, the two messages, the request of the host
+    read) posted behind the particle pass of the iteration BEFORE (Simulation.early_handover, the default on
+    a decomposed domain without moving window) against the whole hand-over at its place in the iteration
+    (reference order, fbpic/main.py:435-446, boundary_communicator.py:750-826): the same particles leave and
+    arrive, in the same order - whole local grids incl. guard cells to the rounding of the deposition
+    atomics' order, every particle, the same particle counts."""
+    import helpers
+    outdir = tempfile.mkdtemp()
+    import atexit
+    import shutil
+    atexit.register(shutil.rmtree, outdir, ignore_errors=True)
+    ctx = mp.get_context('spawn')
+    world = 2
+    for tag in ('_early', '_late'):
+        port = _free_port()
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, 'linear', outdir, False, q, True, tag))
+                 for r in range(world)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=600) for _ in range(world)]
+        for p in procs:
+            p.join(60)
+        for rank, msg in res:
+            assert msg == 'ok', 'rank %d (%s):\n%s' % (rank, tag, msg)
+    for r in range(world):
+        a = np.load(os.path.join(outdir, 'w2_r%d_early.npz' % r))
+        b = np.load(os.path.join(outdir, 'w2_r%d_late.npz' % r))
+        assert int(a['early_handovers']) == 1 and int(b['early_handovers']) == 0
+        for m in range(NM):
+            for k in helpers.INTERP:
+                key = '%s_%d' % (k, m)
+                grp = [kk for kk in helpers.INTERP if kk[0] == k[0]]
+                scale = max(np.abs(b['%s_%d' % (kk, mm)]).max() for kk in grp for mm in range(NM))
+                if scale > 0:
+                    achieved(None, np.abs(a[key] - b[key]).max() / scale, 1e-13, 'fields, whole local grid')
+        pa = np.array([a['p_' + k] for k in helpers.PTCL[:8]])
+        pb = np.array([b['p_' + k] for k in helpers.PTCL[:8]])
+        assert pa.shape == pb.shape                      # the same number of particles on the rank
+        # ... in the same ORDER (leavers compacted and arrivals appended identically)
+        for j in range(8):
+            achieved(None, np.abs(pa[j] - pb[j]).max() / max(np.abs(pb[j]).max(), 1e-300), 1e-13,
+                     'particles, same order')
