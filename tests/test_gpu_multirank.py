@@ -310,7 +310,7 @@ def test_early_handover_equals_handover_in_place():
     read) posted behind the particle pass of the iteration BEFORE (Simulation.early_handover, the default on
     a decomposed domain without moving window) against the whole hand-over at its place in the iteration
     (reference order, fbpic/main.py:435-446, boundary_communicator.py:750-826): the same particles leave and
-    arrive, in the same order - whole local grids incl. guard cells to the rounding of the deposition
+    arrive - whole local grids incl. guard cells to the rounding of the deposition
     atomics' order, every particle, the same particle counts."""
     import helpers
     outdir = tempfile.mkdtemp()
@@ -345,7 +345,10 @@ def test_early_handover_equals_handover_in_place():
         pa = np.array([a['p_' + k] for k in helpers.PTCL[:8]])
         pb = np.array([b['p_' + k] for k in helpers.PTCL[:8]])
         assert pa.shape == pb.shape                      # the same number of particles on the rank
-        # ... in the same ORDER (leavers compacted and arrivals appended identically)
+        # (the ORDER of the leavers in a message, and with it of the arrivals and of the survivors that fill
+        # the holes, is that of the selection's atomics - it differs between two executions of either form)
+        o1 = np.lexsort((pa[2], pa[1], pa[0], pa[7]))
+        o2 = np.lexsort((pb[2], pb[1], pb[0], pb[7]))
         for j in range(8):
-            achieved(None, np.abs(pa[j] - pb[j]).max() / max(np.abs(pb[j]).max(), 1e-300), 1e-13,
-                     'particles, same order')
+            achieved(None, np.abs(pa[j][o1] - pb[j][o2]).max() / max(np.abs(pb[j]).max(), 1e-300), 1e-13,
+                     'particles')
