@@ -488,69 +488,6 @@ struct CycleDep {
     // ---- strays: staged particle l (wave-uniform) written out directly - lane = (node l >> 4,
     // amplitude, variant), value = (Sz Sr) amplitude from the staged rows, one atomic instruction per
     // tile for BOTH engines where the particle is a stray of both (keys per engine).
-#ifdef FB_SCAT_PIPE
-    // (A/B build, round 6: the staged operands of stray k + 1 are read while stray k is written out - the loop
-    // is otherwise one LDS round trip per stray that nothing covers)
-    __device__ __forceinline__ void scatter_strays(unsigned long long smJ, unsigned long long smR,
-            int jkz, int jkr, int jnb, int rkz, int rkr, int rnb)
-    {
-        unsigned long long um = smJ | smR;
-        if (!um) return;
-        int l = __builtin_ctzll(um);
-        um &= um - 1ull;
-        double s_, t_, x_[NTL], y_[NTL];
-        {
-            const int so = 8 * l - k8;
-            s_ = ld(aS + so); t_ = ld(aT + so);
-#pragma unroll
-            for (int t = 0; t < NTL; t++) { x_[t] = ld(aX[t] + so); y_[t] = ld(aY[t] + so); }
-        }
-        while (true) {
-            const bool more = um != 0ull;
-            // (the last stray reads its own operands again: no branch around a load)
-            const int ln = more ? __builtin_ctzll(um) : l;
-            um &= um - 1ull;
-            const int son = 8 * ln - k8;
-            const double sn = ld(aS + son), tn = ld(aT + son);
-            double xn[NTL], yn[NTL];
-#pragma unroll
-            for (int t = 0; t < NTL; t++) { xn[t] = ld(aX[t] + son); yn[t] = ld(aY[t] + son); }
-            const bool inJ = (smJ >> l) & 1ull, inR = (smR >> l) & 1ull;
-            const int zJ = __builtin_amdgcn_readlane(jkz, l), rJ = __builtin_amdgcn_readlane(jkr, l);
-            const int nJ = __builtin_amdgcn_readlane(jnb, l);
-            const int zR = __builtin_amdgcn_readlane(rkz, l), rR = __builtin_amdgcn_readlane(rkr, l);
-            const int nR = __builtin_amdgcn_readlane(rnb, l);
-            const bool mine = engR ? inR : inJ;
-            const double wz = jzD ? 1. - s_ : s_;
-            const double wr = jrD ? 1. - t_ : t_;
-            const double w = wz * wr;
-            const bool intJ = zJ >= 0 && zJ + 2 <= Nz && rJ >= 0 && rJ + 2 <= Nr;
-            const bool intR = zR >= 0 && zR + 2 <= Nz && rR >= 0 && rR + 2 <= Nr;
-            const bool interior = (intJ || !inJ) && (intR || !inR);
-            const int baseJ = zJ * rsB + rJ * csB, baseR = zR * rsB + rR * csB;
-#pragma unroll
-            for (int t = 0; t < NTL; t++) {
-                double v = w * (x_[t] * y_[t]);
-                if (!mine || !((valid >> t) & 1u) || v == 0.) continue;
-                unsigned voff;
-                if (interior) {
-                    voff = f_off[t] + (unsigned)((engR ? baseR : baseJ) + jrDB);
-                } else {
-                    const int kz = engR ? zR : zJ, kr = engR ? rR : rJ, nb = engR ? nR : nJ;
-                    int gz = kz + jzD, gr = kr + jrD;
-                    fold_node(gz, gr, Nz, Nr);
-                    if (jrD < nb && ((neg >> t) & 1u)) v = -v;
-                    voff = f_off[t] + (unsigned)((gz - jzD) * rsB + gr * csB);
-                }
-                atomicAdd((double *)(gbase + voff), v);
-            }
-            if (!more) break;
-            l = ln; s_ = sn; t_ = tn;
-#pragma unroll
-            for (int t = 0; t < NTL; t++) { x_[t] = xn[t]; y_[t] = yn[t]; }
-        }
-    }
-#else
     __device__ __forceinline__ void scatter_strays(unsigned long long smJ, unsigned long long smR,
             int jkz, int jkr, int jnb, int rkz, int rkr, int rnb)
     {
@@ -596,7 +533,6 @@ struct CycleDep {
             }
         }
     }
-#endif
 };
 
 }  // namespace fb
