@@ -193,7 +193,9 @@ typedef ZCfg<256, 16, 256, 16, 16, 1, 1, 1> ZC256;
 typedef ZCfg<512, 8, 256, 8, 8, 8, 1, 1> ZC512;
 typedef ZCfg<1024, 4, 256, 16, 8, 8, 1, 1> ZC1024;
 // (round 6, measured at C2 - 1024 rows x 1024 / 1536 columns: two columns per 128-lane workgroup, <1024, 2, 128, ...>:
-// 24.4 / 20.0 us for the records / (p, m) launch against 22.7 / 18.8; eight columns per 512-lane workgroup: 28.3 / 19.5)
+// 24.4 / 20.0 us for the records / (p, m) launch against 22.7 / 18.8; eight columns per 512-lane workgroup: 28.3 / 19.5;
+// MORE WAVES on the same four-column tile - 8 points per lane, 512 lanes, radix 8 8 4 4: 20.8 / 16.4 - 17.1 against 21.0 /
+// 18.1; 4 points per lane, 1024 lanes, radix 4^5: 21.1 - 22.5 / 17.8 - the step unchanged, profiles/r06_zfft_waves_per_tile.txt)
 typedef ZCfg<2048, 2, 256, 16, 16, 8, 1, 1> ZC2048;
 typedef ZCfg<4096, 1, 256, 16, 16, 16, 1, 1> ZC4096;
 // 9 x 2^k (a power-of-two slab plus 2 x 64 guard cells, e.g. 1024 + 128): 4608 points per
