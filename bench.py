@@ -492,7 +492,8 @@ def main():
     out['extra'].update(side)
     if kern:
         out['roofline'], out['kernels'] = roofline(kern, ceil, {'C2': True, 'C5': 'c5'}.get(config_name(args, ppc, world), False))
-        dp_issue_floor(out['roofline'], kern, clocks_first or clocks_after, out['extra']['device'])
+        dp_issue_floor(out['roofline'], kern, clocks_first or clocks_after, out['extra']['device'],
+                       config_name(args, ppc, world))
         tb = out['roofline'].get('traffic_box')
         if out['roofline'].get('traffic') is not None:
             same = bool(tb) and tb.get('unique_id_suffix') == out['extra']['device'].get('unique_id_suffix')
@@ -690,7 +691,7 @@ def roofline(kern, ceil=None, profiled_workload=True):
     return roof, compact
 
 
-def dp_issue_floor(roof, kern, clocks, device):
+def dp_issue_floor(roof, kern, clocks, device, config=None):
     """The second, compute-side floor of the dominant particle kernel.  On gfx950 fp64 VALU instructions and
     fp64 MFMAs share ONE pipe per SIMD (tools/overlap_probe.hip): a wave64 VALU
     instruction occupies it for 4 cycles, v_mfma_f64_4x4x4 for 16.  With the instruction counts per chunk of
@@ -704,21 +705,29 @@ def dp_issue_floor(roof, kern, clocks, device):
         counts = json.load(open(os.path.join(ROOT, 'profiles', 'r06_dp_issue_counts.json')))
     except (OSError, ValueError):
         return
-    c = counts.get(roof['kernel'])
     sclk = (clocks or {}).get('sclk_MHz')
-    if not c or roof['kernel'] not in kern:
-        return
-    recs = kern[roof['kernel']]
-    npart = sum(r[1][2] for r in recs) / len(recs)
-    chunks = (npart + 63) // 64
     cus = device.get('compute_units', 256)
-    cyc = chunks * (4.0 * c['valu_per_chunk'] + c['mfma_cycles_per_chunk']) / (cus * 4)
-    for label, mhz in (('', sclk), ('_at_2400MHz', 2400)):
-        if mhz:
-            us = cyc / mhz
-            roof['dp_issue_floor_us' + label] = us
-            roof['frac_of_dp_floor' + label] = us / (1e3 * roof['mean_launch_ms'])
-    roof['dp_issue_counts'] = c
+    cfg = None if config is None else str(config).split('-per-rank')[0]      # ('C2-per-rank x8': N slabs of C2)
+
+    def price(target, entry, mean_ms):
+        # (the counts of an entry point belong to ONE template instance: those of another configuration's are not used)
+        c = counts.get(entry)
+        if not c or entry not in kern or not mean_ms or c.get('config', cfg) != cfg:
+            return
+        recs = kern[entry]
+        npart = sum(r[1][2] for r in recs) / len(recs)
+        chunks = (npart + 63) // 64
+        cyc = chunks * (4.0 * c['valu_per_chunk'] + c['mfma_cycles_per_chunk']) / (cus * 4)
+        for label, mhz in (('', sclk), ('_at_2400MHz', 2400)):
+            if mhz:
+                us = cyc / mhz
+                target['dp_issue_floor_us' + label] = us
+                target['frac_of_dp_floor' + label] = us / (1e3 * mean_ms)
+        target['dp_issue_counts'] = c
+    price(roof, roof['kernel'], roof.get('mean_launch_ms'))
+    # C5: the first pass of its two (roofline.gather_push) next to the dominant second one
+    if isinstance(roof.get('gather_push'), dict):
+        price(roof['gather_push'], 'fb_gather_push_rank_next', roof['gather_push'].get('mean_ms'))
 
 
 # entry point -> substrings identifying its dominant device kernel in the rocprofv3 summaries
