@@ -715,7 +715,7 @@ def dp_issue_floor(roof, kern, clocks, device, config=None):
         if not c or entry not in kern or not mean_ms or c.get('config', cfg) != cfg:
             return
         recs = kern[entry]
-        npart = sum(r[1][2] for r in recs) / len(recs)
+        npart = sum(r[1][c.get('n_arg', 2)] for r in recs) / len(recs)
         chunks = (npart + 63) // 64
         cyc = chunks * (4.0 * c['valu_per_chunk'] + c['mfma_cycles_per_chunk']) / (cus * 4)
         for label, mhz in (('', sclk), ('_at_2400MHz', 2400)):
