@@ -593,7 +593,7 @@ static int launch_perm_J_rho(long n, double q, double c, const DepGeom &gJ, cons
     const long target_waves = 256L * 64;
     int cpw = (int)((nchunks + target_waves - 1) / target_waves);
     if (cpw < 1) cpw = 1;
-    if (cpw > 64) cpw = 64;
+    if (cpw > fb_cpw_cap(16)) cpw = fb_cpw_cap(16);
     const long total_waves = (nchunks + cpw - 1) / cpw;
     const long nblocks = xcd_grid((total_waves + nwaves - 1) / nwaves);
     hipLaunchKernelGGL((k_perm_deposit_J_rho<SHAPE, NM>), dim3((unsigned)nblocks), dim3(64 * nwaves),
@@ -612,7 +612,7 @@ static int launch_perm_J_rho_merged(long n, double q, double c, const DepGeom &g
     const long target_waves = 256L * 64;
     int cpw = (int)((nchunks + target_waves - 1) / target_waves);
     if (cpw < 1) cpw = 1;
-    if (cpw > 64) cpw = 64;
+    if (cpw > fb_cpw_cap(16)) cpw = fb_cpw_cap(16);
     const long total_waves = (nchunks + cpw - 1) / cpw;
     const long nblocks = xcd_grid((total_waves + nwaves - 1) / nwaves);
     hipLaunchKernelGGL((k_perm_deposit_J_rho_merged<NM>), dim3((unsigned)nblocks), dim3(64 * nwaves),

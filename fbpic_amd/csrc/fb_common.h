@@ -2,6 +2,7 @@
 // Whole library is compiled with -ffp-contract=off: cell indices must be bit-identical
 // to the reference CPU path (invdr*(r-rmin)-0.5 must not fuse into an FMA).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/fbpic_amd.h"
@@ -161,6 +162,17 @@ int bin_sort_prepare(const char *who, bool push, bool preranked, const PushX &P,
         void *workspace, size_t workspace_bytes, BinSortWs *Wout, hipStream_t s);
 int bin_sort_build_sidx(const char *who, long n, int ncell, const BinSortWs &W, const int *prefix_sum,
                         int *sidx, hipStream_t s);
+
+// Longest range of 64-particle chunks one wave of a particle kernel walks (launches aim at 16384 waves and lengthen the
+// ranges beyond that).  Round 6, C5 (1 M chunks): ranges of 64 chunks make a wave last ~1 ms of a 5 ms launch, and the last
+// generation of waves leaves the chip half empty - gather + push + rank 5.07 -> 4.77 ms with ranges of 8, the sorting
+// deposition pass 5.64 -> 5.46 with 16 (32: 5.44, 8: 5.62), profiles/r06_range_per_wave.txt.  FBPIC_AMD_CPW_CAP overrides
+// every kernel's cap (developer knob for such scans).
+inline int fb_cpw_cap(int dflt)
+{
+    static const int e = getenv("FBPIC_AMD_CPW_CAP") ? atoi(getenv("FBPIC_AMD_CPW_CAP")) : 0;
+    return e > 0 ? e : dflt;
+}
 
 }  // namespace fb
 

@@ -890,7 +890,7 @@ static int launch_gather_cubic_mx(long n, const double *x, const double *y, cons
     const long target_waves = 256L * 64;
     int cpw = (int)((nchunks + target_waves - 1) / target_waves);
     if (cpw < 1) cpw = 1;
-    if (cpw > 64) cpw = 64;
+    if (cpw > fb_cpw_cap(8)) cpw = fb_cpw_cap(8);
     const long total_waves = (nchunks + cpw - 1) / cpw;
     dim3 grid((unsigned)xcd_grid((total_waves + nwaves - 1) / nwaves)), block(64 * nwaves);
     hipLaunchKernelGGL((k_gather_cubic_mx<NMT>), grid, block, wave_bytes * nwaves, s, n, x, y, z,
