@@ -64,12 +64,7 @@ struct CycleArgs {
     long rsR;
     cplx *baseJ, *baseR;                       // dep_grids_base() of the two targets
     const double *beta0, *betah;               // Ruyten coefficients, mode 0 / modes >= 1
-    int chunks_per_wave;
-    // Graded ranges (one-wave workgroups only): of the waves of an XCD - which start in the order of their index - the
-    // first `long_waves` walk `chunks_per_wave` chunks each, the others `short_cpw`; `chunks_per_xcd` chunks belong to
-    // an XCD, the first `long_chunks` of them to its long waves.  long_waves < 0: every wave walks chunks_per_wave.
-    int long_waves, short_cpw;
-    long chunks_per_xcd, long_chunks;
+    WaveRanges rg;                             // range of chunks of every wave (graded_ranges, fb_common.h)
     unsigned long long *stats;                 // optional: [0, 512) strays of the J deposition, [512, 1024) chunks
                                                // with more than FB_CYCLE_BAD_CHUNK of them
     // RANK mode (fb_gather_push_rank_next_home): no deposition; x is left at x(n+1/2) and the cell
@@ -377,26 +372,9 @@ __device__ __forceinline__ void cycle_linear_body(const CycleArgs &A)
     };
 
     // range of chunks of this wave: [chunk0, chunk0 + cpw_w)
-    long chunk0 = (xcd_block_id() * nwaves + wave) * A.chunks_per_wave;
-    int cpw_w = A.chunks_per_wave;
-    if (A.long_waves >= 0) {
-        // The waves of a launch end one wave duration apart, and the last generation leaves the chip half empty for
-        // that long: the waves that start LAST (highest index within their XCD) walk short ranges, the others long
-        // ones (whose per-wave prologue - ~540 instructions - is what forbids short ranges everywhere).
-        const long xcd = blockIdx.x % FB_NXCD, j = blockIdx.x / FB_NXCD;
-        const long c0x = xcd * A.chunks_per_xcd;
-        if (j < A.long_waves) {
-            const long o = j * A.chunks_per_wave;
-            chunk0 = c0x + o;
-            cpw_w = (int)max(0L, min((long)A.chunks_per_wave, A.long_chunks - o));
-        } else {
-            const long o = A.long_chunks + (j - A.long_waves) * A.short_cpw;
-            chunk0 = c0x + o;
-            cpw_w = (int)max(0L, min((long)A.short_cpw, A.chunks_per_xcd - o));
-        }
-        cpw_w = __builtin_amdgcn_readfirstlane(cpw_w);
-        if (cpw_w <= 0) return;
-    }
+    long chunk0;
+    int cpw_w;
+    if (!wave_range(A.rg, nwaves, wave, chunk0, cpw_w)) return;
     long base = chunk0 * 64;
     if (base >= n) return;
     // Software pipeline.  Every wait of this kernel for vector memory is ONE s_waitcnt vmcnt(0) per
@@ -845,29 +823,10 @@ static int launch_cycle_linear(const CycleArgs &A0, hipStream_t s)
     }
     if (cpw < 1) cpw = 1;
     if (cpw > 64) cpw = 64;
-    A.chunks_per_wave = cpw;
-    A.long_waves = -1; A.short_cpw = cpw; A.chunks_per_xcd = 0; A.long_chunks = 0;
-    const long total_waves = (nchunks + cpw - 1) / cpw;
-    long nblocks = xcd_grid((total_waves + nwaves - 1) / nwaves);
-    {
-        // graded ranges (see the kernel): the last eighth of an XCD's chunks in ranges of 2 chunks.  Measured
-        // (profiles/r06_graded_ranges.txt): the launch 0.234 -> 0.229 ms at C2 (ranges of 4), 0.82 -> 0.745 ms at C3
-        // (ranges of 10).  (FBPIC_AMD_CYCLE_TAIL = "<share denominator>,<short>": developer override; 0 = off)
-        static const char *env = getenv("FBPIC_AMD_CYCLE_TAIL");
-        int den = 8, shrt = 2;
-        if (env) { den = atoi(env); const char *c = strchr(env, ','); shrt = c ? atoi(c + 1) : 1; }
-        if (!RANK && SHAPE == FB_SHAPE_LINEAR && nwaves == 1 && den > 0 && shrt > 0 && shrt < cpw) {
-            const long cx = (nchunks + FB_NXCD - 1) / FB_NXCD;            // chunks of an XCD
-            long tail = cx / den;
-            tail = (tail + shrt - 1) / shrt * shrt;                       // whole short ranges
-            if (tail > 0 && tail < cx) {
-                const long lc = cx - tail;
-                const long lw = (lc + cpw - 1) / cpw, sw = tail / shrt;
-                A.long_waves = (int)lw; A.short_cpw = shrt; A.chunks_per_xcd = cx; A.long_chunks = lc;
-                nblocks = FB_NXCD * (lw + sw);
-            }
-        }
-    }
+    // graded ranges for the linear kernels (both forms): the launch 0.234 -> 0.229 ms at C2 (ranges of 4 chunks), 0.83 ->
+    // 0.745 ms at C3 (ranges of 10), profiles/r06_graded_ranges.txt; the cubic kernel keeps the plain cut
+    long nblocks;
+    A.rg = graded_ranges(nchunks, cpw, nwaves, &nblocks, SHAPE == FB_SHAPE_LINEAR ? 8 : 0);
     if constexpr (SHAPE == FB_SHAPE_CUBIC)
         hipLaunchKernelGGL((k_cycle_cubic<NM, WIDE>), dim3((unsigned)nblocks), dim3(64 * nwaves),
                            wave_bytes * nwaves, s, A);
@@ -988,7 +947,7 @@ static int cycle_entry(const char *who, bool rank, int shape, int Nm, long n,
         if (!A.baseJ) wide = true;
     }
     A.beta0 = ruyten_m0; A.betah = ruyten_mh;
-    A.chunks_per_wave = 1;
+    A.rg = WaveRanges{1, -1, 1, 0, 0};
     A.stats = stats;
     A.rk_cell = rk_cell; A.rk_rank = rk_rank; A.rk_count = rk_count;
     hipStream_t s = (hipStream_t)stream;

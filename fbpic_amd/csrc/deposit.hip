@@ -193,7 +193,7 @@ template <int SHAPE, int NM>
 __global__ __launch_bounds__(256) void k_perm_deposit_J_rho(long n, double q, double c_light,
         DepGeom gJ, DepGeom gR, DepGrids GJ, long rsJ, DepGrids GR, long rsR,
         const double *__restrict__ beta0, const double *__restrict__ betah,
-        int chunks_per_wave, PermArgs PM)
+        WaveRanges RG, PermArgs PM)
 {
     using P = FusedPlan<SHAPE, NM>;
     using EJ = typename P::EJ;
@@ -207,7 +207,9 @@ __global__ __launch_bounds__(256) void k_perm_deposit_J_rho(long n, double q, do
     ej.init(lds + (size_t)wave * WAVE_DOUBLES, lane, GJ, rsJ, 0, gJ.Nz, gJ.Nr);
     er.init(lds + (size_t)wave * WAVE_DOUBLES, lane, GR, rsR, 0, gR.Nz, gR.Nr);
 
-    const long chunk0 = (xcd_block_id() * nwaves + wave) * chunks_per_wave;
+    long chunk0;
+    int chunks_per_wave;
+    if (!wave_range(RG, nwaves, wave, chunk0, chunks_per_wave)) return;
     double pn[8];
     int idx_n = 0, idx_c = 0, idx_nn = 0;
     auto prefetch = [&](long ip) {
@@ -279,7 +281,7 @@ template <int NM>
 __global__ __launch_bounds__(256) void k_perm_deposit_J_rho_merged(long n, double q, double c_light,
         DepGeom g, DepGrids GJ, DepGrids GR, long rs, cplx *gbase,
         const double *__restrict__ beta0, const double *__restrict__ betah,
-        int chunks_per_wave, PermArgs PM)
+        WaveRanges RG, PermArgs PM)
 {
     using ED = CycleDep<NM>;
     extern __shared__ double lds[];
@@ -288,7 +290,9 @@ __global__ __launch_bounds__(256) void k_perm_deposit_J_rho_merged(long n, doubl
     ED ed;
     ed.init(lds + (size_t)wave * ED::L::WAVE_DOUBLES, lane, GJ, rs, GR, rs, g.Nz, g.Nr, gbase);
 
-    const long chunk0 = (xcd_block_id() * nwaves + wave) * chunks_per_wave;
+    long chunk0;
+    int chunks_per_wave;
+    if (!wave_range(RG, nwaves, wave, chunk0, chunks_per_wave)) return;
     double pn[8];
     // (lanes beyond the last particle stage a harmless particle of weight 0)
     pn[0] = 1. / g.invdr; pn[1] = 0.; pn[2] = g.zmin + 1. / g.invdz; pn[3] = 0.; pn[4] = 0.; pn[5] = 0.; pn[6] = 0.; pn[7] = 1.;
@@ -594,10 +598,12 @@ static int launch_perm_J_rho(long n, double q, double c, const DepGeom &gJ, cons
     int cpw = (int)((nchunks + target_waves - 1) / target_waves);
     if (cpw < 1) cpw = 1;
     if (cpw > fb_cpw_cap(16)) cpw = fb_cpw_cap(16);
-    const long total_waves = (nchunks + cpw - 1) / cpw;
-    const long nblocks = xcd_grid((total_waves + nwaves - 1) / nwaves);
+    // graded ranges for the linear shape (C3: 0.75 -> 0.69 ms per launch); the cubic pass keeps the plain cut - its waves pay two
+    // cubic engine set-ups, and short ranges at the end measured 5.41 -> 5.56 ms at C5 (profiles/r06_graded_ranges.txt)
+    long nblocks;
+    const WaveRanges RG = graded_ranges(nchunks, cpw, nwaves, &nblocks, SHAPE == FB_SHAPE_LINEAR ? 8 : 0);
     hipLaunchKernelGGL((k_perm_deposit_J_rho<SHAPE, NM>), dim3((unsigned)nblocks), dim3(64 * nwaves),
-                       wave_bytes * nwaves, s, n, q, c, gJ, gR, GJ, rsJ, GR, rsR, b0, bh, cpw, PM);
+                       wave_bytes * nwaves, s, n, q, c, gJ, gR, GJ, rsJ, GR, rsR, b0, bh, RG, PM);
     return check(hipGetLastError(), "fb_push_x_sort_deposit_J_rho");
 }
 
@@ -613,10 +619,10 @@ static int launch_perm_J_rho_merged(long n, double q, double c, const DepGeom &g
     int cpw = (int)((nchunks + target_waves - 1) / target_waves);
     if (cpw < 1) cpw = 1;
     if (cpw > fb_cpw_cap(16)) cpw = fb_cpw_cap(16);
-    const long total_waves = (nchunks + cpw - 1) / cpw;
-    const long nblocks = xcd_grid((total_waves + nwaves - 1) / nwaves);
+    long nblocks;
+    const WaveRanges RG = graded_ranges(nchunks, cpw, nwaves, &nblocks);
     hipLaunchKernelGGL((k_perm_deposit_J_rho_merged<NM>), dim3((unsigned)nblocks), dim3(64 * nwaves),
-                       wave_bytes * nwaves, s, n, q, c, g, GJ, GR, rs, gbase, b0, bh, cpw, PM);
+                       wave_bytes * nwaves, s, n, q, c, g, GJ, GR, rs, gbase, b0, bh, RG, PM);
     return check(hipGetLastError(), "fb_push_x_sort_deposit_J_rho");
 }
 

@@ -3,6 +3,7 @@
 // to the reference CPU path (invdr*(r-rmin)-0.5 must not fuse into an FMA).
 #pragma once
 #include <cstdlib>
+#include <cstring>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/fbpic_amd.h"
@@ -72,6 +73,56 @@ __device__ __forceinline__ long xcd_block_id()
 {
     const long per = gridDim.x / FB_NXCD;
     return (long)(blockIdx.x % FB_NXCD) * per + blockIdx.x / FB_NXCD;
+}
+#endif
+
+// GRADED ranges of 64-particle chunks for the particle kernels that walk ranges (one-wave workgroups).  The waves of a
+// launch end one wave duration apart, and once the dispatcher has handed out its last workgroup the chip drains for that
+// long (C3: a wave of 10 chunks lasts a fifth of the launch).  Workgroups start in the order of their index within an
+// XCD, so the waves with the HIGHEST indices - the last 1 / den of an XCD's chunks - walk `short_cpw` chunks each and
+// the others `cpw` (short ranges everywhere would pay the per-wave prologue of these kernels for every chunk or two).
+// A static cut: no atomics, every chunk belongs to exactly one wave.  long_waves < 0: the plain cut (every wave `cpw`
+// chunks, workgroups of any number of waves).  profiles/r06_graded_ranges.txt.
+struct WaveRanges {
+    int cpw, long_waves, short_cpw;
+    long chunks_per_xcd, long_chunks;      // chunks of an XCD; those of its long waves
+};
+// (FBPIC_AMD_CYCLE_TAIL = "<den>,<short>": developer override for scans; "0" = plain cut)
+inline WaveRanges graded_ranges(long nchunks, int cpw, int nwaves, long *nblocks, int den = 8, int shrt = 2)
+{
+    static const char *env = getenv("FBPIC_AMD_CYCLE_TAIL");
+    if (env && *env) { den = atoi(env); const char *c = strchr(env, ','); shrt = c ? atoi(c + 1) : 1; }
+    WaveRanges R = {cpw, -1, cpw, 0, 0};
+    const long total_waves = (nchunks + cpw - 1) / cpw;
+    *nblocks = xcd_grid((total_waves + nwaves - 1) / nwaves);
+    if (nwaves == 1 && den > 0 && shrt > 0 && shrt < cpw) {
+        const long cx = (nchunks + FB_NXCD - 1) / FB_NXCD;
+        long tail = cx / den;
+        tail = (tail + shrt - 1) / shrt * shrt;                           // whole short ranges
+        if (tail > 0 && tail < cx) {
+            const long lc = cx - tail, lw = (lc + cpw - 1) / cpw, sw = tail / shrt;
+            R.long_waves = (int)lw; R.short_cpw = shrt; R.chunks_per_xcd = cx; R.long_chunks = lc;
+            *nblocks = FB_NXCD * (lw + sw);
+        }
+    }
+    return R;
+}
+#ifdef __HIPCC__
+// first chunk and number of chunks of this wave; false: nothing to do (a wave beyond the end of its XCD's chunks)
+__device__ __forceinline__ bool wave_range(const WaveRanges &R, int nwaves, int wave, long &chunk0, int &nch)
+{
+    chunk0 = (xcd_block_id() * nwaves + wave) * R.cpw;
+    nch = R.cpw;
+    if (R.long_waves >= 0) {
+        const long xcd = blockIdx.x % FB_NXCD, j = blockIdx.x / FB_NXCD;
+        const bool lng = j < R.long_waves;
+        const long o = lng ? j * R.cpw : R.long_chunks + (j - R.long_waves) * R.short_cpw;
+        const long room = (lng ? R.long_chunks : R.chunks_per_xcd) - o;
+        chunk0 = xcd * R.chunks_per_xcd + o;
+        nch = (int)max(0L, min((long)(lng ? R.cpw : R.short_cpw), room));
+        nch = __builtin_amdgcn_readfirstlane(nch);
+    }
+    return nch > 0;
 }
 #endif
 

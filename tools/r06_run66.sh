@@ -1,0 +1,12 @@
+#!/bin/bash
+# round 6, GPU run 66: graded ranges in every range kernel (default) against the plain cut (FBPIC_AMD_CYCLE_TAIL=0), same box, alternating
+cd /root/repo; export TMPDIR=/tmp
+O=gpurun_out/r06_v10; mkdir -p $O
+line() { LBL="$1" python -c "
+import json,sys,os; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); k=d['kernels']; print(os.environ['LBL'], round(d['ms_per_step'],4), [round(x,4) for x in d.get('extra',{}).get('repeat_ms_per_step',[])], {n: round(k[n]['mean_ms'],4) for n in ('fb_gather_push_deposit_J_rho','fb_gather_push_rank_next_home','fb_push_x_sort_deposit_J_rho','fb_gather_push_rank_next') if n in k})" | tee -a $O/scan_ab.txt; }
+for t in graded plain graded plain; do
+  if [ $t = plain ]; then export FBPIC_AMD_CYCLE_TAIL=0; else unset FBPIC_AMD_CYCLE_TAIL; fi
+  python bench.py --steps 40 --warmup 20 --no-cpu-baseline --no-side-legs 2>/dev/null | line "C2 40/20 $t"
+  python bench.py --config C3 --no-cpu-baseline --no-side-legs 2>/dev/null | line "C3 $t"
+done
+export FBPIC_AMD_CYCLE_TAIL=0; python bench.py --config C5 --no-cpu-baseline --no-side-legs 2>/dev/null | line "C5 plain"
